@@ -1,0 +1,213 @@
+"""CPU suite (-m "not gpu"): pins the oracle (oracle/) against
+
+  * the reference's own known answers (model/DCNv2/test.py:32-65) and closed forms, and
+  * tests/golden/*.npz, produced by tools/gen_golden.py from the reference's own Python
+    (model graph, lib/rpn_util helpers, lib/nms/py_cpu_nms.py, im_detect_3d).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from m3dssd_amd import rpn_util, synth
+from oracle import anchors as oanch
+from oracle import dcn as odcn
+from oracle import detect as odet
+from oracle import model_cpu
+from oracle import nms as onms
+
+torch.set_num_threads(max(1, os.cpu_count() or 1))
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+# ----------------------------------------------------------------------------- DCNv2 op
+def test_dcn_zero_offset_identity_known_answer():
+    """model/DCNv2/test.py:32-65: zero offsets, mask = sigmoid(0) = 0.5, identity 3x3 weight
+    => 2 * output == input."""
+    torch.manual_seed(0)
+    N, C, H, W = 2, 2, 4, 4
+    x = torch.randn(N, C, H, W)
+    w = torch.zeros(C, C, 3, 3)
+    for c in range(C):
+        w[c, c, 1, 1] = 1.0
+    off = torch.zeros(N, 18, H, W)
+    mask = torch.sigmoid(torch.zeros(N, 9, H, W))
+    out = odcn.dcn_v2_forward(x, off, mask, w, torch.zeros(C), 1, 1, 1, 1)
+    assert (x - out * 2).abs().max().item() < 1e-10
+
+
+@pytest.mark.parametrize("k,pad,stride,dil", [(3, 1, 1, 1), (1, 0, 1, 1), (3, 1, 2, 1), (3, 2, 1, 2), (3, 0, 1, 1)])
+def test_dcn_zero_offset_unit_mask_is_conv2d(k, pad, stride, dil):
+    torch.manual_seed(1)
+    x = torch.randn(2, 5, 9, 11)
+    w = torch.randn(7, 5, k, k)
+    b = torch.randn(7)
+    ho, wo = odcn.out_size(9, 11, k, k, stride, pad, dil)
+    off = torch.zeros(2, 2 * k * k, ho, wo)
+    m = torch.ones(2, k * k, ho, wo)
+    out = odcn.dcn_v2_forward(x, off, m, w, b, stride, pad, dil, 1)
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad, dilation=dil)
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max().item() < 1e-4
+
+
+def test_dcn_integer_offsets_are_a_shifted_conv():
+    torch.manual_seed(2)
+    x = torch.randn(1, 3, 8, 10)
+    w = torch.randn(4, 3, 3, 3)
+    b = torch.zeros(4)
+    off = torch.zeros(1, 18, 8, 10)
+    off[:, 0::2] = 2.0      # dh for every tap
+    off[:, 1::2] = -3.0     # dw
+    out = odcn.dcn_v2_forward(x, off, torch.ones(1, 9, 8, 10), w, b, 1, 1, 1, 1)
+    # tap (i, j) of output (y, x) samples the zero-extended input at (y - 1 + i + 2, x - 1 + j - 3):
+    # with xp = x zero-padded by 4, that is xp[y + 5 + i, x + j] -> a plain conv over a window of xp
+    xp = F.pad(x, (4, 4, 4, 4))
+    ref = F.conv2d(xp[:, :, 5:5 + 10, 0:12], w, b)
+    assert ref.shape == out.shape
+    assert (out - ref).abs().max().item() < 1e-4
+
+
+def test_dcn_mask_linearity_and_c_vs_numpy_with_out_of_range_samples():
+    torch.manual_seed(3)
+    x = torch.randn(2, 4, 6, 7)
+    w = torch.randn(5, 4, 3, 3)
+    b = torch.randn(5)
+    off = torch.randn(2, 18, 6, 7) * 4.0          # many samples land outside [-1, H) x [-1, W)
+    off[0, 0, 0, 0] = -1.0                         # h_im exactly -1 for tap 0 at (0,0): gate is strict (> -1)
+    m = torch.rand(2, 9, 6, 7)
+    a = odcn.dcn_v2_forward(x, off, m, w, b, 1, 1, 1, 1)
+    r = odcn.dcn_v2_forward_numpy(x.numpy(), off.numpy(), m.numpy(), w.numpy(), b.numpy(), 1, 1, 1)
+    assert np.abs(a.numpy() - r).max() < 2e-5
+    a2 = odcn.dcn_v2_forward(x, off, 2 * m, w, torch.zeros(5), 1, 1, 1, 1)
+    a1 = odcn.dcn_v2_forward(x, off, m, w, torch.zeros(5), 1, 1, 1, 1)
+    assert (a2 - 2 * a1).abs().max().item() < 1e-4
+
+
+def test_dcn_rejects_channel_mismatch():
+    with pytest.raises(RuntimeError):
+        odcn.dcn_v2_forward(torch.zeros(1, 3, 4, 4), torch.zeros(1, 18, 4, 4), torch.zeros(1, 9, 4, 4),
+                            torch.zeros(2, 4, 3, 3), torch.zeros(2), 1, 1, 1, 1)
+
+
+# ----------------------------------------------------------------------------- NMS
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 300, 3000])
+def test_nms_matches_reference_py_cpu_nms(golden_dir, n):
+    g = _load(golden_dir, "nms.npz")
+    dets, keep = g["dets_%d" % n], g["keep_%d" % n]
+    assert np.array_equal(np.asarray(onms.gpu_nms(dets, 0.4), dtype=np.int64), keep)
+    assert np.array_equal(np.asarray(onms.nms_numpy(dets, 0.4), dtype=np.int64), keep)
+
+
+@pytest.mark.parametrize("thr", [0.0, 0.25, 0.4, 0.5, 1.0])
+def test_nms_threshold_ties_on_grid_boxes(golden_dir, thr):
+    g = _load(golden_dir, "nms.npz")
+    dets, keep = g["dets_grid"], g["keep_grid_%g" % thr]
+    assert np.array_equal(np.asarray(onms.gpu_nms(dets, thr), dtype=np.int64), keep)
+
+
+def test_nms_empty_and_synth_recipe_is_stable():
+    assert onms.gpu_nms(np.zeros((0, 5), dtype=np.float32), 0.4) == []
+    a, b = synth.synth_boxes(100, 5), synth.synth_boxes(100, 5)
+    assert np.array_equal(a, b) and len(np.unique(a[:, 4])) == 100
+
+
+# ----------------------------------------------------------------------------- anchors / rois
+def test_anchor_helpers_match_reference(golden_dir):
+    g = _load(golden_dir, "anchors.npz")
+    conf = synth.synth_conf((384, 1280), 0)
+    for mod in (rpn_util, oanch):
+        a2d = mod.generate_anchors_2d(conf.anchor_scales, conf.anchor_ratios, 8)
+        assert np.array_equal(a2d, g["anchors_2d"])
+        assert np.array_equal(mod.calc_output_size(np.array([384, 1280]), 8), g["out_size"])
+        assert np.array_equal(mod.calc_output_size(np.array([370, 1225]), 8), g["out_size_odd"])
+    r = rpn_util.locate_anchors(conf.anchors, [4, 6], 8, convert_tensor=True)
+    assert r.dtype == torch.float64 and np.array_equal(r.numpy(), g["rois_4x6"])
+    assert np.array_equal(rpn_util.locate_anchors(conf.anchors, [4, 6], 8), g["rois_4x6_np"])
+    assert np.array_equal(oanch.locate_anchors(conf.anchors, [4, 6], 8), g["rois_4x6"])
+    full = rpn_util.locate_anchors(conf.anchors, [48, 160], 8, convert_tensor=True).float()
+    assert np.array_equal(full[::997].numpy(), g["rois_full_rows"])
+    chk = g["rois_full_chk"]
+    assert full.double().sum().item() == chk[0] and full.numel() == chk[2]
+    assert np.array_equal(rpn_util.flatten_tensor(torch.from_numpy(g["flat_in"])).numpy(), g["flat_out"])
+
+
+def test_state_dict_contract_size():
+    spec = synth.param_spec()
+    assert len(spec) == 542
+    sd = synth.synth_state_dict(0)
+    n = sum(v.numel() for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k)
+    assert n == 20726180       # parameter count of the imported reference model
+    assert list(sd) == list(spec)
+
+
+# ----------------------------------------------------------------------------- whole forward
+def _close(a, b, tol):
+    return np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max() <= tol
+
+
+def test_model_small_matches_reference(golden_dir):
+    g = _load(golden_dir, "model_128x320_b2.npz")
+    conf = synth.synth_conf((128, 320), 0, batch_size=2, device="cpu")
+    sd = synth.synth_state_dict(0)
+    x = synth.synth_frames(2, (128, 320), 1234)
+    taps = {}
+    with torch.no_grad():
+        cls, prob, b2, b3, fs, rois = model_cpu.rpn_forward(sd, conf, x, taps)
+    rs = int(g["row_stride"])
+    # same torch primitives in the same order -> expect (near) bit equality; tolerance covers
+    # thread-count dependent reduction order inside BLAS/oneDNN
+    for name, t in (("cls", cls), ("prob", prob), ("bbox_2d", b2), ("bbox_3d", b3)):
+        assert _close(t[:, ::rs].numpy(), g[name], 2e-4), name
+        chk = g["chk." + name]
+        assert abs(t.double().abs().sum().item() - chk[1]) <= 1e-5 * chk[1] and t.numel() == chk[2]
+    assert np.array_equal(rois[::rs].numpy(), g["rois"])
+    assert np.array_equal(fs.numpy(), g["feat_size"])
+    for key in g.files:
+        if key.startswith("tap."):
+            assert _close(taps[key[4:]][:, ::8].numpy(), g[key], 2e-4), key
+    # both branches of the hard mask are exercised by the synthetic recipe
+    hard = taps["shape_align.hard"].mean().item()
+    assert 0.2 < hard < 0.8
+
+
+def test_model_full_size_matches_reference_samples(golden_dir):
+    g = _load(golden_dir, "model_384x1280_b1.npz")
+    conf = synth.synth_conf((384, 1280), 0, batch_size=1, device="cpu")
+    sd = synth.synth_state_dict(0)
+    x = synth.synth_frames(1, (384, 1280), 1234, pad_right_third=True)
+    taps = {}
+    with torch.no_grad():
+        cls, prob, b2, b3, fs, rois = model_cpu.rpn_forward(sd, conf, x, taps)
+    st = int(g["stride"])
+    assert cls.shape == (1, 276480, 4) and b3.shape == (1, 276480, 7) and rois.shape == (276480, 5)
+    for name, t in (("cls", cls), ("prob", prob), ("bbox_2d", b2), ("bbox_3d", b3)):
+        assert _close(t[:, ::st].numpy(), g[name], 5e-4), name
+        chk = g["chk." + name]
+        assert abs(t.double().abs().sum().item() - chk[1]) <= 1e-5 * chk[1]
+    for key in g.files:
+        if key.startswith("tap."):
+            assert _close(taps[key[4:]][:, ::16, ::3, ::5].numpy(), g[key], 5e-4), key
+
+
+# ----------------------------------------------------------------------------- decode + NMS
+@pytest.mark.parametrize("crop,name", [((128, 320), "detect_128x320.npz"), ((384, 1280), "detect_384x1280.npz")])
+def test_detect_matches_reference_im_detect_3d(golden_dir, crop, name):
+    g = _load(golden_dir, name)
+    b = 2 if crop[0] == 128 else 1
+    conf = synth.synth_conf(crop, 0, batch_size=b, device="cpu")
+    sd = synth.synth_state_dict(0)
+    x = synth.synth_frames(b, crop, 1234, pad_right_third=(crop[0] == 384))
+    with torch.no_grad():
+        cls, prob, b2, b3, fs, rois = model_cpu.rpn_forward(sd, conf, x)
+    ab, keep, top = odet.detect_image(prob[0], b2[0], b3[0], rois, conf)
+    ref = g["aboxes"]
+    assert ab.shape == ref.shape
+    # kept anchors identical (col 13 = anchor id, col 5 = class), coordinates to fp32 roundoff
+    assert np.array_equal(ab[:, 13], ref[:, 13]) and np.array_equal(ab[:, 5], ref[:, 5])
+    assert np.abs(ab - ref).max() < 1e-3 * max(1.0, np.abs(ref).max())
