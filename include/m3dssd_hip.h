@@ -1,0 +1,202 @@
+/*
+ * m3dssd_hip.h -- C ABI of libm3dssd_hip.so: the MI355X (gfx950) native hot path of M3DSSD.
+ *
+ * Plain pointers and sizes only (no torch types).  All device pointers are BORROWED (the
+ * caller -- torch, or any other allocator -- owns them); nothing here allocates device
+ * memory except the legacy host-pointer `_nms` twin, which mirrors the reference's own
+ * behaviour.  Every entry point is stream-ordered on the `hipStream_t` it is given,
+ * re-entrant per stream, and returns an int status: 0 = ok, <0 = M3D_E_* (the host layer
+ * maps these to Python RuntimeError, like THError/THArgCheck did in the reference).
+ *
+ * Reference interfaces replaced (paths relative to mumianyuxin/M3DSSD):
+ *   m3d_dcn_v2_forward ......... void dcn_v2_cuda_forward(THCudaTensor *input, *weight, *bias, *ones,
+ *                                 *offset, *mask, *output, *columns, kernel_h, kernel_w, stride_h,
+ *                                 stride_w, pad_h, pad_w, dilation_h, dilation_w, deformable_group)
+ *                                 model/DCNv2/src/dcn_v2_cuda.h:9-17, dcn_v2_cuda.c:10-102,
+ *                                 kernel model/DCNv2/src/cuda/dcn_v2_im2col_cuda.cu:118-180
+ *   _nms / m3d_nms_sorted_dev .. void _nms(int* keep_out, int* num_out, const float* boxes_host,
+ *                                 int boxes_num, int boxes_dim, float nms_overlap_thresh, int device_id)
+ *                                 lib/nms/gpu_nms.hpp:1-2, lib/nms/nms_kernel.cu:91-144 (kernel :34-78)
+ *   m3d_conv2d_forward ......... the cuDNN/ATen nn.Conv2d + BatchNorm2d(eval) + LeakyReLU + residual
+ *                                 chains of model/pose_dla_dcn.py:107-121,261-269,379-389 and the RPN
+ *                                 heads model/M3d_inference_align.py:66-210, plus (deformable mode)
+ *                                 the fused im2col+GEMM of dcn_v2_cuda.c:80-96 without `columns`
+ *   m3d_stem_conv7x7 ........... DLA.base_layer, model/pose_dla_dcn.py:336-340
+ *   m3d_maxpool2x2 ............. Tree.downsample nn.MaxPool2d(2,2), pose_dla_dcn.py:306,316
+ *   m3d_upsample2x_add ......... IDAUp: depthwise ConvTranspose2d(4, s2, p1) + skip add,
+ *                                 pose_dla_dcn.py:536-538,550-552
+ *   m3d_anchor_select .......... softmax over classes + fg_prob + topk(k=1)/max/hard mask,
+ *                                 M3d_inference_align.py:229-234, feturealign_mgpu.py:58-62,160-164
+ *   m3d_align_offsets .......... offset/mask synthesis of shape_align (feturealign_mgpu.py:119-136,
+ *                                 166-183) and center_align (:67-89)
+ *   m3d_anab_pool* ............. PAPAModule weighted adaptive average pooling, attention.py:136-147
+ *   m3d_softmax_rows ........... nn.Softmax(dim=-1) on the 337-key logits, attention.py:208
+ *   m3d_bundle_outputs ......... flatten_tensor x13 + torch.cat + softmax, M3d_inference_align.py:280-301,
+ *                                 lib/rpn_util.py:892-901 (+ the score key used by top-k)
+ *   m3d_decode_rows ............ lib/rpn_util.py:1442-1521 (im_detect_3d decode) and
+ *                                 bbox_transform_inv :1137-1186, for the top-N-pre rows
+ */
+#ifndef M3DSSD_HIP_H
+#define M3DSSD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *m3d_stream_t; /* hipStream_t */
+
+enum {
+    M3D_OK = 0,
+    M3D_E_ARG = -1,      /* bad argument / unsupported shape (message via m3d_last_error) */
+    M3D_E_HIP = -2,      /* a HIP runtime call or kernel launch failed */
+    M3D_E_WORKSPACE = -3 /* workspace too small */
+};
+
+/* Thread-local text of the last error returned on this thread. */
+const char *m3d_last_error(void);
+/* Library/ABI version (bumped when a signature changes). */
+int m3d_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32), NHWC activations.
+ *   GEMM view: M = N*Ho*Wo pixels, N = Cout, K = kh*kw*Cin (tap-major, channel-minor).
+ *   out = act( conv(in, wgt) * scale[c] + shift[c] + res )   (res_mode 0; scale/shift/res optional)
+ *   out = act( (conv(in, wgt) + res) * scale[c] + shift[c] )  (res_mode 1)
+ * Deformable mode (dcn_offmask != NULL): the A operand is the modulated bilinear gather of
+ * DCNv2 (dcn_v2_im2col_cuda.cu:18-47,129-178) computed on the fly -- no `columns` buffer.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct m3d_conv_desc {
+    const float *in;          /* NHWC view: in[(n*H + h)*W + w][c], pixel stride in_cs floats   */
+    int in_cs;
+    int N, H, W, Cin;         /* Cin % 16 == 0                                                  */
+    const float *wgt;         /* packed [Cout_pad][K], K = (i*kw + j)*Cin + c; rows >= Cout = 0 */
+    long long wgt_img_stride; /* 0, or floats between per-image weight sets (needs Ho*Wo % BM == 0) */
+    int Cout, Cout_pad;       /* Cout_pad % 32 == 0                                             */
+    int kh, kw, stride, pad, dil;
+    int Ho, Wo;
+    float *out;
+    int out_cs;               /* NHWC pixel stride (out_nchw == 0)                              */
+    int out_nchw;             /* 1: planar out[n*out_img_stride + c*Ho*Wo + p]                  */
+    long long out_img_stride;
+    const float *scale;       /* [Cout] or NULL (=1)                                            */
+    const float *shift;       /* [Cout] or NULL (=0)                                            */
+    const float *res;         /* NHWC residual view or NULL                                     */
+    int res_cs;
+    int res_mode;             /* 0: acc*scale+shift+res   1: (acc+res)*scale+shift (BN after the add) */
+    int act;                  /* 0 none, 1 LeakyReLU(0.01)                                      */
+    int sigmoid_from;         /* channels >= this get sigmoid instead of act; <0: none          */
+    const float *dcn_offmask; /* NHWC [.., 3*kh*kw]: 2k=dh, 2k+1=dw, 2*kh*kw+k=mask; NULL=plain */
+    int dcn_om_cs;
+} m3d_conv_desc;
+
+int m3d_conv2d_forward(const m3d_conv_desc *d, m3d_stream_t stream);
+
+/* Average launch geometry chosen for a descriptor (for roofline bookkeeping / tests). */
+int m3d_conv2d_tile(const m3d_conv_desc *d, int *bm, int *bn, int *bk, int *grid);
+
+/* ------------------------------------------------------------------------------------------
+ * Drop-in for dcn_v2_cuda_forward: NCHW contiguous fp32 device tensors, exactly the reference
+ * argument meaning.  `workspace` replaces the reference's `ones`/`columns` scratch tensors
+ * (dcn_v2_func.py:28): the caller allocates m3d_dcn_v2_workspace_bytes() bytes.
+ * deformable_group must be 1 (the only value on the M3DSSD path).
+ * ------------------------------------------------------------------------------------------ */
+long long m3d_dcn_v2_workspace_bytes(int batch, int channels, int height, int width, int channels_out,
+                                     int kernel_h, int kernel_w, int stride, int pad, int dilation);
+int m3d_dcn_v2_forward(const float *input, const float *weight, const float *bias, const float *offset,
+                       const float *mask, float *output, int batch, int channels, int height, int width,
+                       int channels_out, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h,
+                       int pad_w, int dilation_h, int dilation_w, int deformable_group, void *workspace,
+                       long long workspace_bytes, m3d_stream_t stream);
+
+/* Weight packing: [Cout, Cin, kh, kw] (torch layout) -> [Cout_pad, kh*kw*Cin_pad] (tap-major, zero pad). */
+int m3d_pack_conv_weight(const float *w, float *packed, int Cout, int Cout_pad, int Cin, int Cin_pad, int kh,
+                         int kw, m3d_stream_t stream);
+/* Layout changes at the op boundary. */
+int m3d_nchw_to_nhwc(const float *in, float *out, int N, int C, int H, int W, int out_cs, m3d_stream_t stream);
+int m3d_nhwc_to_nchw(const float *in, int in_cs, float *out, int N, int C, int H, int W, m3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backbone helpers (NHWC, channel-sliced views allowed through *_cs).
+ * ------------------------------------------------------------------------------------------ */
+/* 7x7, 3->16, stride 1, pad 3 on an NCHW image; fused affine (folded BN) + LeakyReLU; NHWC out. */
+int m3d_stem_conv7x7(const float *img_nchw, const float *wgt /*[7*7*3][16]*/, const float *scale,
+                     const float *shift, float *out, int out_cs, int N, int H, int W, m3d_stream_t stream);
+int m3d_maxpool2x2(const float *in, int in_cs, float *out, int out_cs, int N, int H, int W, int C,
+                   m3d_stream_t stream);
+/* out = ConvTranspose2d_depthwise(in, wgt[4][4][C], stride 2, pad 1) + skip ;  in is [N,H,W,C], out/skip [N,2H,2W,C] */
+int m3d_upsample2x_add(const float *in, int in_cs, const float *wgt, const float *skip, int skip_cs,
+                       float *out, int out_cs, int N, int H, int W, int C, m3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Alignment stages.
+ * ------------------------------------------------------------------------------------------ */
+/* cls_planar [B][num_classes*A][HW] (class-major).  Writes per pixel: top-1 fg anchor (lowest
+ * index among equals), its fg probability, and fg_all [B][A][HW] (may be NULL). */
+int m3d_anchor_select(const float *cls_planar, int B, int A, int num_classes, int HW, int *sel_idx,
+                      float *sel_prob, float *fg_all, m3d_stream_t stream);
+/* Top-1 over anchors of a given fg-probability map [B][A][HW] (lowest index among equals). */
+int m3d_fg_top1(const float *prob, int B, int A, int HW, int *idx, float *val, m3d_stream_t stream);
+/* mode 0 = shape_align (table [A][2*kk] -> offmask [B*HW][3*kk], kk=9), mode 1 = center_align
+ * (bbox_x/bbox_y planar: value of image b, anchor a, pixel p at b*box_img_stride + a*HW + p;
+ *  anchor_wh [A][2] = (w/stride, h/stride), mean/std xy). */
+int m3d_align_offsets(int mode, const int *sel_idx, const float *sel_prob, float thresh, const float *table,
+                      const float *bbox_x, const float *bbox_y, const float *anchor_wh, float mean_x,
+                      float std_x, float mean_y, float std_y, float *offmask, int om_cs, int B, int A, int HW,
+                      int kk, long long box_img_stride, m3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ANAB (asymmetric non-local block).
+ * ------------------------------------------------------------------------------------------ */
+/* items: int32 [n_items][6] = (bin, h0, h1, w0, w1, slot); grid = n_items x B.
+ * kv: NHWC view of the K|V channels (C = Ck + Cv), s: NHWC view of the sigmoid gates, bin_scale[bin]
+ * = which gate weights that bin; partial [B][n_bins][max_slots][C]. */
+int m3d_anab_pool_partial(const float *kv, int kv_cs, const float *s, int s_cs, const int *items, int n_items,
+                          const int *bin_scale, int n_bins, float *partial, int max_slots, int B, int H, int W,
+                          int C, m3d_stream_t stream);
+/* Reduce slots, divide by bin area, scatter into GEMM operand layouts:
+ *   khat [B][keys_pad][ck_pad]  (row = key j, col = channel)   -- "weights" of the logits GEMM
+ *   vhatT[B][Cv][keys_pad]      (row = channel, col = key j)   -- "weights" of the P.V GEMM   */
+int m3d_anab_pool_finish(const float *partial, const int *bin_slots, const float *bin_inv_area, int n_bins,
+                         int max_slots, int Ck, int Cv, float *khat, int keys_pad, int ck_pad, float *vhatT,
+                         int B, m3d_stream_t stream);
+/* In-place softmax over the first `valid` columns of each row; columns [valid, cs) are zeroed. */
+int m3d_softmax_rows(float *x, int rows, int valid, int cs, m3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Outputs, decode, NMS.
+ * ------------------------------------------------------------------------------------------ */
+/* planar staging (cls [B][4A][HW], box [B][11][A][HW] in the order x,y,w,h,x3d,y3d,z3d,w3d,h3d,l3d,rY3d)
+ * -> cls/prob [B][A*HW][4], bbox_2d [B][A*HW][4], bbox_3d [B][A*HW][7], and (optional) a sortable
+ * 64-bit key per row: (monotone bits of max fg class prob) << 32 | (0xFFFFFFFF - row). */
+int m3d_bundle_outputs(const float *cls_planar, const float *box_planar, float *cls, float *prob, float *bbox_2d,
+                       float *bbox_3d, long long *score_key, int B, int A, int HW, m3d_stream_t stream);
+/* Decode `n_rows` selected rows per image -> aboxes [B][n_rows][14]
+ * (x1,y1,x2,y2,score,cls,x3d,y3d,z3d,w3d,h3d,l3d,ry3d,anchor). */
+int m3d_decode_rows(const long long *rows /*[B][n_rows] row ids*/, const float *prob, const float *bbox_2d,
+                    const float *bbox_3d, const float *rois /*[R][5]*/, const float *anchors /*[A][9]*/,
+                    const float *means /*[11]*/, const float *stds /*[11]*/, float *aboxes, int B, int R,
+                    int n_rows, m3d_stream_t stream);
+
+/* Greedy NMS on device.  boxes_dev [B][n][box_stride>=4] sorted by descending score; mask_ws needs
+ * B*n*ceil(n/64) uint64.  keep_dev [B][n] int32 (kept positions, ascending), num_keep_dev [B]. */
+long long m3d_nms_workspace_bytes(int B, int n);
+int m3d_nms_sorted_dev(const float *boxes_dev, int B, int n, int box_stride, float thresh, void *mask_ws,
+                       int *keep_dev, int *num_keep_dev, m3d_stream_t stream);
+/* Exact twin of the reference's _nms (lib/nms/gpu_nms.hpp): host pointers, synchronous. */
+void _nms(int *keep_out, int *num_out, const float *boxes_host, int boxes_num, int boxes_dim,
+          float nms_overlap_thresh, int device_id);
+
+/* ------------------------------------------------------------------------------------------
+ * Instrumentation: HIP-event timing of a launch sequence on a stream (used by bench.py).
+ * ------------------------------------------------------------------------------------------ */
+int m3d_event_create(void **ev);
+int m3d_event_record(void *ev, m3d_stream_t stream);
+int m3d_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on stop */
+int m3d_event_destroy(void *ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M3DSSD_HIP_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of libm3dssd_hip.so (include/m3dssd_hip.h).
+
+The library is built in-tree (m3dssd_amd/csrc/build/) by ``build()`` -- plain hipcc for gfx950,
+no torch headers.  There is NO fallback: if the shared object is missing or a symbol is absent the
+import fails loudly, and every entry point that returns a non-zero status raises RuntimeError with
+the library's message (the reference surfaced THError/THArgCheck the same way).
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "build", "libm3dssd_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "m3dssd_hip.h")
+
+c_int, c_float, c_ll, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_longlong, ctypes.c_void_p
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of ``m3d_conv_desc``."""
+    _fields_ = [
+        ("inp", c_void_p), ("in_cs", c_int),
+        ("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int),
+        ("wgt", c_void_p), ("wgt_img_stride", c_ll),
+        ("Cout", c_int), ("Cout_pad", c_int),
+        ("kh", c_int), ("kw", c_int), ("stride", c_int), ("pad", c_int), ("dil", c_int),
+        ("Ho", c_int), ("Wo", c_int),
+        ("out", c_void_p), ("out_cs", c_int), ("out_nchw", c_int), ("out_img_stride", c_ll),
+        ("scale", c_void_p), ("shift", c_void_p),
+        ("res", c_void_p), ("res_cs", c_int), ("res_mode", c_int),
+        ("act", c_int), ("sigmoid_from", c_int),
+        ("dcn_offmask", c_void_p), ("dcn_om_cs", c_int),
+    ]
+
+
+P = c_void_p
+# name -> (restype, argtypes); every name here must be declared in include/m3dssd_hip.h
+SIGNATURES = {
+    "m3d_last_error": (ctypes.c_char_p, []),
+    "m3d_abi_version": (c_int, []),
+    "m3d_conv2d_forward": (c_int, [ctypes.POINTER(ConvDesc), P]),
+    "m3d_conv2d_tile": (c_int, [ctypes.POINTER(ConvDesc)] + [ctypes.POINTER(c_int)] * 4),
+    "m3d_dcn_v2_workspace_bytes": (c_ll, [c_int] * 10),
+    "m3d_dcn_v2_forward": (c_int, [P] * 6 + [c_int] * 14 + [P, c_ll, P]),
+    "m3d_pack_conv_weight": (c_int, [P, P] + [c_int] * 6 + [P]),
+    "m3d_nchw_to_nhwc": (c_int, [P, P] + [c_int] * 5 + [P]),
+    "m3d_nhwc_to_nchw": (c_int, [P, c_int, P] + [c_int] * 4 + [P]),
+    "m3d_stem_conv7x7": (c_int, [P, P, P, P, P] + [c_int] * 4 + [P]),
+    "m3d_maxpool2x2": (c_int, [P, c_int, P, c_int] + [c_int] * 4 + [P]),
+    "m3d_upsample2x_add": (c_int, [P, c_int, P, P, c_int, P, c_int] + [c_int] * 4 + [P]),
+    "m3d_anchor_select": (c_int, [P] + [c_int] * 4 + [P, P, P, P]),
+    "m3d_fg_top1": (c_int, [P, c_int, c_int, c_int, P, P, P]),
+    "m3d_align_offsets": (c_int, [c_int, P, P, c_float, P, P, P, P] + [c_float] * 4 + [P] + [c_int] * 5 + [c_ll, P]),
+    "m3d_anab_pool_partial": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P] + [c_int] * 5 + [P]),
+    "m3d_anab_pool_finish": (c_int, [P, P, P] + [c_int] * 4 + [P, c_int, c_int, P, c_int, P]),
+    "m3d_softmax_rows": (c_int, [P, c_int, c_int, c_int, P]),
+    "m3d_bundle_outputs": (c_int, [P] * 7 + [c_int] * 3 + [P]),
+    "m3d_decode_rows": (c_int, [P] * 9 + [c_int] * 3 + [P]),
+    "m3d_nms_workspace_bytes": (c_ll, [c_int, c_int]),
+    "m3d_nms_sorted_dev": (c_int, [P, c_int, c_int, c_int, c_float, P, P, P, P]),
+    "_nms": (None, [P, P, P, c_int, c_int, c_float, c_int]),
+    "m3d_event_create": (c_int, [ctypes.POINTER(c_void_p)]),
+    "m3d_event_record": (c_int, [P, P]),
+    "m3d_event_elapsed_ms": (c_int, [P, P, ctypes.POINTER(c_float)]),
+    "m3d_event_destroy": (c_int, [P]),
+}
+
+_lib = None
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into csrc/build/libm3dssd_hip.so (make, hipcc)."""
+    cmd = ["make", "-C", CSRC, "-j", str(os.cpu_count() or 4)] + (["-B"] if force else [])
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise RuntimeError("building libm3dssd_hip.so failed")
+    return SO_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                "libm3dssd_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                "there is no non-HIP fallback for the M3DSSD hot path" % SO_PATH)
+        L = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)            # AttributeError if a declared symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        raise RuntimeError("m3dssd_hip error %d: %s" % (status, lib().m3d_last_error().decode()))

@@ -1,0 +1,236 @@
+// HBM-bound helpers of the backbone / up-sampling path (NHWC, 16-byte vector access along C):
+// weight packing, layout changes at the op boundary, the 7x7 stem, 2x2 max-pool and the
+// depthwise transposed-conv up-sampler fused with the IDA skip add.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------
+// [Cout, Cin, kh, kw] -> [Cout_pad, (i*kw + j)*Cin_pad + c]   (rows >= Cout and channels >= Cin are zero)
+__global__ void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ p, int Cout, int Cout_pad,
+                                   int Cin, int Cin_pad, int KK)
+{
+    const long long total = (long long)Cout_pad * KK * Cin_pad;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cin_pad);
+        const int tap = (int)((i / Cin_pad) % KK);
+        const int co = (int)(i / ((long long)Cin_pad * KK));
+        p[i] = (co < Cout && c < Cin) ? w[((long long)co * Cin + c) * KK + tap] : 0.f;
+    }
+}
+
+extern "C" int m3d_pack_conv_weight(const float *w, float *packed, int Cout, int Cout_pad, int Cin, int Cin_pad,
+                                    int kh, int kw, m3d_stream_t stream)
+{
+    M3D_REQUIRE(w && packed && Cout > 0 && Cout_pad >= Cout && Cin_pad >= Cin, "pack_conv_weight: bad arguments");
+    const long long total = (long long)Cout_pad * kh * kw * Cin_pad;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(imin(cdiv(total, 256), 4096)), dim3(256), 0, (hipStream_t)stream, w,
+                       packed, Cout, Cout_pad, Cin, Cin_pad, kh * kw);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// NCHW <-> NHWC through a 32x32 LDS tile (coalesced on both sides).
+__global__ void nchw_to_nhwc_kernel(const float *__restrict__ in, float *__restrict__ out, int C, int HW, int out_cs)
+{
+    __shared__ float t[32][33];
+    const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        t[r][tx] = (c < C && p < HW) ? in[((size_t)n * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        if (c < C && p < HW) out[((size_t)n * HW + p) * out_cs + c] = t[tx][r];
+    }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float *__restrict__ in, int in_cs, float *__restrict__ out, int C, int HW)
+{
+    __shared__ float t[32][33];
+    const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        t[r][tx] = (c < C && p < HW) ? in[((size_t)n * HW + p) * in_cs + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        if (c < C && p < HW) out[((size_t)n * C + c) * HW + p] = t[tx][r];
+    }
+}
+
+extern "C" int m3d_nchw_to_nhwc(const float *in, float *out, int N, int C, int H, int W, int out_cs,
+                                m3d_stream_t stream)
+{
+    M3D_REQUIRE(in && out && out_cs >= C, "nchw_to_nhwc: bad arguments");
+    const int HW = H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), N), dim3(256), 0, (hipStream_t)stream, in,
+                       out, C, HW, out_cs);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+extern "C" int m3d_nhwc_to_nchw(const float *in, int in_cs, float *out, int N, int C, int H, int W,
+                                m3d_stream_t stream)
+{
+    M3D_REQUIRE(in && out && in_cs >= C, "nhwc_to_nchw: bad arguments");
+    const int HW = H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), N), dim3(256), 0, (hipStream_t)stream, in,
+                       in_cs, out, C, HW);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Stem: 7x7, 3 -> 16, stride 1, pad 3 (model/pose_dla_dcn.py:336-340), NCHW image in, NHWC out.
+// HBM-bound layer (5.9 MB in, 31.5 MB out per 384x1280 image).  One thread = one output pixel x
+// 16 channels; the input patch of the 8x32-pixel tile sits in LDS, the 2352 weights are read
+// through the scalar cache (wave-uniform index) so the VALU sees them as SGPR operands.
+#define STEM_TH 8
+#define STEM_TW 32
+__global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float *__restrict__ img, const float *__restrict__ wgt,
+                                                           const float *__restrict__ scale,
+                                                           const float *__restrict__ shift, float *__restrict__ out,
+                                                           int out_cs, int H, int W)
+{
+    constexpr int PH = STEM_TH + 6, PW = STEM_TW + 6;
+    __shared__ float patch[3][PH][PW + 1];
+    const int n = blockIdx.z, h0 = blockIdx.y * STEM_TH, w0 = blockIdx.x * STEM_TW;
+    const float *im = img + (size_t)n * 3 * H * W;
+    for (int i = threadIdx.x; i < 3 * PH * PW; i += 256) {
+        const int c = i / (PH * PW), r = (i / PW) % PH, q = i % PW;
+        const int h = h0 + r - 3, w = w0 + q - 3;
+        patch[c][r][q] = (h >= 0 && h < H && w >= 0 && w < W) ? im[((size_t)c * H + h) * W + w] : 0.f;
+    }
+    __syncthreads();
+    const int ty = threadIdx.x / STEM_TW, tx = threadIdx.x % STEM_TW;
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = 0.f;
+    for (int i = 0; i < 7; ++i) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = patch[c][ty + i][tx + j];
+                const float *wp = wgt + ((i * 7 + j) * 3 + c) * 16;   // uniform -> s_load
+#pragma unroll
+                for (int o = 0; o < 16; ++o) acc[o] = fmaf(v, wp[o], acc[o]);
+            }
+        }
+    }
+    const int h = h0 + ty, w = w0 + tx;
+    if (h < H && w < W) {
+        float *op = out + ((size_t)(n * H + h) * W + w) * out_cs;
+#pragma unroll
+        for (int o4 = 0; o4 < 4; ++o4) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = leaky(acc[o4 * 4 + e] * scale[o4 * 4 + e] + shift[o4 * 4 + e]);
+            *reinterpret_cast<f32x4 *>(op + o4 * 4) = v;
+        }
+    }
+}
+
+extern "C" int m3d_stem_conv7x7(const float *img_nchw, const float *wgt, const float *scale, const float *shift,
+                                float *out, int out_cs, int N, int H, int W, m3d_stream_t stream)
+{
+    M3D_REQUIRE(img_nchw && wgt && scale && shift && out && out_cs % 4 == 0 && out_cs >= 16, "stem: bad arguments");
+    hipLaunchKernelGGL(stem_conv7x7_kernel, dim3(cdiv(W, STEM_TW), cdiv(H, STEM_TH), N), dim3(256), 0,
+                       (hipStream_t)stream, img_nchw, wgt, scale, shift, out, out_cs, H, W);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// MaxPool2d(2, 2) (floor mode), float4 along channels.
+__global__ void maxpool2x2_kernel(const float *__restrict__ in, int in_cs, float *__restrict__ out, int out_cs, int N,
+                                  int H, int W, int C4)
+{
+    const int Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)N * Ho * Wo * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long p = i / C4;
+        const int wo = (int)(p % Wo);
+        p /= Wo;
+        const int ho = (int)(p % Ho), n = (int)(p / Ho);
+        const float *b = in + ((size_t)(n * H + 2 * ho) * W + 2 * wo) * in_cs + c4 * 4;
+        const f32x4 v00 = *reinterpret_cast<const f32x4 *>(b);
+        const f32x4 v01 = *reinterpret_cast<const f32x4 *>(b + in_cs);
+        const f32x4 v10 = *reinterpret_cast<const f32x4 *>(b + (size_t)W * in_cs);
+        const f32x4 v11 = *reinterpret_cast<const f32x4 *>(b + (size_t)W * in_cs + in_cs);
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = fmaxf(fmaxf(v00[e], v01[e]), fmaxf(v10[e], v11[e]));
+        *reinterpret_cast<f32x4 *>(out + ((size_t)(n * Ho + ho) * Wo + wo) * out_cs + c4 * 4) = r;
+    }
+}
+
+extern "C" int m3d_maxpool2x2(const float *in, int in_cs, float *out, int out_cs, int N, int H, int W, int C,
+                              m3d_stream_t stream)
+{
+    M3D_REQUIRE(in && out && C % 4 == 0 && in_cs % 4 == 0 && out_cs % 4 == 0, "maxpool: C and strides must be x4");
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2x2_kernel, dim3(imin(cdiv(total, 256), 8192)), dim3(256), 0, (hipStream_t)stream, in,
+                       in_cs, out, out_cs, N, H, W, C / 4);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Depthwise ConvTranspose2d(kernel 4, stride 2, padding 1, groups=C, no bias) + skip add
+// (model/pose_dla_dcn.py:536-538,550-552).  out[y][x] += in[iy][ix] * w[ky][kx] with
+// y = 2*iy - 1 + ky: each output pixel has exactly 2x2 contributing inputs.
+// wgt layout [4][4][C] (ky, kx, c).
+__global__ void upsample2x_add_kernel(const float *__restrict__ in, int in_cs, const float *__restrict__ wgt,
+                                      const float *__restrict__ skip, int skip_cs, float *__restrict__ out, int out_cs,
+                                      int N, int H, int W, int C4)
+{
+    const int Ho = 2 * H, Wo = 2 * W, C = C4 * 4;
+    const long long total = (long long)N * Ho * Wo * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long p = i / C4;
+        const int x = (int)(p % Wo);
+        p /= Wo;
+        const int y = (int)(p % Ho), n = (int)(p / Ho);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // ky = y + 1 - 2*iy in [0,3]  ->  iy in { (y+1)>>1, ((y+1)>>1) - 1 }
+        const int iy_hi = (y + 1) >> 1, ix_hi = (x + 1) >> 1;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int iy = iy_hi - a, ky = y + 1 - 2 * iy;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int ix = ix_hi - b, kx = x + 1 - 2 * ix;
+                if (ix < 0 || ix >= W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(in + ((size_t)(n * H + iy) * W + ix) * in_cs + c4 * 4);
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(wgt + (ky * 4 + kx) * C + c4 * 4);
+                acc += v * w;
+            }
+        }
+        const size_t o = (size_t)(n * Ho + y) * Wo + x;
+        if (skip) acc += *reinterpret_cast<const f32x4 *>(skip + o * skip_cs + c4 * 4);
+        *reinterpret_cast<f32x4 *>(out + o * out_cs + c4 * 4) = acc;
+    }
+}
+
+extern "C" int m3d_upsample2x_add(const float *in, int in_cs, const float *wgt, const float *skip, int skip_cs,
+                                  float *out, int out_cs, int N, int H, int W, int C, m3d_stream_t stream)
+{
+    M3D_REQUIRE(in && wgt && out && C % 4 == 0 && in_cs % 4 == 0 && out_cs % 4 == 0 && (!skip || skip_cs % 4 == 0),
+                "upsample2x_add: C and strides must be x4");
+    const long long total = (long long)N * 4 * H * W * (C / 4);
+    hipLaunchKernelGGL(upsample2x_add_kernel, dim3(imin(cdiv(total, 256), 8192)), dim3(256), 0, (hipStream_t)stream, in,
+                       in_cs, wgt, skip, skip_cs, out, out_cs, N, H, W, C / 4);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}

@@ -1,0 +1,393 @@
+// Implicit-GEMM convolution / deformable convolution for gfx950 on the fp32 MFMA pipe.
+//
+//   C[m][n] = sum_k A[m][k] * B[n][k]      m = output pixel (N*Ho*Wo), n = output channel,
+//                                           k = (tap i*kw+j) * Cin + c      (NHWC: c contiguous)
+//
+// * A is never materialised (no im2col `columns` buffer, cf. the reference's 35 MB scratch per
+//   128-channel DCN call, model/DCNv2/src/dcn_v2_cuda.c:54): each k-tile (BK channels of ONE tap)
+//   is gathered straight from the NHWC activation into LDS with 16-byte loads.  In deformable
+//   mode the gather is the modulated bilinear sample of DCNv2
+//   (model/DCNv2/src/cuda/dcn_v2_im2col_cuda.cu:18-47,129-178): the 4 corner weights / offsets of
+//   a (pixel, tap) are computed once per tap in registers and reused for all Cin/BK k-tiles.
+// * Math is v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), 64 FLOP/clk/SIMD =
+//   157 TFLOP/s chip peak (MI355X_MICROARCH.md).  One wave owns TM x TN tiles of 32x32.
+//   The k order inside an 8-wide group is permuted (lane half h, step t -> k = 8g + 4h + t) so that
+//   every lane fetches its 4 A and 4 B values of a group with ONE ds_read_b128 each.
+// * LDS rows are padded to BK+4 floats: conflict-free for the b128 fragment reads.
+// * Global->register prefetch of tile kt+1 overlaps the MFMAs of tile kt; one barrier per k-tile.
+// * Epilogue fuses per-channel affine (folded BatchNorm + conv bias), residual add, LeakyReLU or
+//   sigmoid, and writes NHWC (lanes along channels: 128 B per half-wave) or, in SWAP mode, planar
+//   NCHW (operands swapped so lanes run along pixels) -- the layout the RPN outputs need.
+// * blockIdx is remapped so each XCD (private L2) works on a contiguous range of tiles.
+#include "common.h"
+
+struct IgemmArgs {
+    const float *in;
+    const float *wgt;
+    float *out;
+    const float *scale;
+    const float *shift;
+    const float *res;
+    const float *om;
+    long long wgt_img_stride;
+    long long out_img_stride;
+    int in_cs, out_cs, res_cs, om_cs;
+    int H, W, Cin, Ho, Wo, HoWo;
+    int Cout, Cout_pad;
+    int kh, kw, stride, pad, dil;
+    int M, Ktot, KT;
+    int tiles_m, tiles_n;
+    int act, sigmoid_from, res_mode;
+};
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool DEFORM, bool SWAP>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
+{
+    constexpr int TM = BM / (32 * WAVES_M);
+    constexpr int TN = BN / (32 * WAVES_N);
+    constexpr int LDK = BK + 4;
+    constexpr int TPR = BK / 4;      // threads covering one row of a k-tile (float4 each)
+    constexpr int RPP = 256 / TPR;   // rows per pass
+    constexpr int PA = BM / RPP;     // A passes per thread
+    constexpr int PB = (BN + RPP - 1) / RPP;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+    static_assert(TM >= 1 && TN >= 1 && PA >= 1, "tile too small");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                      // [2][BM][LDK]
+    float *Bs = smem + 2 * BM * LDK;       // [2][BN][LDK]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = (wave / WAVES_N) * (TM * 32);
+    const int wn = (wave % WAVES_N) * (TN * 32);
+
+    // XCD-aware tile id: block b runs on XCD b%8; give each XCD a contiguous tile range.
+    int tile;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tile_m = tile / a.tiles_n, tile_n = tile - tile_m * a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const float *__restrict__ wgt = a.wgt;
+    if (a.wgt_img_stride) wgt += (long long)(m0 / a.HoWo) * a.wgt_img_stride;
+
+    // ---- per-thread A rows -------------------------------------------------------------
+    const int rsub = tid / TPR;            // row within a pass
+    const int csub = (tid % TPR) * 4;      // channel offset within the k-tile
+    int pix_base[PA], hi0[PA], wi0[PA];
+    bool rvalid[PA];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        const int m = m0 + p * RPP + rsub;
+        rvalid[p] = m < a.M;
+        const int mm = rvalid[p] ? m : 0;
+        const int n = mm / a.HoWo, rem = mm - n * a.HoWo;
+        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        pix_base[p] = n * a.H * a.W;
+        hi0[p] = ho * a.stride - a.pad;
+        wi0[p] = wo * a.stride - a.pad;
+    }
+    // deformable: bilinear state of the current tap
+    float bw[DEFORM ? PA : 1][4], bmask[DEFORM ? PA : 1];
+    int boff[DEFORM ? PA : 1][4];
+
+    f32x4 ra[PA][DEFORM ? 4 : 1];
+    f32x4 rb[PB];
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+        const int tap = k0 / a.Cin;
+        const int c0 = k0 - tap * a.Cin + csub;
+        const int ti = tap / a.kw, tj = tap - ti * a.kw;
+        if constexpr (!DEFORM) {
+#pragma unroll
+            for (int p = 0; p < PA; ++p) {
+                const int hi = hi0[p] + ti * a.dil, wi = wi0[p] + tj * a.dil;
+                const bool ok = rvalid[p] && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok)
+                    v = *reinterpret_cast<const f32x4 *>(
+                        a.in + (size_t)(pix_base[p] + hi * a.W + wi) * a.in_cs + c0);
+                ra[p][0] = v;
+            }
+        } else {
+            if (k0 == tap * a.Cin) {   // first k-tile of a tap: refresh the sampling state
+                const int KK = a.kh * a.kw;
+#pragma unroll
+                for (int p = 0; p < PA; ++p) {
+                    float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f, mk = 0.f;
+                    int o1 = 0, o2 = 0, o3 = 0, o4 = 0;
+                    if (rvalid[p]) {
+                        const float *omp = a.om + (size_t)(m0 + p * RPP + rsub) * a.om_cs;
+                        const float dh = omp[2 * tap], dw = omp[2 * tap + 1];
+                        mk = omp[2 * KK + tap];
+                        const float h_im = (float)(hi0[p] + ti * a.dil) + dh;
+                        const float w_im = (float)(wi0[p] + tj * a.dil) + dw;
+                        if (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
+                            const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
+                            const int hh = hl + 1, wh = wl + 1;
+                            const float lh = h_im - (float)hl, lw = w_im - (float)wl;
+                            const float uh = 1.f - lh, uw = 1.f - lw;
+                            if (hl >= 0 && wl >= 0) { w1 = uh * uw; o1 = hl * a.W + wl; }
+                            if (hl >= 0 && wh <= a.W - 1) { w2 = uh * lw; o2 = hl * a.W + wh; }
+                            if (hh <= a.H - 1 && wl >= 0) { w3 = lh * uw; o3 = hh * a.W + wl; }
+                            if (hh <= a.H - 1 && wh <= a.W - 1) { w4 = lh * lw; o4 = hh * a.W + wh; }
+                        }
+                    }
+                    bw[p][0] = w1; bw[p][1] = w2; bw[p][2] = w3; bw[p][3] = w4;
+                    boff[p][0] = o1; boff[p][1] = o2; boff[p][2] = o3; boff[p][3] = o4;
+                    bmask[p] = mk;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < PA; ++p) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    ra[p][q] = *reinterpret_cast<const f32x4 *>(
+                        a.in + (size_t)(pix_base[p] + boff[p][q]) * a.in_cs + c0);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int r = p * RPP + rsub;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < BN && n0 + r < a.Cout_pad)
+                v = *reinterpret_cast<const f32x4 *>(wgt + (size_t)(n0 + r) * a.Ktot + k0 + csub);
+            rb[p] = v;
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        float *Ab = As + buf * BM * LDK;
+        float *Bb = Bs + buf * BN * LDK;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            f32x4 v;
+            if constexpr (!DEFORM) {
+                v = ra[p][0];
+            } else {
+                // (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask   -- dcn_v2_im2col_cuda.cu:44-46,174
+                v = bw[p][0] * ra[p][0] + bw[p][1] * ra[p][1] + bw[p][2] * ra[p][2] + bw[p][3] * ra[p][3];
+                v = v * bmask[p];
+            }
+            *reinterpret_cast<f32x4 *>(Ab + (p * RPP + rsub) * LDK + csub) = v;
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int r = p * RPP + rsub;
+            if (r < BN) *reinterpret_cast<f32x4 *>(Bb + r * LDK + csub) = rb[p];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int l31 = lane & 31, lh4 = (lane >> 5) * 4;
+    for (int kt = 0; kt < a.KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < a.KT) load_tile(kt + 1);
+        const float *Ab = As + buf * BM * LDK + (wm + l31) * LDK + lh4;
+        const float *Bb = Bs + buf * BN * LDK + (wn + l31) * LDK + lh4;
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * LDK + g * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * LDK + g * 8);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (SWAP)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][t], fa[i][t], acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+                    }
+        }
+        if (kt + 1 < a.KT) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------
+    // D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+    const int hrow = 4 * (lane >> 5);
+    if constexpr (!SWAP) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int co = n0 + wn + j * 32 + l31;
+            const bool cok = co < a.Cout;
+            const float sc = (cok && a.scale) ? a.scale[co] : 1.f;
+            const float sh = (cok && a.shift) ? a.shift[co] : 0.f;
+            const bool sg = a.sigmoid_from >= 0 && co >= a.sigmoid_from;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + hrow;
+                    if (cok && m < a.M) {
+                        float v = acc[i][j][r];
+                        if (a.res) {
+                            const float rv = a.res[(size_t)m * a.res_cs + co];
+                            v = a.res_mode ? (v + rv) * sc + sh : v * sc + sh + rv;
+                        } else {
+                            v = v * sc + sh;
+                        }
+                        if (sg) v = sigmoidf_(v);
+                        else if (a.act == 1) v = leaky(v);
+                        a.out[(size_t)m * a.out_cs + co] = v;
+                    }
+                }
+            }
+        }
+    } else {
+        // D[row = channel][col = pixel]
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm + i * 32 + l31;
+            const bool mok = m < a.M;
+            const int mm = mok ? m : 0;
+            const int n = mm / a.HoWo, pix = mm - n * a.HoWo;
+            float *ob = a.out + (long long)n * a.out_img_stride + pix;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = n0 + wn + j * 32 + (r & 3) + 8 * (r >> 2) + hrow;
+                    if (mok && co < a.Cout) {
+                        const float sc = a.scale ? a.scale[co] : 1.f;
+                        const float sh = a.shift ? a.shift[co] : 0.f;
+                        float v = acc[i][j][r] * sc + sh;
+                        if (a.sigmoid_from >= 0 && co >= a.sigmoid_from) v = sigmoidf_(v);
+                        else if (a.act == 1) v = leaky(v);
+                        ob[(size_t)co * a.HoWo] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool DEFORM, bool SWAP>
+static int launch_igemm(const IgemmArgs &a, hipStream_t stream)
+{
+    constexpr size_t smem = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
+    auto kern = igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, DEFORM, SWAP>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        M3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    IgemmArgs b = a;
+    b.tiles_m = cdiv(a.M, BM);
+    b.tiles_n = cdiv(a.Cout_pad, BN);
+    hipLaunchKernelGGL(kern, dim3(b.tiles_m * b.tiles_n), dim3(256), smem, stream, b);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+struct TileChoice { int bm, bn, bk; };
+
+static int choose_tile(const m3d_conv_desc *d, TileChoice *t)
+{
+    const long long M = (long long)d->N * d->Ho * d->Wo;
+    t->bk = (d->Cin % 32 == 0) ? 32 : 16;
+    if (d->Cout_pad <= 32) t->bn = 32;
+    else if (d->Cout_pad <= 64 || (d->Cout_pad % 128 != 0 && d->Cout_pad % 64 == 0 && d->Cout_pad < 256)) t->bn = 64;
+    else t->bn = 128;
+    if (t->bk == 16) t->bn = 32;
+    t->bm = 128;
+    if (t->bn >= 64) {
+        const long long blocks128 = ((M + 127) / 128) * ((d->Cout_pad + t->bn - 1) / t->bn);
+        if (blocks128 < 2 * 256) t->bm = 64;     // under two blocks per CU: smaller tiles fill the chip
+    }
+    if (d->wgt_img_stride && (d->Ho * d->Wo) % t->bm != 0) {
+        t->bm = 64;
+        if ((d->Ho * d->Wo) % 64 != 0) return -1;
+    }
+    return 0;
+}
+
+extern "C" int m3d_conv2d_tile(const m3d_conv_desc *d, int *bm, int *bn, int *bk, int *grid)
+{
+    TileChoice t;
+    M3D_REQUIRE(choose_tile(d, &t) == 0, "per-image weights need Ho*Wo %% 64 == 0");
+    const long long M = (long long)d->N * d->Ho * d->Wo;
+    *bm = t.bm; *bn = t.bn; *bk = t.bk;
+    *grid = cdiv(M, t.bm) * cdiv(d->Cout_pad, t.bn);
+    return M3D_OK;
+}
+
+extern "C" int m3d_conv2d_forward(const m3d_conv_desc *d, m3d_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    M3D_REQUIRE(d && d->in && d->wgt && d->out, "conv2d: null pointer");
+    M3D_REQUIRE(d->Cin % 16 == 0, "conv2d: Cin (%d) must be a multiple of 16", d->Cin);
+    M3D_REQUIRE(d->Cout_pad % 32 == 0 && d->Cout <= d->Cout_pad, "conv2d: bad Cout_pad %d", d->Cout_pad);
+    M3D_REQUIRE(d->in_cs % 4 == 0 && d->in_cs >= d->Cin, "conv2d: in_cs must be a multiple of 4 and >= Cin");
+    M3D_REQUIRE(((uintptr_t)d->in & 15) == 0 && ((uintptr_t)d->wgt & 15) == 0, "conv2d: 16-byte alignment");
+    const int ho = (d->H + 2 * d->pad - (d->dil * (d->kh - 1) + 1)) / d->stride + 1;
+    const int wo = (d->W + 2 * d->pad - (d->dil * (d->kw - 1) + 1)) / d->stride + 1;
+    M3D_REQUIRE(ho == d->Ho && wo == d->Wo, "conv2d: Ho/Wo mismatch (%d,%d) vs (%d,%d)", d->Ho, d->Wo, ho, wo);
+    const long long M = (long long)d->N * d->Ho * d->Wo;
+    M3D_REQUIRE(M > 0 && M < (1ll << 31) / 4, "conv2d: M out of range");
+    M3D_REQUIRE((long long)d->N * d->H * d->W * d->in_cs < (1ll << 40), "conv2d: input too large");
+    if (d->dcn_offmask) M3D_REQUIRE(!d->out_nchw && d->Cout_pad % 64 == 0, "deformable conv: NHWC out, Cout_pad %% 64");
+    if (d->out_nchw) M3D_REQUIRE(!d->res, "planar output does not take a residual");
+
+    TileChoice t;
+    M3D_REQUIRE(choose_tile(d, &t) == 0, "per-image weights need Ho*Wo %% 64 == 0");
+
+    IgemmArgs a;
+    a.in = d->in; a.wgt = d->wgt; a.out = d->out; a.scale = d->scale; a.shift = d->shift; a.res = d->res;
+    a.om = d->dcn_offmask; a.wgt_img_stride = d->wgt_img_stride; a.out_img_stride = d->out_img_stride;
+    a.in_cs = d->in_cs; a.out_cs = d->out_cs; a.res_cs = d->res_cs; a.om_cs = d->dcn_om_cs;
+    a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.HoWo = d->Ho * d->Wo;
+    a.Cout = d->Cout; a.Cout_pad = d->Cout_pad;
+    a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
+    a.M = (int)M; a.Ktot = d->kh * d->kw * d->Cin; a.KT = a.Ktot / t.bk;
+    a.tiles_m = a.tiles_n = 0;
+    a.act = d->act; a.sigmoid_from = d->sigmoid_from; a.res_mode = d->res_mode;
+
+    const bool deform = d->dcn_offmask != nullptr, swap = d->out_nchw != 0;
+    if (deform) {
+        if (t.bn == 128 && t.bm == 128) return launch_igemm<128, 128, 32, 2, 2, true, false>(a, stream);
+        if (t.bn == 128 && t.bm == 64) return launch_igemm<64, 128, 32, 2, 2, true, false>(a, stream);
+        if (t.bn == 64 && t.bm == 128) return launch_igemm<128, 64, 32, 2, 2, true, false>(a, stream);
+        if (t.bn == 64 && t.bm == 64) return launch_igemm<64, 64, 32, 2, 2, true, false>(a, stream);
+        M3D_REQUIRE(false, "deformable conv: unsupported tile (%d,%d,%d)", t.bm, t.bn, t.bk);
+    }
+    if (swap) {
+        M3D_REQUIRE(t.bk == 32, "planar output needs Cin %% 32 == 0");
+        if (t.bn == 32) return launch_igemm<128, 32, 32, 4, 1, false, true>(a, stream);
+        if (t.bn == 64 && t.bm == 128) return launch_igemm<128, 64, 32, 2, 2, false, true>(a, stream);
+        if (t.bn == 64 && t.bm == 64) return launch_igemm<64, 64, 32, 2, 2, false, true>(a, stream);
+        if (t.bn == 128 && t.bm == 128) return launch_igemm<128, 128, 32, 2, 2, false, true>(a, stream);
+        if (t.bn == 128 && t.bm == 64) return launch_igemm<64, 128, 32, 2, 2, false, true>(a, stream);
+    }
+    if (t.bk == 16) return launch_igemm<128, 32, 16, 4, 1, false, false>(a, stream);
+    if (t.bn == 32) return launch_igemm<128, 32, 32, 4, 1, false, false>(a, stream);
+    if (t.bn == 64 && t.bm == 128) return launch_igemm<128, 64, 32, 2, 2, false, false>(a, stream);
+    if (t.bn == 64 && t.bm == 64) return launch_igemm<64, 64, 32, 2, 2, false, false>(a, stream);
+    if (t.bn == 128 && t.bm == 128) return launch_igemm<128, 128, 32, 2, 2, false, false>(a, stream);
+    if (t.bn == 128 && t.bm == 64) return launch_igemm<64, 128, 32, 2, 2, false, false>(a, stream);
+    M3D_REQUIRE(false, "conv2d: no kernel for tile (%d,%d,%d)", t.bm, t.bn, t.bk);
+}

@@ -1,0 +1,339 @@
+// RPN-side kernels that are bandwidth/latency bound: class softmax + top-1 foreground anchor,
+// offset/mask synthesis for shape_align / center_align, ANAB pyramid pooling, row softmax,
+// output bundling (flatten + cat + prob) and decode of the selected rows.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------
+// M3d_inference_align.py:229-234 (softmax over classes, fg = 1 - p(bg)) and
+// feturealign_mgpu.py:58-62 / 160-164 (topk k=1 -> index, max prob).  Tie rule: lowest index.
+// cls_planar [B][num_classes*A][HW], channel = cls*A + a.
+__global__ void anchor_select_kernel(const float *__restrict__ cls, int A, int NC, int HW, int *__restrict__ sel_idx,
+                                     float *__restrict__ sel_prob, float *__restrict__ fg_all)
+{
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const float *base = cls + (size_t)b * NC * A * HW + p;
+    float best = -1.f;
+    int bi = 0;
+    for (int a = 0; a < A; ++a) {
+        float l[8];
+        float mx = -INFINITY;
+        for (int c = 0; c < NC; ++c) {
+            l[c] = base[(size_t)(c * A + a) * HW];
+            mx = fmaxf(mx, l[c]);
+        }
+        float s = 0.f, e0 = 0.f;
+        for (int c = 0; c < NC; ++c) {
+            const float e = expf(l[c] - mx);
+            if (c == 0) e0 = e;
+            s += e;
+        }
+        const float fg = 1.f - e0 / s;
+        if (fg_all) fg_all[((size_t)b * A + a) * HW + p] = fg;
+        if (fg > best) { best = fg; bi = a; }
+    }
+    sel_idx[(size_t)b * HW + p] = bi;
+    sel_prob[(size_t)b * HW + p] = best;
+}
+
+extern "C" int m3d_anchor_select(const float *cls_planar, int B, int A, int num_classes, int HW, int *sel_idx,
+                                 float *sel_prob, float *fg_all, m3d_stream_t stream)
+{
+    M3D_REQUIRE(cls_planar && sel_idx && sel_prob && num_classes >= 2 && num_classes <= 8, "anchor_select: bad arguments");
+    hipLaunchKernelGGL(anchor_select_kernel, dim3(cdiv(HW, 256), B), dim3(256), 0, (hipStream_t)stream, cls_planar, A,
+                       num_classes, HW, sel_idx, sel_prob, fg_all);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+// Same selection on an already computed fg-probability map [B][A][HW] (stand-alone align modules).
+__global__ void fg_top1_kernel(const float *__restrict__ prob, int A, int HW, int *__restrict__ idx,
+                               float *__restrict__ val)
+{
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const float *base = prob + (size_t)b * A * HW + p;
+    float best = base[0];
+    int bi = 0;
+    for (int a = 1; a < A; ++a) {
+        const float v = base[(size_t)a * HW];
+        if (v > best) { best = v; bi = a; }
+    }
+    idx[(size_t)b * HW + p] = bi;
+    val[(size_t)b * HW + p] = best;
+}
+
+extern "C" int m3d_fg_top1(const float *prob, int B, int A, int HW, int *idx, float *val, m3d_stream_t stream)
+{
+    M3D_REQUIRE(prob && idx && val && A >= 1, "fg_top1: bad arguments");
+    hipLaunchKernelGGL(fg_top1_kernel, dim3(cdiv(HW, 256), B), dim3(256), 0, (hipStream_t)stream, prob, A, HW, idx, val);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// mode 0, shape_align (feturealign_mgpu.py:166-183): offmask[p][0..2kk) = table[idx][.] * hard,
+//                                                    offmask[p][2kk..3kk) = max fg prob
+// mode 1, center_align (feturealign_mgpu.py:67-89):  offmask[p] = (off_y, off_x, prob) with
+//         off_x = ((bbox_x[idx] * std_x + mean_x) * anchor_w/stride) * hard        (kk = 1)
+__global__ void align_offsets_kernel(int mode, const int *__restrict__ sel_idx, const float *__restrict__ sel_prob,
+                                     float thresh, const float *__restrict__ table, const float *__restrict__ bbox_x,
+                                     const float *__restrict__ bbox_y, const float *__restrict__ anchor_wh, float mean_x,
+                                     float std_x, float mean_y, float std_y, float *__restrict__ om, int om_cs, int A,
+                                     int HW, int kk, long long box_img_stride)
+{
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const size_t bp = (size_t)b * HW + p;
+    const int idx = sel_idx[bp];
+    const float pr = sel_prob[bp];
+    const float hard = pr > thresh ? 1.f : 0.f;
+    float *o = om + bp * om_cs;
+    if (mode == 0) {
+        for (int k = 0; k < 2 * kk; ++k) o[k] = table[idx * 2 * kk + k] * hard;
+        for (int k = 0; k < kk; ++k) o[2 * kk + k] = pr;
+    } else {
+        const float bx = bbox_x[(size_t)b * box_img_stride + (size_t)idx * HW + p];
+        const float by = bbox_y[(size_t)b * box_img_stride + (size_t)idx * HW + p];
+        const float off_x = ((bx * std_x + mean_x) * anchor_wh[idx * 2 + 0]) * hard;
+        const float off_y = ((by * std_y + mean_y) * anchor_wh[idx * 2 + 1]) * hard;
+        o[0] = off_y;
+        o[1] = off_x;
+        o[2] = pr;
+    }
+}
+
+extern "C" int m3d_align_offsets(int mode, const int *sel_idx, const float *sel_prob, float thresh, const float *table,
+                                 const float *bbox_x, const float *bbox_y, const float *anchor_wh, float mean_x,
+                                 float std_x, float mean_y, float std_y, float *offmask, int om_cs, int B, int A, int HW,
+                                 int kk, long long box_img_stride, m3d_stream_t stream)
+{
+    M3D_REQUIRE(sel_idx && sel_prob && offmask && om_cs >= 3 * kk, "align_offsets: bad arguments");
+    M3D_REQUIRE(mode == 0 ? (table != nullptr) : (bbox_x && bbox_y && anchor_wh && kk == 1), "align_offsets: mode inputs");
+    hipLaunchKernelGGL(align_offsets_kernel, dim3(cdiv(HW, 256), B), dim3(256), 0, (hipStream_t)stream, mode, sel_idx,
+                       sel_prob, thresh, table, bbox_x, bbox_y, anchor_wh, mean_x, std_x, mean_y, std_y, offmask, om_cs,
+                       A, HW, kk, box_img_stride);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// ANAB weighted pyramid pooling (attention.py:136-147): for scale s, bin (i,j):
+//   mean over the adaptive window of  feat[c] * gate_s      (AdaptiveAvgPool2d windows:
+//   rows [floor(i*H/s), ceil((i+1)*H/s)) etc.).  Work is split into row-chunk items so that the
+//   48x160 "size 1" bin does not serialise on one block; slots are reduced in fixed order
+//   (deterministic, no float atomics).
+// items[i] = (bin, h0, h1, w0, w1, slot); partial [B][n_bins][max_slots][C].
+__global__ void anab_pool_partial_kernel(const float *__restrict__ kv, int kv_cs, const float *__restrict__ s, int s_cs,
+                                         const int *__restrict__ items, const int *__restrict__ bin_scale,
+                                         float *__restrict__ partial, int n_bins, int max_slots, int H, int W, int C)
+{
+    const int it = blockIdx.x, b = blockIdx.y;
+    const int bin = items[it * 6 + 0], h0 = items[it * 6 + 1], h1 = items[it * 6 + 2];
+    const int w0 = items[it * 6 + 3], w1 = items[it * 6 + 4], slot = items[it * 6 + 5];
+    const int sc = bin_scale[bin];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = 0.f;
+        for (int h = h0; h < h1; ++h)
+            for (int w = w0; w < w1; ++w) {
+                const size_t p = (size_t)(b * H + h) * W + w;
+                acc += kv[p * kv_cs + c] * s[p * s_cs + sc];
+            }
+        partial[(((size_t)b * n_bins + bin) * max_slots + slot) * C + c] = acc;
+    }
+}
+
+extern "C" int m3d_anab_pool_partial(const float *kv, int kv_cs, const float *s, int s_cs, const int *items,
+                                     int n_items, const int *bin_scale, int n_bins, float *partial, int max_slots,
+                                     int B, int H, int W, int C, m3d_stream_t stream)
+{
+    M3D_REQUIRE(kv && s && items && bin_scale && partial && n_items > 0 && n_bins > 0, "anab_pool_partial: bad arguments");
+    hipLaunchKernelGGL(anab_pool_partial_kernel, dim3(n_items, B), dim3(256), 0, (hipStream_t)stream, kv, kv_cs, s, s_cs,
+                       items, bin_scale, partial, n_bins, max_slots, H, W, C);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+// Sum the slots of each bin in order, scale by 1/area, scatter into the two GEMM operand layouts.
+// channels [0, Ck) are keys, [Ck, Ck+Cv) values.
+__global__ void anab_pool_finish_kernel(const float *__restrict__ partial, const int *__restrict__ bin_slots,
+                                        const float *__restrict__ bin_inv_area, int n_bins, int max_slots, int Ck,
+                                        int Cv, float *__restrict__ khat, int keys_pad, int ck_pad,
+                                        float *__restrict__ vhatT)
+{
+    const int bin = blockIdx.x, b = blockIdx.y;
+    const int C = Ck + Cv;
+    const int ns = bin_slots[bin];
+    const float inv = bin_inv_area[bin];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float *pp = partial + (((size_t)b * n_bins + bin) * max_slots) * C + c;
+        float acc = 0.f;
+        for (int sl = 0; sl < ns; ++sl) acc += pp[(size_t)sl * C];
+        acc *= inv;
+        if (c < Ck) khat[((size_t)b * keys_pad + bin) * ck_pad + c] = acc;
+        else vhatT[((size_t)b * Cv + (c - Ck)) * keys_pad + bin] = acc;
+    }
+}
+
+extern "C" int m3d_anab_pool_finish(const float *partial, const int *bin_slots, const float *bin_inv_area, int n_bins,
+                                    int max_slots, int Ck, int Cv, float *khat, int keys_pad, int ck_pad, float *vhatT,
+                                    int B, m3d_stream_t stream)
+{
+    M3D_REQUIRE(partial && bin_slots && bin_inv_area && khat && vhatT && keys_pad >= n_bins && ck_pad >= Ck,
+                "anab_pool_finish: bad arguments");
+    hipLaunchKernelGGL(anab_pool_finish_kernel, dim3(n_bins, B), dim3(256), 0, (hipStream_t)stream, partial, bin_slots,
+                       bin_inv_area, n_bins, max_slots, Ck, Cv, khat, keys_pad, ck_pad, vhatT);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Row softmax (attention.py:208), one wave per row, in place; pad columns zeroed.
+__global__ void softmax_rows_kernel(float *__restrict__ x, int rows, int valid, int cs)
+{
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float *r = x + (size_t)row * cs;
+    float mx = -INFINITY;
+    for (int j = lane; j < valid; j += 64) mx = fmaxf(mx, r[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int j = lane; j < valid; j += 64) sum += expf(r[j] - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.f / sum;
+    for (int j = lane; j < cs; j += 64) r[j] = j < valid ? expf(r[j] - mx) * inv : 0.f;
+}
+
+extern "C" int m3d_softmax_rows(float *x, int rows, int valid, int cs, m3d_stream_t stream)
+{
+    M3D_REQUIRE(x && rows > 0 && valid > 0 && cs >= valid, "softmax_rows: bad arguments");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, rows, valid, cs);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Output bundling: flatten_tensor x13 + cat + class softmax (M3d_inference_align.py:229-232,280-301).
+// One thread per anchor row = (a*HW + p); planar reads are coalesced along p, row writes are 16 B.
+__device__ __forceinline__ unsigned int f32_sortable(float f)
+{
+    unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ void bundle_outputs_kernel(const float *__restrict__ cls_pl, const float *__restrict__ box_pl,
+                                      float *__restrict__ cls, float *__restrict__ prob, float *__restrict__ b2,
+                                      float *__restrict__ b3, long long *__restrict__ key, int A, int HW)
+{
+    const int b = blockIdx.y;
+    const int R = A * HW;
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= R) return;
+    const int a = row / HW, p = row - a * HW;
+    const float *cb = cls_pl + (size_t)b * 4 * R;
+    f32x4 l;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) l[c] = cb[(size_t)(c * A + a) * HW + p];
+    const float mx = fmaxf(fmaxf(l[0], l[1]), fmaxf(l[2], l[3]));
+    f32x4 e;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { e[c] = expf(l[c] - mx); s += e[c]; }
+    f32x4 pr;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pr[c] = e[c] / s;
+    const size_t o = (size_t)b * R + row;
+    *reinterpret_cast<f32x4 *>(cls + o * 4) = l;
+    *reinterpret_cast<f32x4 *>(prob + o * 4) = pr;
+    const float *bb = box_pl + (size_t)b * 11 * R + row;
+    f32x4 v2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v2[k] = bb[(size_t)k * R];
+    *reinterpret_cast<f32x4 *>(b2 + o * 4) = v2;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) b3[o * 7 + k] = bb[(size_t)(4 + k) * R];
+    if (key) {
+        const float sc = fmaxf(fmaxf(pr[1], pr[2]), pr[3]);
+        key[o] = (long long)(((unsigned long long)f32_sortable(sc) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)row));
+    }
+}
+
+extern "C" int m3d_bundle_outputs(const float *cls_planar, const float *box_planar, float *cls, float *prob,
+                                  float *bbox_2d, float *bbox_3d, long long *score_key, int B, int A, int HW,
+                                  m3d_stream_t stream)
+{
+    M3D_REQUIRE(cls_planar && box_planar && cls && prob && bbox_2d && bbox_3d, "bundle_outputs: null pointer");
+    hipLaunchKernelGGL(bundle_outputs_kernel, dim3(cdiv((long long)A * HW, 256), B), dim3(256), 0, (hipStream_t)stream,
+                       cls_planar, box_planar, cls, prob, bbox_2d, bbox_3d, score_key, A, HW);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Decode (lib/rpn_util.py:1442-1521 + bbox_transform_inv :1137-1186), scale_factor = 1.
+// Row layout out: x1,y1,x2,y2,score,cls,x3d,y3d,z3d,w3d,h3d,l3d,ry3d,anchor  (rpn_util.py:1550)
+__global__ void decode_rows_kernel(const long long *__restrict__ rows, const float *__restrict__ prob,
+                                   const float *__restrict__ b2, const float *__restrict__ b3,
+                                   const float *__restrict__ rois, const float *__restrict__ anchors,
+                                   const float *__restrict__ means, const float *__restrict__ stds,
+                                   float *__restrict__ out, int R, int n_rows)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    const int row = (int)rows[(size_t)b * n_rows + i];
+    const size_t o = (size_t)b * R + row;
+    const float *ro = rois + (size_t)row * 5;
+    const float x1 = ro[0], y1 = ro[1], x2 = ro[2], y2 = ro[3];
+    const int tr = (int)ro[4];
+    const float *an = anchors + tr * 9;
+    const float widths = x2 - x1 + 1.0f, heights = y2 - y1 + 1.0f;
+    const float ctr_x = x1 + 0.5f * widths, ctr_y = y1 + 0.5f * heights;
+    float d3[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) d3[k] = b3[o * 7 + k] * stds[4 + k] + means[4 + k];
+    float *q = out + ((size_t)b * n_rows + i) * 14;
+    const float dx = b2[o * 4 + 0] * stds[0] + means[0];
+    const float dy = b2[o * 4 + 1] * stds[1] + means[1];
+    const float dw = b2[o * 4 + 2] * stds[2] + means[2];
+    const float dh = b2[o * 4 + 3] * stds[3] + means[3];
+    const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
+    const float pw = expf(dw) * widths, ph = expf(dh) * heights;
+    q[0] = pcx - 0.5f * pw;
+    q[1] = pcy - 0.5f * ph;
+    q[2] = pcx + 0.5f * pw;
+    q[3] = pcy + 0.5f * ph;
+    const float p1 = prob[o * 4 + 1], p2 = prob[o * 4 + 2], p3 = prob[o * 4 + 3];
+    float sc = p1;
+    int cl = 1;
+    if (p2 > sc) { sc = p2; cl = 2; }
+    if (p3 > sc) { sc = p3; cl = 3; }
+    q[4] = sc;
+    q[5] = (float)cl;
+    q[6] = d3[0] * widths + ctr_x;
+    q[7] = d3[1] * heights + ctr_y;
+    q[8] = an[4] + d3[2];
+    q[9] = expf(d3[3]) * an[5];
+    q[10] = expf(d3[4]) * an[6];
+    q[11] = expf(d3[5]) * an[7];
+    q[12] = an[8] + d3[6];
+    q[13] = (float)tr;
+}
+
+extern "C" int m3d_decode_rows(const long long *rows, const float *prob, const float *bbox_2d, const float *bbox_3d,
+                               const float *rois, const float *anchors, const float *means, const float *stds,
+                               float *aboxes, int B, int R, int n_rows, m3d_stream_t stream)
+{
+    M3D_REQUIRE(rows && prob && bbox_2d && bbox_3d && rois && anchors && means && stds && aboxes && n_rows > 0,
+                "decode_rows: bad arguments");
+    hipLaunchKernelGGL(decode_rows_kernel, dim3(cdiv(n_rows, 256), B), dim3(256), 0, (hipStream_t)stream, rows, prob,
+                       bbox_2d, bbox_3d, rois, anchors, means, stds, aboxes, R, n_rows);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}

@@ -1,0 +1,591 @@
+"""Inference engine: the whole RPN.forward of M3DSSD as a fixed sequence of HIP kernel launches.
+
+Design (MI355X-first):
+  * activations live in HBM as NHWC fp32; channel concatenations (DLA ``Root`` inputs) are never
+    materialised -- producers write straight into channel slices of one buffer (``View.slice``);
+  * every conv / DCN is one ``m3d_conv2d_forward`` launch with BatchNorm(eval) + bias folded into a
+    per-channel affine, residual add and LeakyReLU in the epilogue;
+  * parameters are folded / packed once (``Engine.__init__``), buffers and launch descriptors are
+    built once per input shape (``_Plan``) and replayed; PyTorch only owns device memory + streams.
+
+Reference graph being executed: model/M3d_inference_align.py:215-313 (RPN.forward),
+model/pose_dla_dcn.py:391-397,314-327,546-578,687-696 (DLA-34, Tree, IDAUp, DLAUp, DLASeg),
+model/DCNv2/dcn_v2.py:64-70 (DCN), model/module/feturealign_mgpu.py:48-99,153-208,
+model/module/attention.py:183-216.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _hip
+from ._hip import ConvDesc
+
+BN_EPS = 1e-5
+PSP_SIZES = (1, 4, 8, 16)
+
+
+def _rup(a, b):
+    return (a + b - 1) // b * b
+
+
+class View:
+    """NHWC view (possibly a channel slice) of a device buffer."""
+    __slots__ = ("t", "ptr", "n", "h", "w", "c", "cs", "keep")
+
+    def __init__(self, t, n, h, w, c, cs=None, ptr=None):
+        self.t, self.n, self.h, self.w, self.c = t, n, h, w, c
+        self.cs = c if cs is None else cs
+        self.ptr = t.data_ptr() if ptr is None else ptr
+
+    def slice(self, c0, c):
+        assert c0 % 4 == 0 and c0 + c <= self.cs
+        return View(self.t, self.n, self.h, self.w, c, self.cs, self.ptr + 4 * c0)
+
+    def torch_nchw(self):
+        """Debug helper: materialise as an NCHW torch tensor (copies)."""
+        full = self.t.view(self.n, self.h, self.w, self.cs)
+        off = (self.ptr - self.t.data_ptr()) // 4
+        return full[..., off:off + self.c].permute(0, 3, 1, 2).contiguous()
+
+
+class _Stream:
+    @staticmethod
+    def current():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class PackedConv:
+    """Packed weights + folded affine of one conv (or DCN main conv)."""
+
+    def __init__(self, eng, weight, bias=None, bn=None, cout_pad_to=32, cin_pad=None):
+        w = weight.detach().to(eng.device, torch.float32).contiguous()
+        self.cout, self.cin, self.kh, self.kw = w.shape
+        self.cin_pad = self.cin if cin_pad is None else cin_pad
+        self.cout_pad = _rup(self.cout, cout_pad_to)
+        self.wp = torch.empty(self.cout_pad * self.kh * self.kw * self.cin_pad, device=eng.device, dtype=torch.float32)
+        _hip.check(eng.L.m3d_pack_conv_weight(w.data_ptr(), self.wp.data_ptr(), self.cout, self.cout_pad, self.cin,
+                                              self.cin_pad, self.kh, self.kw, _Stream.current()))
+        scale = torch.ones(self.cout, device=eng.device, dtype=torch.float32)
+        shift = torch.zeros(self.cout, device=eng.device, dtype=torch.float32)
+        if bias is not None:
+            shift = bias.detach().to(eng.device, torch.float32).clone()
+        if bn is not None:
+            g, b, m, v = (t.detach().to(eng.device, torch.float32) for t in bn)
+            s = g / torch.sqrt(v + BN_EPS)
+            shift = (shift - m) * s + b
+            scale = s
+        self.scale, self.shift = scale.contiguous(), shift.contiguous()
+        self.has_affine = (bias is not None) or (bn is not None)
+
+
+class _Plan:
+    """Buffers + launch list for one input shape."""
+
+    def __init__(self):
+        self.ops = []          # (name, callable)
+        self.keep = []         # tensors kept alive
+        self.named = {}        # name -> View / tensor (taps for tests)
+
+
+class Engine:
+    def __init__(self, state_dict, conf, device=None, backbone_only=False):
+        self.L = _hip.lib()
+        self.backbone_only = backbone_only
+        self.device = torch.device(device if device is not None else conf.device)
+        if self.device.type != "cuda":
+            raise NotImplementedError("the M3DSSD HIP engine runs on a ROCm device only (got %s)" % self.device)
+        self.conf = conf
+        sd = {k[7:] if k.startswith("module.") else k: v for k, v in state_dict.items()}
+        self.sd = sd
+        self.A = int(np.asarray(conf.anchors).shape[0]) if not backbone_only else 0
+        self.NC = len(conf.lbls) + 1 if not backbone_only else 0
+        self.stride = int(conf.feat_stride)
+        with torch.cuda.device(self.device):
+            self._pack(sd)
+        self.plans = {}
+        self.profile = None    # set to a list to collect (name, ms) per op
+
+    # ------------------------------------------------------------------ parameters
+    def _bn(self, p):
+        sd = self.sd
+        return (sd[p + ".weight"], sd[p + ".bias"], sd[p + ".running_mean"], sd[p + ".running_var"])
+
+    def _pc(self, conv, bn=None, **kw):
+        sd = self.sd
+        return PackedConv(self, sd[conv + ".weight"], sd.get(conv + ".bias"), self._bn(bn) if bn else None, **kw)
+
+    def _pack(self, sd):
+        dev = self.device
+        P = {}
+        b = "base.base"
+        # stem 7x7: [16,3,7,7] -> [(i*7+j)*3+c][16]
+        w = sd[b + ".base_layer.0.weight"].detach().to(dev, torch.float32)
+        P["stem.w"] = w.permute(2, 3, 1, 0).contiguous()
+        g, be, m, v = (t.detach().to(dev, torch.float32) for t in self._bn(b + ".base_layer.1"))
+        s = g / torch.sqrt(v + BN_EPS)
+        P["stem.scale"], P["stem.shift"] = s.contiguous(), (be - m * s).contiguous()
+        P["level0"] = self._pc(b + ".level0.0", b + ".level0.1")
+        P["level1"] = self._pc(b + ".level1.0", b + ".level1.1")
+
+        def block(p):
+            P[p + ".conv1"] = self._pc(p + ".conv1", p + ".bn1")
+            P[p + ".conv2"] = self._pc(p + ".conv2", p + ".bn2")
+
+        def tree1(p):
+            block(p + ".tree1")
+            block(p + ".tree2")
+            P[p + ".root"] = self._pc(p + ".root.conv", p + ".root.bn")
+            if (p + ".project.0.weight") in sd:
+                P[p + ".project"] = self._pc(p + ".project.0", p + ".project.1")
+
+        tree1(b + ".level2")
+        for lv in (3, 4):
+            tree1("%s.level%d.tree1" % (b, lv))
+            tree1("%s.level%d.tree2" % (b, lv))
+        tree1(b + ".level5")
+
+        def deform(p):
+            P[p + ".om"] = self._pc(p + ".conv.conv_offset_mask")
+            P[p + ".dcn"] = PackedConv(self, sd[p + ".conv.weight"], sd[p + ".conv.bias"], self._bn(p + ".actf.0"),
+                                       cout_pad_to=64)
+
+        def ida(p, n):
+            for i in range(1, n):
+                deform("%s.proj_%d" % (p, i))
+                deform("%s.node_%d" % (p, i))
+                up = sd["%s.up_%d.weight" % (p, i)].detach().to(dev, torch.float32)     # [C,1,4,4]
+                P["%s.up_%d" % (p, i)] = up[:, 0].permute(1, 2, 0).contiguous()          # [4][4][C]
+
+        ida("base.dla_up.ida_0", 2)
+        ida("base.dla_up.ida_1", 3)
+        ida("base.ida_up", 2)
+
+        self.P = P
+        if not self.backbone_only:
+            self._pack_heads(sd, P)
+        torch.cuda.synchronize(self.device)
+
+    def _pack_anab(self, P, wq, wk, wv, ws):
+        """One fused 1x1 conv producing [Q (168 -> 192 pad) | K 168 | V 128 | S 4], sigmoid on S."""
+        self.ck, self.cv, self.ns = wq.shape[0], wv.shape[0], ws.shape[0]
+        self.ck_pad = _rup(self.ck, 32)
+        cin = wq.shape[1]
+        zpad = torch.zeros(self.ck_pad - self.ck, cin, 1, 1)
+        wall = torch.cat([wq.detach().cpu().float(), zpad, wk.detach().cpu().float(), wv.detach().cpu().float(),
+                          ws.detach().cpu().float()], 0)
+        P["anab.qkvs"] = PackedConv(self, wall, None, None)
+        self.anab_off = dict(q=0, k=self.ck_pad, v=self.ck_pad + self.ck, s=self.ck_pad + self.ck + self.cv)
+        self.anab_ctot = wall.shape[0]
+
+    def _pack_heads(self, sd, P):
+        dev = self.device
+
+        def head(p):
+            P[p + ".0"] = self._pc(p + ".0", p + ".1")
+            P[p + ".3"] = self._pc(p + ".3", p + ".4")
+            P[p + ".6"] = self._pc(p + ".6")
+
+        self.box_heads = ["bbox_x", "bbox_y", "bbox_w", "bbox_h", "bbox_x3d", "bbox_y3d", "bbox_z3d", "bbox_w3d",
+                          "bbox_h3d", "bbox_l3d", "bbox_rY3d"]
+        for h in ["cls"] + self.box_heads:
+            head(h)
+        for p in ("shape_align", "center_align2d", "center_align3d"):
+            P[p] = PackedConv(self, sd[p + ".align.weight"], sd[p + ".align.bias"], None, cout_pad_to=64)
+
+        a = "bbox_z3d_gl.0"
+        self._pack_anab(P, sd[a + ".query_conv.weight"], sd[a + ".key_conv.weight"], sd[a + ".value_conv.weight"],
+                        sd[a + ".spatial_conv.weight"])
+        g, be, m, v = (t.detach().to(dev, torch.float32) for t in self._bn("bbox_z3d_gl.1"))
+        s = g / torch.sqrt(v + BN_EPS)
+        P["anab.bn.scale"], P["anab.bn.shift"] = s.contiguous(), (be - m * s).contiguous()
+
+        # constants of the align stages
+        anchors = torch.as_tensor(np.asarray(self.conf.anchors), dtype=torch.float32)
+        aw = (anchors[:, 2] - anchors[:, 0])
+        ah = (anchors[:, 3] - anchors[:, 1])
+        tab = torch.zeros(self.A, 18, dtype=torch.float32)
+        h_step, w_step = ah / self.stride / 3, aw / self.stride / 3        # feturealign_mgpu.py:119-136
+        for i in range(3):
+            for j in range(3):
+                k = i * 3 + j
+                tab[:, 2 * k] = (h_step - 1) * (i - 3 / 2 + 0.5)
+                tab[:, 2 * k + 1] = (w_step - 1) * (j - 3 / 2 + 0.5)
+        P["shape.table"] = tab.to(dev).contiguous()
+        P["anchor_wh"] = torch.stack([aw / self.stride, ah / self.stride], 1).to(dev).contiguous()
+        P["anchors"] = anchors.to(dev).contiguous()
+        P["means"] = torch.as_tensor(np.asarray(self.conf.bbox_means), dtype=torch.float32).reshape(-1).to(dev)
+        P["stds"] = torch.as_tensor(np.asarray(self.conf.bbox_stds), dtype=torch.float32).reshape(-1).to(dev)
+
+    # ------------------------------------------------------------------ launch helpers
+    def _buf(self, plan, n, h, w, c, cs=None, name=None, zero=False):
+        cs = c if cs is None else cs
+        t = (torch.zeros if zero else torch.empty)(n * h * w * cs, device=self.device, dtype=torch.float32)
+        plan.keep.append(t)
+        v = View(t, n, h, w, c, cs)
+        if name:
+            plan.named[name] = v
+        return v
+
+    def _conv(self, plan, name, pc, x, out, stride=1, pad=0, act=0, res=None, res_mode=0, sigmoid_from=-1, om=None,
+              planar=None, affine=True, wgt_ptr=None, wgt_img_stride=0, cout=None, cout_pad=None, scale=None, shift=None,
+              kh=None, kw=None):
+        d = ConvDesc()
+        d.inp, d.in_cs, d.N, d.H, d.W, d.Cin = x.ptr, x.cs, x.n, x.h, x.w, x.c
+        kh = pc.kh if kh is None else kh
+        kw = pc.kw if kw is None else kw
+        d.wgt = pc.wp.data_ptr() if wgt_ptr is None else wgt_ptr
+        d.wgt_img_stride = wgt_img_stride
+        d.Cout = pc.cout if cout is None else cout
+        d.Cout_pad = pc.cout_pad if cout_pad is None else cout_pad
+        d.kh, d.kw, d.stride, d.pad, d.dil = kh, kw, stride, pad, 1
+        d.Ho = (x.h + 2 * pad - kh) // stride + 1
+        d.Wo = (x.w + 2 * pad - kw) // stride + 1
+        if planar is not None:
+            t, img_stride, ch_off = planar
+            d.out, d.out_nchw, d.out_img_stride = t.data_ptr() + 4 * ch_off * d.Ho * d.Wo, 1, img_stride
+        else:
+            assert out.h == d.Ho and out.w == d.Wo and out.c >= d.Cout, (name, out.h, out.w, d.Ho, d.Wo)
+            d.out, d.out_cs = out.ptr, out.cs
+        if scale is not None:
+            d.scale, d.shift = scale.data_ptr(), shift.data_ptr()
+            plan.keep += [scale, shift]
+        elif affine and pc is not None and pc.has_affine:
+            d.scale, d.shift = pc.scale.data_ptr(), pc.shift.data_ptr()
+        if res is not None:
+            d.res, d.res_cs, d.res_mode = res.ptr, res.cs, res_mode
+        d.act, d.sigmoid_from = act, sigmoid_from
+        if om is not None:
+            d.dcn_offmask, d.dcn_om_cs = om.ptr, om.cs
+        L = self.L
+        ref = ctypes.byref(d)
+        flops = 2.0 * x.n * d.Ho * d.Wo * d.Cout * kh * kw * x.c
+        plan.ops.append((name, "igemm", flops, lambda st: _hip.check(L.m3d_conv2d_forward(ref, st)), d))
+
+    def _op(self, plan, name, kind, fn):
+        plan.ops.append((name, kind, 0.0, fn, None))
+
+    # ------------------------------------------------------------------ plan construction
+    def _build_plan(self, B, H, W):
+        L, P = self.L, self.P
+        plan = _Plan()
+        chs = [16, 32, 64, 128, 256, 512]
+        b = "base.base"
+        x_in = torch.empty(B, 3, H, W, device=self.device, dtype=torch.float32)
+        plan.named["input"] = x_in
+        s0 = self._buf(plan, B, H, W, 16)
+        self._op(plan, "stem", "stem", lambda st: _hip.check(L.m3d_stem_conv7x7(
+            x_in.data_ptr(), P["stem.w"].data_ptr(), P["stem.scale"].data_ptr(), P["stem.shift"].data_ptr(), s0.ptr,
+            s0.cs, B, H, W, st)))
+        l0 = self._buf(plan, B, H, W, 16, name="level0")
+        self._conv(plan, "level0", P["level0"], s0, l0, 1, 1, act=1)
+        l1 = self._buf(plan, B, H // 2, W // 2, 32, name="level1")
+        self._conv(plan, "level1", P["level1"], l0, l1, 2, 1, act=1)
+
+        def maxpool(name, x, out):
+            self._op(plan, name, "maxpool", lambda st: _hip.check(L.m3d_maxpool2x2(
+                x.ptr, x.cs, out.ptr, out.cs, x.n, x.h, x.w, x.c, st)))
+
+        def block(p, x, res, out, stride):
+            co = P[p + ".conv1"].cout
+            t = self._buf(plan, B, out.h, out.w, co)
+            self._conv(plan, p + ".conv1", P[p + ".conv1"], x, t, stride, 1, act=1)
+            self._conv(plan, p + ".conv2", P[p + ".conv2"], t, out, 1, 1, act=1, res=res)
+
+        def tree1(p, x, co, stride, out, bottom=None):
+            """Tree(levels=1, level_root=False): pose_dla_dcn.py:314-323; root input = (x2, x1)."""
+            h, w = x.h // stride, x.w // stride
+            cat = self._buf(plan, B, h, w, 2 * co)
+            x2v, x1v = cat.slice(0, co), cat.slice(co, co)
+            if stride == 1:
+                bottom = x
+            elif bottom is None:
+                bottom = self._buf(plan, B, h, w, x.c)
+                maxpool(p + ".downsample", x, bottom)
+            if (p + ".project") in P:
+                res = self._buf(plan, B, h, w, co)
+                self._conv(plan, p + ".project", P[p + ".project"], bottom, res, 1, 0, act=0)
+            else:
+                res = bottom
+            block(p + ".tree1", x, res, x1v, stride)
+            block(p + ".tree2", x1v, x1v, x2v, 1)
+            self._conv(plan, p + ".root", P[p + ".root"], cat, out, 1, 0, act=1)
+
+        # level2: Tree(1, 32 -> 64, stride 2)
+        l2 = self._buf(plan, B, H // 4, W // 4, 64, name="level2")
+        tree1(b + ".level2", l1, 64, 2, l2)
+
+        def tree2(p, x, co, out):
+            """Tree(levels=2, level_root=True): pose_dla_dcn.py:314-327."""
+            ci = x.c
+            h, w = x.h // 2, x.w // 2
+            # tree2's root input: (x2'', x1'', bottom, X1)
+            catb = self._buf(plan, B, h, w, 2 * co + ci + co)
+            bottom = catb.slice(2 * co, ci)
+            X1 = catb.slice(2 * co + ci, co)
+            maxpool(p + ".downsample", x, bottom)
+            tree1(p + ".tree1", x, co, 2, X1, bottom=bottom)
+            # tree2 = Tree(1, co -> co, stride 1) writing x2'', x1'' into catb[0:2co]
+            x2v, x1v = catb.slice(0, co), catb.slice(co, co)
+            block(p + ".tree2.tree1", X1, X1, x1v, 1)
+            block(p + ".tree2.tree2", x1v, x1v, x2v, 1)
+            self._conv(plan, p + ".tree2.root", P[p + ".tree2.root"], catb, out, 1, 0, act=1)
+
+        l3 = self._buf(plan, B, H // 8, W // 8, 128, name="level3")
+        tree2(b + ".level3", l2, 128, l3)
+        l4 = self._buf(plan, B, H // 16, W // 16, 256, name="level4")
+        tree2(b + ".level4", l3, 256, l4)
+        # level5: Tree(1, 256 -> 512, stride 2, level_root): root input (x2, x1, bottom)
+        l5 = self._buf(plan, B, H // 32, W // 32, 512, name="level5")
+        h5, w5 = H // 32, W // 32
+        cat5 = self._buf(plan, B, h5, w5, 1024 + 256)
+        bottom5 = cat5.slice(1024, 256)
+        maxpool(b + ".level5.downsample", l4, bottom5)
+        res5 = self._buf(plan, B, h5, w5, 512)
+        self._conv(plan, b + ".level5.project", P[b + ".level5.project"], bottom5, res5, 1, 0, act=0)
+        block(b + ".level5.tree1", l4, res5, cat5.slice(512, 512), 2)
+        block(b + ".level5.tree2", cat5.slice(512, 512), cat5.slice(512, 512), cat5.slice(0, 512), 1)
+        self._conv(plan, b + ".level5.root", P[b + ".level5.root"], cat5, l5, 1, 0, act=1)
+
+        # ---- DLAUp / IDAUp ------------------------------------------------------------
+        def deform(p, x, out):
+            om = self._buf(plan, B, x.h, x.w, 27, 28)
+            self._conv(plan, p + ".offset_mask", P[p + ".om"], x, om, 1, 1, act=0, sigmoid_from=18)
+            self._conv(plan, p + ".dcn", P[p + ".dcn"], x, out, 1, 1, act=1, om=om)
+            plan.named[p + ".out"] = out
+
+        def ida_step(p, i, x, skip, co):
+            proj = self._buf(plan, B, x.h, x.w, co)
+            deform("%s.proj_%d" % (p, i), x, proj)
+            summed = self._buf(plan, B, 2 * x.h, 2 * x.w, co)
+            upw = P["%s.up_%d" % (p, i)]
+            self._op(plan, "%s.up_%d" % (p, i), "upsample", lambda st: _hip.check(L.m3d_upsample2x_add(
+                proj.ptr, proj.cs, upw.data_ptr(), skip.ptr, skip.cs, summed.ptr, summed.cs, B, proj.h, proj.w, co, st)))
+            node = self._buf(plan, B, 2 * x.h, 2 * x.w, co)
+            deform("%s.node_%d" % (p, i), summed, node)
+            return node
+
+        L5a = ida_step("base.dla_up.ida_0", 1, l5, l4, 256)            # 256 @ H/16
+        L4b = ida_step("base.dla_up.ida_1", 1, l4, l3, 128)            # 128 @ H/8
+        L5b = ida_step("base.dla_up.ida_1", 2, L5a, L4b, 128)          # 128 @ H/8
+        feats0 = ida_step("base.ida_up", 1, L5a, L5b, 128)             # 128 @ H/8
+        plan.named["feats0"] = feats0
+
+        plan.feat = (feats0.h, feats0.w)
+        if self.backbone_only:
+            return plan
+
+        # ---- RPN heads ----------------------------------------------------------------
+        fh, fw = feats0.h, feats0.w
+        HW = fh * fw
+        A, NC = self.A, self.NC
+        R = A * HW
+        cls_pl = torch.empty(B * NC * A * HW, device=self.device, dtype=torch.float32)
+        box_pl = torch.empty(B * 11 * A * HW, device=self.device, dtype=torch.float32)
+        plan.keep += [cls_pl, box_pl]
+        plan.named["cls_planar"], plan.named["box_planar"] = cls_pl, box_pl
+
+        def head(p, x, planar, k0=1):
+            h1 = self._buf(plan, B, fh, fw, 256)
+            self._conv(plan, p + ".0", P[p + ".0"], x, h1, 1, k0 // 2, act=1)
+            h2 = self._buf(plan, B, fh, fw, 256)
+            self._conv(plan, p + ".3", P[p + ".3"], h1, h2, 1, 0, act=1)
+            self._conv(plan, p + ".6", P[p + ".6"], h2, None, 1, 0, act=0, planar=planar)
+
+        head("cls", feats0, (cls_pl, NC * A * HW, 0), 3)
+        sel_idx = torch.empty(B * HW, device=self.device, dtype=torch.int32)
+        sel_prob = torch.empty(B * HW, device=self.device, dtype=torch.float32)
+        plan.keep += [sel_idx, sel_prob]
+        plan.named["sel_idx"], plan.named["sel_prob"] = sel_idx, sel_prob
+        self._op(plan, "anchor_select", "select", lambda st: _hip.check(L.m3d_anchor_select(
+            cls_pl.data_ptr(), B, A, NC, HW, sel_idx.data_ptr(), sel_prob.data_ptr(), None, st)))
+
+        means = np.asarray(self.conf.bbox_means, dtype=np.float32).reshape(-1)
+        stds = np.asarray(self.conf.bbox_stds, dtype=np.float32).reshape(-1)
+
+        def box_planar(k):
+            return (box_pl, 11 * A * HW, k * A)
+
+        def box_ptr(k):
+            return box_pl.data_ptr() + 4 * k * A * HW          # image 0; per-image stride handled via [B][11][A][HW]
+
+        # shape_align
+        om_sa = self._buf(plan, B, fh, fw, 27, 28)
+        self._op(plan, "shape_align.offsets", "align", lambda st: _hip.check(L.m3d_align_offsets(
+            0, sel_idx.data_ptr(), sel_prob.data_ptr(), 0.5, P["shape.table"].data_ptr(), None, None, None, 0.0, 1.0, 0.0,
+            1.0, om_sa.ptr, om_sa.cs, B, A, HW, 9, 0, st)))
+        feats = self._buf(plan, B, fh, fw, 128, name="feats")
+        self._conv(plan, "shape_align.dcn", P["shape_align"], feats0, feats, 1, 1, act=0, res=feats0, om=om_sa)
+        head("bbox_x", feats, box_planar(0))
+        head("bbox_y", feats, box_planar(1))
+
+        def center_align(p, x, kx, ky, mi, out):
+            om = self._buf(plan, B, fh, fw, 3, 4)
+            self._op(plan, p + ".offsets", "align", lambda st: _hip.check(L.m3d_align_offsets(
+                1, sel_idx.data_ptr(), sel_prob.data_ptr(), 0.5, None, box_ptr(kx), box_ptr(ky),
+                P["anchor_wh"].data_ptr(), float(means[mi]), float(stds[mi]), float(means[mi + 1]),
+                float(stds[mi + 1]), om.ptr, om.cs, B, A, HW, 1, 11 * A * HW, st)))
+            self._conv(plan, p + ".dcn", P[p], x, out, 1, 0, act=0, res=x, om=om)
+
+        f2d = self._buf(plan, B, fh, fw, 128, name="feats_align2d")
+        center_align("center_align2d", feats, 0, 1, 0, f2d)
+        head("bbox_w", f2d, box_planar(2))
+        head("bbox_h", f2d, box_planar(3))
+        head("bbox_x3d", feats, box_planar(4))
+        head("bbox_y3d", feats, box_planar(5))
+        f3d = self._buf(plan, B, fh, fw, 128, name="feats_align3d")
+        center_align("center_align3d", feats, 4, 5, 4, f3d)
+        head("bbox_w3d", f3d, box_planar(7))
+        head("bbox_h3d", f3d, box_planar(8))
+        head("bbox_l3d", f3d, box_planar(9))
+        head("bbox_rY3d", f3d, box_planar(10))
+
+        # ---- ANAB ---------------------------------------------------------------------
+        gl = self._buf(plan, B, fh, fw, 128, name="feats_gl")
+        self._anab_ops(plan, f3d, gl, P["anab.bn.scale"], P["anab.bn.shift"], act=1, res_mode=1)
+        head("bbox_z3d", gl, box_planar(6))
+
+        # ---- outputs ------------------------------------------------------------------
+        cls = torch.empty(B, R, NC, device=self.device, dtype=torch.float32)
+        prob = torch.empty(B, R, NC, device=self.device, dtype=torch.float32)
+        b2 = torch.empty(B, R, 4, device=self.device, dtype=torch.float32)
+        b3 = torch.empty(B, R, 7, device=self.device, dtype=torch.float32)
+        key = torch.empty(B, R, device=self.device, dtype=torch.int64)
+        plan.named.update(cls=cls, prob=prob, bbox_2d=b2, bbox_3d=b3, score_key=key)
+        assert NC == 4, "bundle kernel is written for 4 classes (bg + 3)"
+        self._op(plan, "bundle_outputs", "bundle", lambda st: _hip.check(L.m3d_bundle_outputs(
+            cls_pl.data_ptr(), box_pl.data_ptr(), cls.data_ptr(), prob.data_ptr(), b2.data_ptr(), b3.data_ptr(),
+            key.data_ptr(), B, A, HW, st)))
+        plan.feat = (fh, fw)
+        return plan
+
+
+    def _anab_ops(self, plan, x, out, scale, shift, act, res_mode):
+        """Append the ANAB launches: fused QKVS 1x1 conv -> weighted pyramid pooling -> logits GEMM (per-image
+        pooled keys as weights) -> row softmax -> P.V GEMM with the residual (+ optional BN/LeakyReLU) epilogue."""
+        L, P = self.L, self.P
+        B, fh, fw = x.n, x.h, x.w
+        HW = fh * fw
+        ctot, off = self.anab_ctot, self.anab_off
+        qkvs = self._buf(plan, B, fh, fw, ctot, _rup(ctot, 4))
+        self._conv(plan, "anab.qkvs", P["anab.qkvs"], x, qkvs, 1, 0, act=0, sigmoid_from=off["s"], affine=False)
+        items, bin_scale, bin_slots, bin_inv = self._anab_items(fh, fw)
+        n_bins, max_slots = len(bin_scale), int(bin_slots.max())
+        keys_pad = _rup(n_bins, 32)
+        d_items = torch.from_numpy(items).to(self.device)
+        d_bscale = torch.from_numpy(bin_scale).to(self.device)
+        d_bslots = torch.from_numpy(bin_slots).to(self.device)
+        d_binv = torch.from_numpy(bin_inv).to(self.device)
+        ckv = self.ck + self.cv
+        partial = torch.empty(B * n_bins * max_slots * ckv, device=self.device, dtype=torch.float32)
+        khat = torch.zeros(B * keys_pad * self.ck_pad, device=self.device, dtype=torch.float32)
+        vhatT = torch.zeros(B * self.cv * keys_pad, device=self.device, dtype=torch.float32)
+        plan.keep += [d_items, d_bscale, d_bslots, d_binv, partial, khat, vhatT]
+        plan.named["anab.khat"], plan.named["anab.vhatT"] = khat, vhatT
+        kvv, sv = qkvs.slice(off["k"], ckv), qkvs.slice(off["s"], self.ns)
+        self._op(plan, "anab.pool_partial", "anab_pool", lambda st: _hip.check(L.m3d_anab_pool_partial(
+            kvv.ptr, kvv.cs, sv.ptr, sv.cs, d_items.data_ptr(), items.shape[0], d_bscale.data_ptr(), n_bins,
+            partial.data_ptr(), max_slots, B, fh, fw, ckv, st)))
+        self._op(plan, "anab.pool_finish", "anab_pool", lambda st: _hip.check(L.m3d_anab_pool_finish(
+            partial.data_ptr(), d_bslots.data_ptr(), d_binv.data_ptr(), n_bins, max_slots, self.ck, self.cv,
+            khat.data_ptr(), keys_pad, self.ck_pad, vhatT.data_ptr(), B, st)))
+        logits = self._buf(plan, B, fh, fw, keys_pad)
+        qv = qkvs.slice(off["q"], self.ck_pad)
+        self._conv(plan, "anab.logits", None, qv, logits, 1, 0, act=0, affine=False, wgt_ptr=khat.data_ptr(),
+                   wgt_img_stride=keys_pad * self.ck_pad, cout=n_bins, cout_pad=keys_pad, kh=1, kw=1)
+        self._op(plan, "anab.softmax", "softmax", lambda st: _hip.check(L.m3d_softmax_rows(
+            logits.ptr, B * HW, n_bins, keys_pad, st)))
+        self._conv(plan, "anab.pv", None, logits, out, 1, 0, act=act, res=x, res_mode=res_mode,
+                   wgt_ptr=vhatT.data_ptr(), wgt_img_stride=self.cv * keys_pad, cout=self.cv,
+                   cout_pad=_rup(self.cv, 32), kh=1, kw=1, scale=scale, shift=shift)
+
+    @classmethod
+    def anab_standalone(cls, mod, x):
+        """ANAB.forward for a stand-alone module: x is an NHWC View; returns the output View."""
+        eng = cls.__new__(cls)
+        eng.L, eng.device, eng.profile, eng.P = _hip.lib(), x.t.device, None, {}
+        eng._pack_anab(eng.P, mod.query_conv.weight, mod.key_conv.weight, mod.value_conv.weight,
+                       mod.spatial_conv.weight)
+        plan = _Plan()
+        out = eng._buf(plan, x.n, x.h, x.w, x.c)
+        eng._anab_ops(plan, x, out, None, None, act=0, res_mode=0)
+        eng.run_plan(plan)
+        out.keep = plan          # keep the intermediate buffers alive until the caller has copied out
+        return out
+
+    @staticmethod
+    def _anab_items(H, W, max_rows=None):
+        """Work items of the pyramid pooling: AdaptiveAvgPool2d windows (start = floor(i*H/s),
+        end = ceil((i+1)*H/s)) split into row chunks of ceil(H/16) rows."""
+        chunk = max(1, math.ceil(H / 16))
+        items, bin_scale, bin_slots, bin_inv = [], [], [], []
+        b = 0
+        for si, s in enumerate(PSP_SIZES):
+            for i in range(s):
+                h0, h1 = (i * H) // s, -((-(i + 1) * H) // s)
+                for j in range(s):
+                    w0, w1 = (j * W) // s, -((-(j + 1) * W) // s)
+                    slot = 0
+                    for r0 in range(h0, h1, chunk):
+                        items.append((b, r0, min(r0 + chunk, h1), w0, w1, slot))
+                        slot += 1
+                    bin_scale.append(si)
+                    bin_slots.append(slot)
+                    bin_inv.append(1.0 / ((h1 - h0) * (w1 - w0)))
+                    b += 1
+        return (np.asarray(items, dtype=np.int32), np.asarray(bin_scale, dtype=np.int32),
+                np.asarray(bin_slots, dtype=np.int32), np.asarray(bin_inv, dtype=np.float32))
+
+    # ------------------------------------------------------------------ execution
+    def plan_for(self, B, H, W):
+        key = (B, H, W)
+        if key not in self.plans:
+            if H % 32 or W % 32:
+                raise RuntimeError("input H and W must be multiples of 32 (got %dx%d)" % (H, W))
+            with torch.cuda.device(self.device):
+                self.plans[key] = self._build_plan(B, H, W)
+        return self.plans[key]
+
+    def forward(self, x):
+        """x: float32 [B,3,H,W] on the engine's device -> (cls, prob, bbox_2d, bbox_3d) device tensors
+        (views of plan-owned buffers, overwritten by the next call with the same shape)."""
+        if not x.is_cuda:
+            raise NotImplementedError("M3DSSD HIP engine: input must be a ROCm device tensor")
+        B, _, H, W = x.shape
+        plan = self.plan_for(B, H, W)
+        plan.named["input"].copy_(x)
+        self.run_plan(plan)
+        n = plan.named
+        return n["cls"], n["prob"], n["bbox_2d"], n["bbox_3d"]
+
+    def forward_backbone(self, x):
+        """Backbone + DCN up-sampling only (DLASeg.forward): returns the NHWC View of the 128-channel map."""
+        B, _, H, W = x.shape
+        plan = self.plan_for(B, H, W)
+        plan.named["input"].copy_(x)
+        self.run_plan(plan)
+        return plan.named["feats0"]
+
+    def run_plan(self, plan):
+        st = _Stream.current()
+        if self.profile is None:
+            for op in plan.ops:
+                op[3](st)
+            return
+        L = self.L
+        evs = []
+        for op in plan.ops:
+            e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+            _hip.check(L.m3d_event_create(ctypes.byref(e0)))
+            _hip.check(L.m3d_event_create(ctypes.byref(e1)))
+            _hip.check(L.m3d_event_record(e0, st))
+            op[3](st)
+            _hip.check(L.m3d_event_record(e1, st))
+            evs.append((op, e0, e1))
+        for op, e0, e1 in evs:
+            ms = ctypes.c_float()
+            _hip.check(L.m3d_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+            self.profile.append((op[0], op[1], op[2], ms.value))
+            L.m3d_event_destroy(e0)
+            L.m3d_event_destroy(e1)

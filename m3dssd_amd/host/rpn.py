@@ -1,0 +1,112 @@
+"""RPN module + ``build`` with the reference's interface (model/M3d_inference_align.py:31-331).
+
+``RPN.forward(x)`` returns exactly what the reference does in eval mode --
+``(cls [B,N,4], prob [B,N,4], bbox_2d [B,N,4], bbox_3d [B,N,7], feat_size [2], rois [N,5])`` --
+computed by the HIP engine.  Training (phase='train') is out of scope for this path."""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import rpn_util
+from ..engine import Engine
+from .align import center_align, shape_align
+from .attention import ANAB
+from .dla import DLASeg
+
+BOX_HEADS_A = ["bbox_x", "bbox_y", "bbox_w", "bbox_h", "bbox_x3d", "bbox_y3d"]
+BOX_HEADS_B = ["bbox_w3d", "bbox_h3d", "bbox_l3d", "bbox_rY3d"]
+
+
+def _head(cin, mid, cout, k0):
+    return nn.Sequential(nn.Conv2d(cin, mid, k0, padding=k0 // 2), nn.BatchNorm2d(mid), nn.LeakyReLU(inplace=True),
+                         nn.Conv2d(mid, mid, 1), nn.BatchNorm2d(mid), nn.LeakyReLU(inplace=True),
+                         nn.Conv2d(mid, cout, 1))
+
+
+class RPN(nn.Module):
+    def __init__(self, phase, base, conf):
+        super().__init__()
+        self.base = base
+        self.phase = phase
+        self.device = conf.device
+        self.num_classes = len(conf["lbls"]) + 1
+        self.num_anchors = conf["anchors"].shape[0]
+        self.anchors = torch.tensor(conf.anchors, dtype=torch.float, device=self.device, requires_grad=False)
+        self.bbox_means, self.bbox_stds = conf.bbox_means[0], conf.bbox_stds[0]
+        self.base_channels, self.head_channels = self.base.out_channels, 256
+        self.back_bone, self.batch_size = conf.back_bone, conf.batch_size
+        self.align_type = conf.align_type if "align_type" in conf else "max"
+        self.attention = conf.attention if "attention" in conf else None
+        self.feat_stride = conf.feat_stride
+        self.feat_size = rpn_util.calc_output_size(np.array(conf.crop_size), self.feat_stride)
+        self.rois = rpn_util.locate_anchors(conf.anchors, self.feat_size, conf.feat_stride, convert_tensor=True)
+        self.rois = self.rois.float().to(self.device)
+        if not (conf.center_align and conf.shape_align and self.attention == "ANAB"):
+            raise NotImplementedError("this build implements the anab_fullalign configuration "
+                                      "(center_align, shape_align, attention='ANAB')")
+        c, m, a = self.base_channels, self.head_channels, self.num_anchors
+        self.cls = _head(c, m, a * self.num_classes, 3)
+        for h in BOX_HEADS_A:
+            setattr(self, h, _head(c, m, a, 1))
+        self.center_align2d = center_align(c, self.anchors, xy_mean=self.bbox_means[0:2], xy_std=self.bbox_stds[0:2],
+                                           feat_stride=self.feat_stride, feat_size=self.feat_size, kernel_size=1, k=1,
+                                           thresh=0.5)
+        self.center_align3d = center_align(c, self.anchors, xy_mean=self.bbox_means[4:6], xy_std=self.bbox_stds[4:6],
+                                           feat_stride=self.feat_stride, feat_size=self.feat_size, kernel_size=1, k=1,
+                                           thresh=0.5)
+        self.shape_align = shape_align(c, self.anchors, feat_stride=self.feat_stride, feat_size=self.feat_size,
+                                       kernel_size=3, k=1, thresh=0.5)
+        self.bbox_z3d = _head(c, m, a, 1)
+        self.bbox_z3d_gl = nn.Sequential(ANAB(c, 1), nn.BatchNorm2d(c), nn.LeakyReLU(inplace=True))
+        for h in BOX_HEADS_B:
+            setattr(self, h, _head(c, m, a, 1))
+        self.softmax = nn.Softmax(dim=1)
+        self._conf = conf
+        self._engine = None
+        self._engine_version = None
+
+    # -- engine management: (re)pack parameters whenever they change ------------------------------
+    def _param_version(self):
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def engine(self):
+        ver = self._param_version()
+        if self._engine is None or ver != self._engine_version:
+            dev = next(self.parameters()).device
+            if dev.type != "cuda":
+                raise NotImplementedError("RPN.forward runs on a ROCm device only; move the module with .to('cuda') "
+                                          "(the reference's DCNv2 has no CPU path either, dcn_v2_func.py:23-24)")
+            self._engine = Engine(self.state_dict(), self._conf, device=dev)
+            self._engine_version = ver
+        return self._engine
+
+    def forward(self, x):
+        if self.training:
+            raise NotImplementedError("m3dssd_amd accelerates inference (eval mode); call .eval() or build(conf, 'test')")
+        feat_h, feat_w = x.shape[2] // self.feat_stride, x.shape[3] // self.feat_stride
+        assert feat_h == self.feat_size[0], "x.shape is {}".format(x.shape)
+        with torch.no_grad():
+            cls, prob, bbox_2d, bbox_3d = self.engine().forward(x.float())
+        feat_size = torch.tensor([feat_h, feat_w], dtype=torch.float, device=x.device)
+        if self.feat_size[0] != feat_h or self.feat_size[1] != feat_w:
+            self.feat_size = [feat_h, feat_w]
+            self.rois = rpn_util.locate_anchors(self.anchors, self.feat_size, self.feat_stride, convert_tensor=True)
+            self.rois = self.rois.float().to(x.device)
+        if self.rois.device != x.device:
+            self.rois = self.rois.to(x.device)
+        return cls, prob, bbox_2d, bbox_3d, feat_size, self.rois
+
+
+def build(conf, phase="train"):
+    train = phase.lower() == "train"
+    base_name = conf.back_bone
+    if base_name[0:3] != "dla":
+        raise NotImplementedError
+    base = DLASeg(base_name, pretrained=conf.pre_train, down_ratio=conf.feat_stride, final_kernel=1, last_level=5,
+                  head_conv=256, conf=conf)
+    rpn_net = RPN(phase, base, conf)
+    if train:
+        rpn_net.train()
+    else:
+        rpn_net.eval()
+    return rpn_net

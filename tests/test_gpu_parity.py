@@ -1,0 +1,411 @@
+"""GPU parity suite (-m gpu): every check calls the HIP library through the C ABI (ctypes) and compares
+with the CPU oracle (oracle/) or with the golden vectors generated from the reference.
+
+Tolerances (fp32 path; BASELINE.json: "3D box params within 1e-3 abs fp32, NMS indices bit-exact"):
+  * single ops vs torch-CPU/oracle: 2e-4 * (1 + |ref|) -- different fp32 summation order only;
+  * whole network with the SAME discrete decisions (top-1 anchor, hard mask): 1e-3 abs on all outputs;
+  * discrete decisions themselves: identical except where the oracle's own margin is < 1e-4
+    (1-ulp flips of topk / '> 0.5' are legitimate, SURVEY.md section 7 "hard parts");
+  * NMS keep lists: bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from m3dssd_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.fail("no ROCm device visible: the gpu-marked tests must run on the MI355X box")
+    return torch.device("cuda:0")
+
+
+def _relerr(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / (1.0 + np.abs(b))))
+
+
+# ------------------------------------------------------------------------------------ library
+def test_library_loads_and_reports_errors():
+    from m3dssd_amd import _hip
+    L = _hip.lib()
+    assert L.m3d_abi_version() == 1
+    d = _hip.ConvDesc()
+    assert L.m3d_conv2d_forward(d, None) != 0          # null pointers -> M3D_E_ARG, no crash
+    assert b"null" in L.m3d_last_error()
+    with pytest.raises(NotImplementedError):
+        from m3dssd_amd.host import ops
+        ops.dcn_v2_forward(torch.zeros(1, 2, 4, 4), torch.zeros(1, 18, 4, 4), torch.zeros(1, 9, 4, 4),
+                           torch.zeros(2, 2, 3, 3), torch.zeros(2), 1, 1)
+
+
+# ------------------------------------------------------------------------------------ conv
+CONV_CASES = [
+    # N, Cin, H, W, Cout, k, stride, pad, bias, bn, act, res
+    (2, 16, 20, 24, 16, 3, 1, 1, False, True, 1, False),      # level0-like, BK=16 path
+    (2, 16, 20, 24, 32, 3, 2, 1, False, True, 1, False),      # level1-like, stride 2
+    (1, 32, 18, 22, 64, 3, 2, 1, True, True, 1, False),       # tree conv1 stride 2
+    (1, 64, 17, 19, 64, 3, 1, 1, True, True, 1, True),        # conv2 + residual, ragged M
+    (1, 128, 16, 40, 128, 3, 1, 1, True, True, 1, True),
+    (2, 256, 8, 20, 256, 3, 1, 1, True, True, 1, True),
+    (1, 448, 16, 40, 128, 1, 1, 0, False, True, 1, False),    # root conv over a 448-ch concat
+    (1, 128, 16, 40, 256, 1, 1, 0, True, True, 1, False),     # head layer 1
+    (1, 128, 9, 11, 27, 3, 1, 1, True, False, 0, False),      # offset/mask conv (Cout 27)
+    (3, 512, 4, 10, 512, 3, 1, 1, True, True, 1, True),       # level5-like, small M
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_igemm_matches_torch(case):
+    from m3dssd_amd.host import standalone as S
+    dev = _dev()
+    n, ci, h, w, co, k, stride, pad, bias, bn, act, res = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+    b = torch.randn(co, generator=g) if bias else None
+    bnm = None
+    ref = F.conv2d(x, wt, b, stride=stride, padding=pad)
+    if bn:
+        bnm = torch.nn.BatchNorm2d(co).eval()
+        with torch.no_grad():
+            bnm.weight.uniform_(0.5, 1.5, generator=g)
+            bnm.bias.normal_(0, 0.2, generator=g)
+            bnm.running_mean.normal_(0, 0.2, generator=g)
+            bnm.running_var.uniform_(0.5, 1.5, generator=g)
+        ref = bnm(ref)
+    r = None
+    if res:
+        r = torch.randn_like(ref)
+        ref = ref + r
+    if act:
+        ref = F.leaky_relu(ref, 0.01)
+    with torch.no_grad():
+        v, _ = S._to_nhwc(x.to(dev))
+        rv = S._to_nhwc(r.to(dev))[0] if res else None
+        out, keep = S.conv_nhwc(v, wt.to(dev), None if b is None else b.to(dev), None if bnm is None else bnm.to(dev),
+                                stride, pad, act=act, res=rv)
+        got = S._to_nchw(out, co).cpu()
+    assert got.shape == ref.shape
+    assert _relerr(got, ref.detach()) < 2e-4
+
+
+def test_conv_planar_output_and_sigmoid_channels():
+    """SWAP (planar NCHW) epilogue + per-channel sigmoid, as used by the head outputs / offset-mask conv."""
+    import ctypes
+    from m3dssd_amd import _hip
+    from m3dssd_amd.host import standalone as S
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    n, ci, h, w, co = 2, 256, 16, 40, 36
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 1, 1, generator=g) / 16
+    b = torch.randn(co, generator=g)
+    ref = F.conv2d(x, wt, b)
+    v, _ = S._to_nhwc(x.to(dev))
+    wp, co_, cop, kh, kw = S._pack(wt.to(dev), v.c, 32)
+    scale, shift = S._affine(co, b.to(dev), None, dev)
+    out = torch.zeros(n, 3, co, h * w, device=dev)          # write into slot 1 of a [n][3][co][hw] staging tensor
+    d = _hip.ConvDesc()
+    d.inp, d.in_cs, d.N, d.H, d.W, d.Cin = v.ptr, v.cs, n, h, w, v.c
+    d.wgt, d.Cout, d.Cout_pad = wp.data_ptr(), co, cop
+    d.kh, d.kw, d.stride, d.pad, d.dil, d.Ho, d.Wo = 1, 1, 1, 0, 1, h, w
+    d.out, d.out_nchw, d.out_img_stride = out.data_ptr() + 4 * co * h * w, 1, 3 * co * h * w
+    d.scale, d.shift, d.sigmoid_from = scale.data_ptr(), shift.data_ptr(), 30
+    _hip.check(_hip.lib().m3d_conv2d_forward(ctypes.byref(d), S._stream()))
+    got = out[:, 1].view(n, co, h, w).cpu()
+    ref[:, 30:] = torch.sigmoid(ref[:, 30:])
+    assert _relerr(got, ref) < 2e-4
+    assert out[:, 0].abs().max().item() == 0 and out[:, 2].abs().max().item() == 0
+
+
+# ------------------------------------------------------------------------------------ DCNv2
+def test_dcn_zero_offset_identity_known_answer():
+    """The reference's own op test, model/DCNv2/test.py:32-65, run through the drop-in modules."""
+    from model.DCNv2.dcn_v2 import DCNv2
+    dev = _dev()
+    torch.manual_seed(0)
+    N, C, H, W = 2, 2, 4, 4
+    conv_offset = torch.nn.Conv2d(C, 18, 3, padding=1).to(dev)
+    conv_mask = torch.nn.Conv2d(C, 9, 3, padding=1).to(dev)
+    dcn = DCNv2(C, C, (3, 3), stride=1, padding=1, dilation=1, deformable_groups=1).to(dev)
+    with torch.no_grad():
+        for m in (conv_offset, conv_mask):
+            m.weight.zero_()
+            m.bias.zero_()
+        dcn.weight.zero_()
+        dcn.bias.zero_()
+        for c in range(C):
+            dcn.weight[c, c, 1, 1] = 1.0
+        x = torch.randn(N, C, H, W, device=dev)
+        out = dcn(x, conv_offset(x), torch.sigmoid(conv_mask(x)))
+    assert (x - out * 2).abs().max().item() < 1e-10
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 5, 6, 3, 3, 1, 1), (1, 128, 16, 40, 128, 3, 1, 1), (2, 256, 8, 20, 128, 3, 1, 1),
+                                   (1, 512, 4, 10, 256, 3, 1, 1), (2, 128, 16, 40, 128, 1, 1, 0), (1, 20, 9, 7, 5, 3, 2, 1)])
+def test_dcn_matches_oracle(shape):
+    from m3dssd_amd.host import ops
+    from oracle import dcn as odcn
+    dev = _dev()
+    n, c, h, w, co, k, stride, pad = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(co, c, k, k, generator=g) / (c * k * k) ** 0.5
+    b = torch.randn(co, generator=g)
+    ho, wo = odcn.out_size(h, w, k, k, stride, pad, 1)
+    off = torch.randn(n, 2 * k * k, ho, wo, generator=g) * 3.0     # plenty of samples outside the map
+    off[0, 0, 0, 0] = -1.0 + (1 if pad == 0 else 0) * 0.0            # exact -1 boundary (gate is strict)
+    m = torch.rand(n, k * k, ho, wo, generator=g)
+    ref = odcn.dcn_v2_forward(x, off, m, wt, b, stride, pad, 1, 1)
+    got = ops.dcn_v2_forward(x.to(dev), off.to(dev), m.to(dev), wt.to(dev), b.to(dev), stride, pad, 1, 1).cpu()
+    assert got.shape == ref.shape
+    assert _relerr(got, ref) < 2e-4
+
+
+def test_dcn_module_errors_like_reference():
+    from model.DCNv2.dcn_v2 import DCNv2
+    dev = _dev()
+    dcn = DCNv2(4, 4, 3, 1, 1).to(dev)
+    with pytest.raises(RuntimeError):       # channel mismatch (dcn_v2_cuda.c:37-39)
+        dcn(torch.zeros(1, 3, 4, 4, device=dev), torch.zeros(1, 18, 4, 4, device=dev), torch.zeros(1, 9, 4, 4, device=dev))
+    with pytest.raises(NotImplementedError):  # CPU input (dcn_v2_func.py:23-24)
+        DCNv2(4, 4, 3, 1, 1)(torch.zeros(1, 4, 4, 4), torch.zeros(1, 18, 4, 4), torch.zeros(1, 9, 4, 4))
+
+
+# ------------------------------------------------------------------------------------ NMS
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 300, 3000])
+def test_nms_bit_exact_vs_reference_golden(n):
+    from lib.nms.gpu_nms import gpu_nms
+    _dev()
+    g = np.load(os.path.join(GOLDEN, "nms.npz"))
+    keep = gpu_nms(g["dets_%d" % n], 0.4, 0)
+    assert np.array_equal(np.asarray(keep, dtype=np.int64), g["keep_%d" % n])
+
+
+@pytest.mark.parametrize("thr", [0.0, 0.25, 0.4, 0.5, 1.0])
+def test_nms_threshold_ties_bit_exact(thr):
+    from lib.nms.gpu_nms import gpu_nms
+    _dev()
+    g = np.load(os.path.join(GOLDEN, "nms.npz"))
+    assert np.array_equal(np.asarray(gpu_nms(g["dets_grid"], thr), dtype=np.int64), g["keep_grid_%g" % thr])
+
+
+def test_nms_batched_device_api_and_properties():
+    """Batched device entry == oracle per image; idempotence: NMS of the kept set keeps everything."""
+    from m3dssd_amd.host import ops
+    from oracle import nms as onms
+    dev = _dev()
+    B, n = 5, 3000
+    dets = np.stack([synth.synth_boxes(n, seed=100 + i) for i in range(B)])
+    order = np.stack([onms.order_desc_stable(d[:, 4]) for d in dets])
+    srt = np.stack([d[o] for d, o in zip(dets, order)])
+    keep, num = ops.nms_sorted(torch.from_numpy(srt).to(dev), 0.4)
+    keep, num = keep.cpu().numpy(), num.cpu().numpy()
+    for i in range(B):
+        ref = onms.nms_sorted(srt[i], 0.4)
+        assert num[i] == len(ref) and np.array_equal(keep[i, :num[i]], ref)
+        kept = srt[i][ref]
+        k2, n2 = ops.nms_sorted(torch.from_numpy(kept).to(dev), 0.4)
+        assert int(n2[0]) == len(ref) and np.array_equal(k2[0, :len(ref)].cpu().numpy(), np.arange(len(ref)))
+    assert ops.nms_sorted(torch.zeros(0, 5, device=dev), 0.4)[1].item() == 0
+    assert gpu_nms_empty() == []
+
+
+def gpu_nms_empty():
+    from lib.nms.gpu_nms import gpu_nms
+    return gpu_nms(np.zeros((0, 5), dtype=np.float32), 0.4)
+
+
+# ------------------------------------------------------------------------------------ whole network
+def _run_both(crop, B, pad):
+    from model.M3d_inference_align import build
+    from oracle import model_cpu
+    dev = _dev()
+    conf = synth.synth_conf(crop, 0, batch_size=B, device="cuda:0")
+    sd = synth.synth_state_dict(0)
+    x = synth.synth_frames(B, crop, 1234, pad_right_third=pad)
+    net = build(conf, "test")
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev)
+    with torch.no_grad():
+        out = net(x.to(dev))
+    eng = net.engine()
+    plan = eng.plan_for(B, crop[0], crop[1])
+    fh, fw = crop[0] // 8, crop[1] // 8
+    ind = plan.named["sel_idx"].view(B, 1, fh, fw).long().cpu()
+    prob_sel = plan.named["sel_prob"].view(B, 1, fh, fw).cpu()
+    # oracle free-running (its own decisions) and oracle with the engine's decisions injected
+    cconf = synth.synth_conf(crop, 0, batch_size=B, device="cpu")
+    taps_free, taps_inj = {}, {}
+    with torch.no_grad():
+        free = model_cpu.rpn_forward(sd, cconf, x, taps_free)
+        inj = model_cpu.rpn_forward(sd, cconf, x, taps_inj,
+                                    inject={"sel": {"ind": ind, "hard": (prob_sel > 0.5).float()}})
+    return net, plan, out, free, inj, taps_free, taps_inj, ind, prob_sel
+
+
+def _check_decisions(taps_free, ind, prob_sel):
+    """Engine decisions == oracle decisions except at near-ties of the oracle's own fg probabilities."""
+    fg = taps_free["fg_prob"]
+    o_mask, o_ind = fg.max(dim=1, keepdim=True)
+    diff = (o_ind != ind)
+    if diff.any():
+        alt = torch.gather(fg, 1, ind)
+        assert ((o_mask - alt)[diff].abs() < 1e-4).all(), "top-1 anchor differs beyond a near-tie"
+    assert (prob_sel - torch.gather(fg, 1, ind)).abs().max().item() < 1e-4
+    hard_o, hard_e = (o_mask > 0.5), (prob_sel > 0.5)
+    flip = hard_o != hard_e
+    if flip.any():
+        assert ((o_mask - 0.5)[flip].abs() < 1e-4).all(), "hard mask differs beyond a near-tie at 0.5"
+    return int(diff.sum()), int(flip.sum())
+
+
+@pytest.mark.parametrize("crop,B,pad", [((128, 320), 2, False), ((384, 1280), 1, True)])
+def test_forward_matches_oracle(crop, B, pad):
+    net, plan, out, free, inj, taps_free, taps_inj, ind, prob_sel = _run_both(crop, B, pad)
+    cls, prob, b2, b3, fs, rois = (t.cpu() for t in out)
+    # stage-wise: backbone levels and DCN outputs (no discrete decisions upstream)
+    for name in ("level0", "level1", "level2", "level3", "level4", "level5"):
+        got = plan.named[name].torch_nchw().cpu()
+        assert _relerr(got, taps_free[name]) < 5e-4, name
+    for name in ("base.dla_up.ida_0.proj_1.out", "base.dla_up.ida_0.node_1.out", "base.dla_up.ida_1.node_2.out",
+                 "base.ida_up.node_1.out"):
+        got = plan.named[name].torch_nchw().cpu()
+        assert _relerr(got, taps_free[name]) < 1e-3, name
+    assert _relerr(cls, free[0]) < 1e-3                         # cls head: upstream of every decision
+    n_idx, n_flip = _check_decisions(taps_free, ind, prob_sel)
+    # downstream of the decisions: compare with the oracle run that takes the SAME decisions
+    for name in ("feats", "feats_align2d", "feats_align3d", "feats_gl"):
+        got = plan.named[name].torch_nchw().cpu()
+        assert (got - taps_inj[name]).abs().max().item() < 1e-3, name
+    o_cls, o_prob, o_b2, o_b3, o_fs, o_rois = inj
+    assert (prob - o_prob).abs().max().item() < 1e-4
+    assert (b2 - o_b2).abs().max().item() < 1e-3
+    assert (b3 - o_b3).abs().max().item() < 1e-3               # BASELINE.json: 3D box params within 1e-3 abs
+    assert torch.equal(rois, o_rois) and torch.equal(fs, o_fs)
+    if n_idx == 0 and n_flip == 0:                              # no legit flips: free-running oracle must agree too
+        assert (b3 - free[3]).abs().max().item() < 1e-3
+
+
+def test_forward_matches_reference_golden_samples():
+    """Against the vectors dumped from the reference itself (tools/gen_golden.py), full size."""
+    net, plan, out, free, inj, taps_free, taps_inj, ind, prob_sel = _run_both((384, 1280), 1, True)
+    g = np.load(os.path.join(GOLDEN, "model_384x1280_b1.npz"))
+    st = int(g["stride"])
+    cls = out[0].cpu()
+    assert cls.shape == (1, 276480, 4)
+    assert np.abs(cls[:, ::st].numpy() - g["cls"]).max() < 1e-3
+    n_idx, n_flip = _check_decisions(taps_free, ind, prob_sel)
+    if n_idx == 0 and n_flip == 0:
+        assert np.abs(out[3].cpu()[:, ::st].numpy() - g["bbox_3d"]).max() < 1e-3
+        assert np.abs(out[1].cpu()[:, ::st].numpy() - g["prob"]).max() < 1e-4
+
+
+def test_batch_invariance_and_determinism():
+    """Images are independent units: image i of a batch == the same image alone; two runs are bit-identical."""
+    from model.M3d_inference_align import build
+    dev = _dev()
+    conf = synth.synth_conf((128, 320), 0, batch_size=3, device="cuda:0")
+    net = build(conf, "test")
+    net.load_state_dict(synth.synth_state_dict(0))
+    net = net.to(dev)
+    x = synth.synth_frames(3, (128, 320), 77).to(dev)
+    with torch.no_grad():
+        a = [t.clone() for t in net(x)[:4]]
+        b = [t.clone() for t in net(x)[:4]]
+        single = [t.clone() for t in net(x[1:2])[:4]]
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    for u, s in zip(a, single):
+        assert (u[1:2] - s).abs().max().item() < 1e-4
+
+
+# ------------------------------------------------------------------------------------ detection
+def test_detect_matches_oracle_given_same_network_outputs():
+    """decode + top-k + NMS on the device vs oracle/detect.py fed with the ENGINE's network outputs:
+    kept anchors/classes identical, coordinates to fp32 roundoff."""
+    from lib.rpn_util import im_detect_3d, detect_batch
+    from model.M3d_inference_align import build
+    from oracle import detect as odet
+    dev = _dev()
+    crop, B = (128, 320), 2
+    conf = synth.synth_conf(crop, 0, batch_size=B, device="cuda:0")
+    net = build(conf, "test")
+    net.load_state_dict(synth.synth_state_dict(0))
+    net = net.to(dev)
+    x = synth.synth_frames(B, crop, 1234)
+    ab = im_detect_3d(x[0], net, conf)
+    with torch.no_grad():
+        cls, prob, b2, b3, fs, rois = (t.cpu() for t in net(x[:1].to(dev)))
+    ref, keep, top = odet.detect_image(prob[0], b2[0], b3[0], rois, conf)
+    assert ab.shape == ref.shape
+    assert np.array_equal(ab[:, 13], ref[:, 13]) and np.array_equal(ab[:, 5], ref[:, 5])
+    assert np.abs(ab - ref).max() < 1e-3 * max(1.0, np.abs(ref).max())
+    dets, counts = detect_batch(net, x.to(dev), conf)
+    assert dets.shape == (B, conf.nms_topN_post, 14) and counts.shape == (B,)
+    k = int(counts[0])
+    assert k == min(len(ref), conf.nms_topN_post)
+    assert np.abs(dets[0, :k].cpu().numpy() - ref[:k]).max() < 1e-3 * max(1.0, np.abs(ref).max())
+    assert dets[0, k:].abs().max().item() == 0 if k < conf.nms_topN_post else True
+
+
+# ------------------------------------------------------------------------------------ standalone modules
+def test_standalone_modules_match_oracle():
+    from model.module.attention import ANAB
+    from model.module.feturealign_mgpu import center_align, shape_align
+    from model.pose_dla_dcn import DeformConv
+    from oracle import model_cpu
+    dev = _dev()
+    sd = synth.synth_state_dict(0)
+    conf = synth.synth_conf((128, 320), 0, device="cuda:0")
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 128, 16, 40, generator=g)
+    # DeformConv
+    p = "base.ida_up.node_1"
+    dc = DeformConv(128, 128).eval()
+    dc.load_state_dict({k[len(p) + 1:]: v for k, v in sd.items() if k.startswith(p + ".")})
+    ref = model_cpu.deform_conv(sd, p, x)
+    assert _relerr(dc.to(dev)(x.to(dev)).cpu(), ref) < 5e-4
+    # ANAB
+    an = ANAB(128, 1).eval()
+    an.load_state_dict({k[len("bbox_z3d_gl.0."):]: v for k, v in sd.items() if k.startswith("bbox_z3d_gl.0.")})
+    ref = model_cpu.anab(sd, "bbox_z3d_gl.0", x)
+    assert _relerr(an.to(dev)(x.to(dev)).cpu(), ref) < 5e-4
+    # align modules (distinct fg probabilities -> unambiguous top-1)
+    fg = torch.rand(2, 36, 16, 40, generator=g)
+    anchors = torch.from_numpy(conf.anchors)
+    sa = shape_align(128, anchors, 8, [16, 40]).eval()
+    sa.load_state_dict({k[len("shape_align."):]: v for k, v in sd.items() if k.startswith("shape_align.")})
+    ref = model_cpu.shape_align(sd, "shape_align", x, fg, conf.anchors, 8)
+    assert _relerr(sa.to(dev)(x.to(dev), fg.to(dev)).cpu(), ref) < 5e-4
+    bx, by = torch.randn(2, 36, 16, 40, generator=g), torch.randn(2, 36, 16, 40, generator=g)
+    ca = center_align(128, anchors, conf.bbox_means[0][0:2], conf.bbox_stds[0][0:2], 8, [16, 40]).eval()
+    ca.load_state_dict({k[len("center_align2d."):]: v for k, v in sd.items() if k.startswith("center_align2d.")})
+    ref = model_cpu.center_align(sd, "center_align2d", x, bx, by, fg, conf.anchors, conf.bbox_means[0][0:2],
+                                 conf.bbox_stds[0][0:2], 8)
+    got = ca.to(dev)(x.to(dev), bx.to(dev), by.to(dev), fg.to(dev)).cpu()
+    assert _relerr(got, ref) < 5e-4
+
+
+def test_dlaseg_standalone_matches_oracle():
+    from model.pose_dla_dcn import DLASeg
+    from oracle import model_cpu
+    dev = _dev()
+    sd = synth.synth_state_dict(0)
+    conf = synth.synth_conf((128, 320), 0, device="cuda:0")
+    m = DLASeg("dla34", False, 8, 1, 5, 256, conf).eval()
+    m.load_state_dict({k[len("base."):]: v for k, v in sd.items() if k.startswith("base.")})
+    x = synth.synth_frames(1, (128, 320), 5)
+    ref = model_cpu.dla_seg(sd, "base", x)
+    got = m.to(dev)(x.to(dev)).cpu()
+    assert got.shape == ref.shape == (1, 128, 16, 40)
+    assert _relerr(got, ref) < 1e-3

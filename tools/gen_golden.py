@@ -33,8 +33,15 @@ OUT = os.path.join(REPO, "tests", "golden")
 
 
 def _install_stubs():
+    # The repo ships import-path shims named ``model`` / ``lib`` (regular packages), which would win over
+    # the reference's namespace packages: import what we need from the repo first, then drop it from sys.path.
+    sys.path.insert(0, REPO)
+    import m3dssd_amd.synth  # noqa: F401
+    import oracle.dcn  # noqa: F401
+    sys.path[:] = [p for p in sys.path if os.path.abspath(p or ".") != REPO]
+    for k in [k for k in sys.modules if k == "model" or k.startswith("model.") or k == "lib" or k.startswith("lib.")]:
+        del sys.modules[k]
     sys.path.insert(0, REF)
-    sys.path.insert(1, REPO)
     for name in ["torchvision", "torchvision.models", "cv2", "shapely", "shapely.geometry", "numba",
                  "numba.cuda", "skimage", "skimage.io", "tensorboardX", "fire", "mpl_toolkits",
                  "mpl_toolkits.mplot3d"]:
