@@ -56,7 +56,7 @@ struct DcnWs {
 static DcnWs dcn_ws(int n, int c, int h, int w, int co, int kh, int kw, int stride, int pad, int dil)
 {
     DcnWs s;
-    s.cp = (int)rup(c, 16);
+    s.cp = (int)rup(c, 32);   // deformable tiles use BK = 32
     s.co_pad = (int)rup(co, 64);
     s.ho = (h + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
     s.wo = (w + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;

@@ -109,13 +109,14 @@ extern "C" int m3d_nms_sorted_dev(const float *boxes_dev, int B, int n, int box_
                                   int *keep_dev, int *num_keep_dev, m3d_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    M3D_REQUIRE(boxes_dev && mask_ws && keep_dev && num_keep_dev, "nms: null pointer");
-    M3D_REQUIRE(B >= 1 && box_stride >= 4, "nms: bad batch / box_stride");
+    M3D_REQUIRE(num_keep_dev && B >= 1, "nms: null pointer / bad batch");
     M3D_REQUIRE(n >= 0 && n <= 64 * NMS_TPB, "nms: n (%d) must be <= 4096", n);
-    if (n == 0) {
+    if (n == 0) {   // empty input: nothing kept (boxes/keep may legitimately be null)
         M3D_HIP(hipMemsetAsync(num_keep_dev, 0, sizeof(int) * B, stream));
         return M3D_OK;
     }
+    M3D_REQUIRE(boxes_dev && mask_ws && keep_dev, "nms: null pointer");
+    M3D_REQUIRE(box_stride >= 4, "nms: box_stride must be >= 4");
     const int cb = (n + NMS_TPB - 1) / NMS_TPB;
     hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, B), dim3(NMS_TPB), 0, stream, n, box_stride, thresh, boxes_dev,
                        (unsigned long long *)mask_ws);

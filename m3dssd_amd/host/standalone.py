@@ -85,7 +85,7 @@ def dcn_layer_forward(dcn, x):
     """DCN.forward, model/DCNv2/dcn_v2.py:64-70."""
     _require_cuda(x)
     with torch.no_grad(), torch.cuda.device(x.device):
-        v, _ = _to_nhwc(x)
+        v, _ = _to_nhwc(x, 32)
         out, keep = dcn_layer_nhwc(dcn, v)
         return _to_nchw(out, dcn.out_channels)
 
@@ -96,7 +96,7 @@ def deform_conv_forward(mod, x):
     if mod.training:
         raise NotImplementedError("DeformConv: eval mode only (BatchNorm statistics are folded)")
     with torch.no_grad(), torch.cuda.device(x.device):
-        v, _ = _to_nhwc(x)
+        v, _ = _to_nhwc(x, 32)
         out, keep = dcn_layer_nhwc(mod.conv, v, bn=mod.actf[0], act=1)
         return _to_nchw(out, mod.conv.out_channels)
 
@@ -143,7 +143,7 @@ def shape_align_forward(mod, x, prob):
         _hip.check(L.m3d_align_offsets(0, idx.data_ptr(), val.data_ptr(), float(mod.thresh), tab.data_ptr(), None, None,
                                        None, 0.0, 1.0, 0.0, 1.0, om.ptr, om.cs, B, mod.num_anchors, H * W, kk, 0,
                                        _stream()))
-        v, _ = _to_nhwc(x)
+        v, _ = _to_nhwc(x, 32)
         out, keep = conv_nhwc(v, mod.align.weight, mod.align.bias, None, 1, mod.align.padding, act=0, res=v, om=om,
                               cout_pad_to=64)
         return _to_nchw(out, C)
@@ -165,7 +165,7 @@ def center_align_forward(mod, x, bbox_x, bbox_y, prob):
                                        by.data_ptr(), awh.data_ptr(), float(mod.xy_mean[0]), float(mod.xy_std[0]),
                                        float(mod.xy_mean[1]), float(mod.xy_std[1]), om.ptr, om.cs, B, A, H * W, 1,
                                        A * H * W, _stream()))
-        v, _ = _to_nhwc(x)
+        v, _ = _to_nhwc(x, 32)
         out, keep = conv_nhwc(v, mod.align.weight, mod.align.bias, None, 1, mod.align.padding, act=0, res=v, om=om,
                               cout_pad_to=64)
         return _to_nchw(out, C)

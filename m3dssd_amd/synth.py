@@ -27,6 +27,7 @@ HEADS = ["cls", "bbox_x", "bbox_y", "bbox_w", "bbox_h", "bbox_x3d", "bbox_y3d"]
 HEADS_TAIL = ["bbox_z3d"]
 HEADS_TAIL2 = ["bbox_w3d", "bbox_h3d", "bbox_l3d", "bbox_rY3d"]
 BG_BIAS = 4.2
+BOX_OUT_GAIN = 0.15
 
 
 def _bn(spec, p, c):
@@ -182,6 +183,8 @@ def synth_state_dict(seed=0, num_anchors=36, num_classes=4):
                 v = g.normal(0.0, 1.0 / math.sqrt(fan_in), shape)
             else:
                 v = g.normal(0.0, 0.8 * math.sqrt(2.0 / fan_in), shape)
+                if name.startswith("bbox_") and name.endswith(".6.weight"):
+                    v = v * BOX_OUT_GAIN                      # regression deltas ~N(0, 0.3): realistic align offsets
         dt = torch.int64 if leaf == "num_batches_tracked" else torch.float32
         sd[name] = torch.from_numpy(np.asarray(v)).to(dt).reshape(shape)
     return sd
