@@ -105,7 +105,9 @@ class Engine:
         with torch.cuda.device(self.device):
             self._pack(sd)
         self.plans = {}
-        self.profile = None    # set to a list to collect (name, ms) per op
+        self.profile = None    # set to a list to collect (name, kind, flops, ms) per op (HIP events on the launch stream)
+        self.profile_kinds = None   # optional set: only ops of these kinds are bracketed with events
+        self._pending = []
 
     # ------------------------------------------------------------------ parameters
     def _bn(self, p):
@@ -230,7 +232,7 @@ class Engine:
 
     def _conv(self, plan, name, pc, x, out, stride=1, pad=0, act=0, res=None, res_mode=0, sigmoid_from=-1, om=None,
               planar=None, affine=True, wgt_ptr=None, wgt_img_stride=0, cout=None, cout_pad=None, scale=None, shift=None,
-              kh=None, kw=None):
+              kh=None, kw=None, cin_true=None):
         d = ConvDesc()
         d.inp, d.in_cs, d.N, d.H, d.W, d.Cin = x.ptr, x.cs, x.n, x.h, x.w, x.c
         kh = pc.kh if kh is None else kh
@@ -260,8 +262,15 @@ class Engine:
             d.dcn_offmask, d.dcn_om_cs = om.ptr, om.cs
         L = self.L
         ref = ctypes.byref(d)
-        flops = 2.0 * x.n * d.Ho * d.Wo * d.Cout * kh * kw * x.c
-        plan.ops.append((name, "igemm", flops, lambda st: _hip.check(L.m3d_conv2d_forward(ref, st)), d))
+        bm, bn, bk, grid = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _hip.check(L.m3d_conv2d_tile(ref, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(bk), ctypes.byref(grid)))
+        kind = "igemm<%d,%d,%d%s%s>" % (bm.value, bn.value, bk.value, ",deform" if om is not None else "",
+                                        ",planar" if planar is not None else "")
+        # algorithmic FLOPs of the layer: 2 * pixels * Cout * taps * Cin (true channel counts, no padding)
+        if cin_true is None:
+            cin_true = pc.cin if (pc is not None and wgt_ptr is None) else x.c
+        flops = 2.0 * x.n * d.Ho * d.Wo * d.Cout * kh * kw * cin_true
+        plan.ops.append((name, kind, flops, lambda st: _hip.check(L.m3d_conv2d_forward(ref, st)), d))
 
     def _op(self, plan, name, kind, fn):
         plan.ops.append((name, kind, 0.0, fn, None))
@@ -272,11 +281,11 @@ class Engine:
         plan = _Plan()
         chs = [16, 32, 64, 128, 256, 512]
         b = "base.base"
-        x_in = torch.empty(B, 3, H, W, device=self.device, dtype=torch.float32)
-        plan.named["input"] = x_in
+        in_ptr = [0]                      # set by forward(): the caller's NCHW tensor is read in place
+        plan.named["input_ptr"] = in_ptr
         s0 = self._buf(plan, B, H, W, 16)
         self._op(plan, "stem", "stem", lambda st: _hip.check(L.m3d_stem_conv7x7(
-            x_in.data_ptr(), P["stem.w"].data_ptr(), P["stem.scale"].data_ptr(), P["stem.shift"].data_ptr(), s0.ptr,
+            in_ptr[0], P["stem.w"].data_ptr(), P["stem.scale"].data_ptr(), P["stem.shift"].data_ptr(), s0.ptr,
             s0.cs, B, H, W, st)))
         l0 = self._buf(plan, B, H, W, 16, name="level0")
         self._conv(plan, "level0", P["level0"], s0, l0, 1, 1, act=1)
@@ -493,12 +502,12 @@ class Engine:
         logits = self._buf(plan, B, fh, fw, keys_pad)
         qv = qkvs.slice(off["q"], self.ck_pad)
         self._conv(plan, "anab.logits", None, qv, logits, 1, 0, act=0, affine=False, wgt_ptr=khat.data_ptr(),
-                   wgt_img_stride=keys_pad * self.ck_pad, cout=n_bins, cout_pad=keys_pad, kh=1, kw=1)
+                   wgt_img_stride=keys_pad * self.ck_pad, cout=n_bins, cout_pad=keys_pad, kh=1, kw=1, cin_true=self.ck)
         self._op(plan, "anab.softmax", "softmax", lambda st: _hip.check(L.m3d_softmax_rows(
             logits.ptr, B * HW, n_bins, keys_pad, st)))
         self._conv(plan, "anab.pv", None, logits, out, 1, 0, act=act, res=x, res_mode=res_mode,
                    wgt_ptr=vhatT.data_ptr(), wgt_img_stride=self.cv * keys_pad, cout=self.cv,
-                   cout_pad=_rup(self.cv, 32), kh=1, kw=1, scale=scale, shift=shift)
+                   cout_pad=_rup(self.cv, 32), kh=1, kw=1, scale=scale, shift=shift, cin_true=n_bins)
 
     @classmethod
     def anab_standalone(cls, mod, x):
@@ -554,7 +563,8 @@ class Engine:
             raise NotImplementedError("M3DSSD HIP engine: input must be a ROCm device tensor")
         B, _, H, W = x.shape
         plan = self.plan_for(B, H, W)
-        plan.named["input"].copy_(x)
+        x = x.contiguous()
+        plan.named["input_ptr"][0] = x.data_ptr()
         self.run_plan(plan)
         n = plan.named
         return n["cls"], n["prob"], n["bbox_2d"], n["bbox_3d"]
@@ -563,7 +573,8 @@ class Engine:
         """Backbone + DCN up-sampling only (DLASeg.forward): returns the NHWC View of the 128-channel map."""
         B, _, H, W = x.shape
         plan = self.plan_for(B, H, W)
-        plan.named["input"].copy_(x)
+        x = x.contiguous()
+        plan.named["input_ptr"][0] = x.data_ptr()
         self.run_plan(plan)
         return plan.named["feats0"]
 
@@ -576,6 +587,9 @@ class Engine:
         L = self.L
         evs = []
         for op in plan.ops:
+            if self.profile_kinds is not None and op[1] not in self.profile_kinds:
+                op[3](st)
+                continue
             e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
             _hip.check(L.m3d_event_create(ctypes.byref(e0)))
             _hip.check(L.m3d_event_create(ctypes.byref(e1)))
@@ -583,9 +597,15 @@ class Engine:
             op[3](st)
             _hip.check(L.m3d_event_record(e1, st))
             evs.append((op, e0, e1))
-        for op, e0, e1 in evs:
+        self._pending += evs
+
+    def flush_profile(self):
+        """Resolve the recorded HIP events (synchronises) into self.profile rows (name, kind, flops, ms)."""
+        L = self.L
+        for op, e0, e1 in self._pending:
             ms = ctypes.c_float()
             _hip.check(L.m3d_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
             self.profile.append((op[0], op[1], op[2], ms.value))
             L.m3d_event_destroy(e0)
             L.m3d_event_destroy(e1)
+        self._pending = []

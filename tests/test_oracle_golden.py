@@ -18,7 +18,7 @@ from oracle import detect as odet
 from oracle import model_cpu
 from oracle import nms as onms
 
-torch.set_num_threads(max(1, os.cpu_count() or 1))
+torch.set_num_threads(min(16, max(1, os.cpu_count() or 1)))
 
 
 def _load(golden_dir, name):
