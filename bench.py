@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-layers", default=None, help="write the per-launch table of one instrumented step here")
     args = ap.parse_args()
 
     from m3dssd_amd import dist as mdist
@@ -104,6 +105,11 @@ def main():
     step()
     torch.cuda.synchronize()
     eng.flush_profile()
+    if args.dump_layers and rank == 0:
+        with open(args.dump_layers, "w") as f:
+            f.write("name,kernel,gflop,ms,tflops\n")
+            for name, kind, flops, ms in eng.profile:
+                f.write("%s,\"%s\",%.3f,%.4f,%.1f\n" % (name, kind, flops / 1e9, ms, flops / 1e9 / max(ms, 1e-6)))
     per_kind = {}
     for name, kind, flops, ms in eng.profile:
         a = per_kind.setdefault(kind, [0.0, 0.0, 0])

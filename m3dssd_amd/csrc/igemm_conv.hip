@@ -19,6 +19,8 @@
 //   sigmoid, and writes NHWC (lanes along channels: 128 B per half-wave) or, in SWAP mode, planar
 //   NCHW (operands swapped so lanes run along pixels) -- the layout the RPN outputs need.
 // * blockIdx is remapped so each XCD (private L2) works on a contiguous range of tiles.
+#include <stdlib.h>
+
 #include "common.h"
 
 struct IgemmArgs {
@@ -38,6 +40,7 @@ struct IgemmArgs {
     int M, Ktot, KT;
     int tiles_m, tiles_n;
     int act, sigmoid_from, res_mode;
+    int ablate;   // diagnostics only (M3D_ABLATE): 1 = no steady-state global loads, 2 = no MFMA, 4 = no LDS refill
 };
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool DEFORM, bool SWAP>
@@ -199,9 +202,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
     const int l31 = lane & 31, lh4 = (lane >> 5) * 4;
     for (int kt = 0; kt < a.KT; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < a.KT) load_tile(kt + 1);
+        if (kt + 1 < a.KT && !(a.ablate & 1)) load_tile(kt + 1);
         const float *Ab = As + buf * BM * LDK + (wm + l31) * LDK + lh4;
         const float *Bb = Bs + buf * BN * LDK + (wn + l31) * LDK + lh4;
+        if (!(a.ablate & 2))
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
             f32x4 fa[TM], fb[TN];
@@ -221,8 +225,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
                     }
         }
-        if (kt + 1 < a.KT) store_tile(buf ^ 1);
-        __syncthreads();
+        if (kt + 1 < a.KT && !(a.ablate & 4)) store_tile(buf ^ 1);
+        if (!(a.ablate & 4)) __syncthreads();
     }
 
     // ---- epilogue ----------------------------------------------------------------------
@@ -316,8 +320,15 @@ static int choose_tile(const m3d_conv_desc *d, TileChoice *t)
     if (t->bk == 16) t->bn = 32;
     t->bm = 128;
     if (t->bn >= 64) {
+        static int thr = -1;                     // tuning knob (experiments only): M3D_BM_THRESHOLD
+        if (thr < 0) { const char *e = getenv("M3D_BM_THRESHOLD"); thr = e ? atoi(e) : 2 * 256; }
         const long long blocks128 = ((M + 127) / 128) * ((d->Cout_pad + t->bn - 1) / t->bn);
-        if (blocks128 < 2 * 256) t->bm = 64;     // under two blocks per CU: smaller tiles fill the chip
+        if (blocks128 < thr) t->bm = 64;         // under two blocks per CU: smaller tiles fill the chip
+    }
+    {
+        static int fbn = -1;                     // tuning knob (experiments only): M3D_FORCE_BN
+        if (fbn < 0) { const char *e = getenv("M3D_FORCE_BN"); fbn = e ? atoi(e) : 0; }
+        if (fbn && t->bk == 32 && t->bn > fbn && !d->out_nchw) t->bn = fbn;
     }
     if (d->wgt_img_stride && (d->Ho * d->Wo) % t->bm != 0) {
         t->bm = 64;
@@ -366,6 +377,11 @@ extern "C" int m3d_conv2d_forward(const m3d_conv_desc *d, m3d_stream_t stream_)
     a.M = (int)M; a.Ktot = d->kh * d->kw * d->Cin; a.KT = a.Ktot / t.bk;
     a.tiles_m = a.tiles_n = 0;
     a.act = d->act; a.sigmoid_from = d->sigmoid_from; a.res_mode = d->res_mode;
+    {
+        static int abl = -1;
+        if (abl < 0) { const char *e = getenv("M3D_ABLATE"); abl = e ? atoi(e) : 0; }
+        a.ablate = abl;
+    }
 
     const bool deform = d->dcn_offmask != nullptr, swap = d->out_nchw != 0;
     if (deform) {
