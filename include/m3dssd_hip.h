@@ -21,6 +21,7 @@
  *                                 chains of model/pose_dla_dcn.py:107-121,261-269,379-389 and the RPN
  *                                 heads model/M3d_inference_align.py:66-210, plus (deformable mode)
  *                                 the fused im2col+GEMM of dcn_v2_cuda.c:80-96 without `columns`
+ *   m3d_head_mlp_forward ....... the 3-layer 1x1 heads, model/M3d_inference_align.py:77-210 (one launch per head)
  *   m3d_stem_conv7x7 ........... DLA.base_layer, model/pose_dla_dcn.py:336-340
  *   m3d_maxpool2x2 ............. Tree.downsample nn.MaxPool2d(2,2), pose_dla_dcn.py:306,316
  *   m3d_upsample2x_add ......... IDAUp: depthwise ConvTranspose2d(4, s2, p1) + skip add,
@@ -95,6 +96,30 @@ int m3d_conv2d_forward(const m3d_conv_desc *d, m3d_stream_t stream);
 
 /* Average launch geometry chosen for a descriptor (for roofline bookkeeping / tests). */
 int m3d_conv2d_tile(const m3d_conv_desc *d, int *bm, int *bn, int *bk, int *grid);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused RPN head (model/M3d_inference_align.py:77-210): per-pixel MLP
+ *   [1x1 Cin->256 + affine + LeakyReLU] -> 1x1 256->256 + affine + LeakyReLU -> 1x1 256->Cout + affine
+ * in ONE launch; hidden activations stay in LDS.  Cin = 128 with w1 given (3 layers) or Cin = 256 with
+ * w1 = NULL (2 layers: `in` is already the first hidden activation, e.g. after the 3x3 cls conv).
+ * Weights are packed in MFMA-fragment order: element W[J*32 + r][G*8 + h*4 + t] (row-tile J, k-group G,
+ * r < 32, h < 2, t < 4) at float index ((J*(K/8) + G)*64 + h*32 + r)*4 + t; rows zero-padded to 256 for
+ * w1/w2 and to Cout_pad in {64, 256} for w3.  Output is planar: out[n*out_img_stride + c*HW + p].
+ * ------------------------------------------------------------------------------------------ */
+typedef struct m3d_mlp_desc {
+    const float *in;          /* NHWC view [M][in_cs], first Cin channels used                     */
+    int in_cs;
+    long long M;              /* pixels = N*H*W                                                    */
+    int Cin;
+    const float *w1, *s1, *t1;
+    const float *w2, *s2, *t2;
+    const float *w3, *s3, *t3;
+    int Cout, Cout_pad;
+    float *out;
+    long long out_img_stride;
+    int HW;
+} m3d_mlp_desc;
+int m3d_head_mlp_forward(const m3d_mlp_desc *d, m3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Drop-in for dcn_v2_cuda_forward: NCHW contiguous fp32 device tensors, exactly the reference

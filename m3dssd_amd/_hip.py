@@ -34,12 +34,25 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class MlpDesc(ctypes.Structure):
+    """Mirror of ``m3d_mlp_desc``."""
+    _fields_ = [
+        ("inp", c_void_p), ("in_cs", c_int), ("M", c_ll), ("Cin", c_int),
+        ("w1", c_void_p), ("s1", c_void_p), ("t1", c_void_p),
+        ("w2", c_void_p), ("s2", c_void_p), ("t2", c_void_p),
+        ("w3", c_void_p), ("s3", c_void_p), ("t3", c_void_p),
+        ("Cout", c_int), ("Cout_pad", c_int),
+        ("out", c_void_p), ("out_img_stride", c_ll), ("HW", c_int),
+    ]
+
+
 P = c_void_p
 # name -> (restype, argtypes); every name here must be declared in include/m3dssd_hip.h
 SIGNATURES = {
     "m3d_last_error": (ctypes.c_char_p, []),
     "m3d_abi_version": (c_int, []),
     "m3d_conv2d_forward": (c_int, [ctypes.POINTER(ConvDesc), P]),
+    "m3d_head_mlp_forward": (c_int, [ctypes.POINTER(MlpDesc), P]),
     "m3d_conv2d_tile": (c_int, [ctypes.POINTER(ConvDesc)] + [ctypes.POINTER(c_int)] * 4),
     "m3d_dcn_v2_workspace_bytes": (c_ll, [c_int] * 10),
     "m3d_dcn_v2_forward": (c_int, [P] * 6 + [c_int] * 14 + [P, c_ll, P]),

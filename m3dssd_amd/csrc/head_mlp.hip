@@ -1,0 +1,220 @@
+// Fused RPN head: the per-pixel MLP  1x1 Cin->256 (+BN+LeakyReLU) -> 1x1 256->256 (+BN+LeakyReLU) -> 1x1 256->Cout
+// of model/M3d_inference_align.py:77-210 as ONE kernel per head (the reference runs 3 convs + 2 BN + 2 LeakyReLU
+// launches per head and round-trips two 256-channel intermediates, 7.9 MB each per image, through HBM).
+//
+// One workgroup owns 64 pixels and ALL 256 hidden channels, so the hidden activations never leave the CU:
+//   * the activation tile lives in LDS as act[64][256+4] (fp32, 65 KB -> two workgroups per CU) and is rewritten
+//     in place between layers (layer output sits in the MFMA accumulators until every wave has finished reading);
+//   * each wave owns its own 64 output channels, so a weight tile has NO reuse inside the workgroup: weights are
+//     pre-packed in MFMA-fragment order ([row-tile][k-group][lane][4], see Engine/pack_frag) and every wave
+//     loads its B fragments straight global->register -- one fully coalesced 1 KB load per (row-tile, k-group) --
+//     double-buffered one k-tile ahead across layer boundaries.  No weight staging in LDS, no barrier inside a layer;
+//   * math: v_mfma_f32_32x32x2_f32 with the k-permuted fragment order of igemm_conv.hip (lane half h, step t ->
+//     k = 8g + 4h + t); the last layer swaps operands so lanes run along pixels and writes the planar [Cout][HW]
+//     layout the RPN outputs need (lib/rpn_util.py:892-901 row order).
+// Arithmetic per output element is the same k-ordered fp32 fma chain as the unfused igemm path.
+#include "common.h"
+
+struct MlpArgs {
+    const float *in;
+    const float *w[3];       // fragment-packed; w[0] may be null (2-layer form: input is the first hidden)
+    const float *scale[3];
+    const float *shift[3];
+    float *out;
+    long long out_img_stride;
+    int in_cs, M, HW, Cin, Cout, Cout_pad;
+};
+
+#define MLP_BM 64
+#define MLP_H 256
+#define MLP_LDA (MLP_H + 4)
+#define MLP_BK 32
+
+template <bool HAS_L1, int N3>
+__global__ __launch_bounds__(256) void head_mlp_kernel(const MlpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float act[];   // [64][260]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh4 = (lane >> 5) * 4, hrow = 4 * (lane >> 5);
+    const int m0 = blockIdx.x * MLP_BM;
+    const int kt1 = HAS_L1 ? a.Cin / MLP_BK : 0, kt2 = MLP_H / MLP_BK, kt3 = MLP_H / MLP_BK;
+    const int n_tiles = kt1 + kt2 + kt3;
+    // output-layer tiling: N3 = 64 -> waves 2 (px) x 2 (ch) of 32x32;  N3 = 256 -> like the hidden layers
+    constexpr int TNo = (N3 == 64) ? 1 : 2;
+
+    // ---- B-fragment stream: tile t of the concatenated layers -> 2 row-tiles x 4 k-groups per wave --------
+    // packed weight element W[J*32 + l31][G*8 + h*4 + 0..3] sits at ((J*(K/8) + G)*64 + lane)*4
+    f32x4 fb[2][4], fbn[2][4];
+    auto load_frags = [&](int t, f32x4 (&dst)[2][4]) {
+        const float *w;
+        int kgroups, kt, j0, nj;
+        if (HAS_L1 && t < kt1) { w = a.w[0]; kgroups = a.Cin / 8; kt = t; j0 = wave * 2; nj = 2; }
+        else if (t < kt1 + kt2) { w = a.w[1]; kgroups = MLP_H / 8; kt = t - kt1; j0 = wave * 2; nj = 2; }
+        else { w = a.w[2]; kgroups = MLP_H / 8; kt = t - kt1 - kt2; j0 = (N3 == 64) ? (wave & 1) : wave * 2; nj = TNo; }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (j < nj)
+                    dst[j][g] = *reinterpret_cast<const f32x4 *>(
+                        w + ((size_t)((j0 + j) * kgroups + kt * 4 + g) * 64 + lane) * 4);
+    };
+
+    load_frags(0, fb);
+    // ---- stage the input tile: act[row][0..Cin) ----------------------------------------------------------
+    {
+        const int c4n = a.Cin / 4;                    // float4 per row
+        for (int i = tid; i < MLP_BM * c4n; i += 256) {
+            const int row = i / c4n, c4 = i - row * c4n;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m0 + row < a.M) v = *reinterpret_cast<const f32x4 *>(a.in + (size_t)(m0 + row) * a.in_cs + c4 * 4);
+            *reinterpret_cast<f32x4 *>(act + row * MLP_LDA + c4 * 4) = v;
+        }
+    }
+    __syncthreads();
+
+    int t = 0;   // position in the weight stream
+    // ---- hidden layers: each wave computes 64 px x 64 ch -------------------------------------------------
+    auto hidden_layer = [&](int layer, int KT) {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int wn = wave * 64;
+        for (int kt = 0; kt < KT; ++kt, ++t) {
+            if (t + 1 < n_tiles) load_frags(t + 1, fbn);
+            const float *Ab = act + l31 * MLP_LDA + kt * MLP_BK + lh4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 fa[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * MLP_LDA + g * 8);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][g][s], acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) fb[j][g] = fbn[j][g];
+        }
+        // affine + LeakyReLU in registers, then overwrite the activation tile in place
+        const float *sc = a.scale[layer], *sh = a.shift[layer];
+        __syncthreads();                              // every wave has finished reading the old tile
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int co = wn + j * 32 + l31;
+            const float s = sc[co], b = sh[co];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + hrow;
+                    act[row * MLP_LDA + co] = leaky(acc[i][j][r] * s + b);
+                }
+        }
+        __syncthreads();
+    };
+    if (HAS_L1) hidden_layer(0, kt1);
+    hidden_layer(1, kt2);
+
+    // ---- output layer: 64 px x N3 channels, operands swapped -> D[channel][pixel] ------------------------
+    {
+        constexpr int TMo = (N3 == 64) ? 1 : 2;
+        const int wm = (N3 == 64) ? (wave >> 1) * 32 : 0;
+        const int wn = (N3 == 64) ? (wave & 1) * 32 : wave * 64;
+        f32x16 acc[TMo][TNo];
+#pragma unroll
+        for (int i = 0; i < TMo; ++i)
+#pragma unroll
+            for (int j = 0; j < TNo; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int kt = 0; kt < kt3; ++kt, ++t) {
+            if (t + 1 < n_tiles) load_frags(t + 1, fbn);
+            const float *Ab = act + (wm + l31) * MLP_LDA + kt * MLP_BK + lh4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 fa[TMo];
+#pragma unroll
+                for (int i = 0; i < TMo; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * MLP_LDA + g * 8);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < TMo; ++i)
+#pragma unroll
+                        for (int j = 0; j < TNo; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][g][s], fa[i][s], acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < TNo; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) fb[j][g] = fbn[j][g];
+        }
+        const float *sc = a.scale[2], *sh = a.shift[2];
+#pragma unroll
+        for (int i = 0; i < TMo; ++i) {
+            const int m = m0 + wm + i * 32 + l31;
+            const bool mok = m < a.M;
+            const int mm = mok ? m : 0;
+            const int n = mm / a.HW, pix = mm - n * a.HW;
+            float *ob = a.out + (long long)n * a.out_img_stride + pix;
+#pragma unroll
+            for (int j = 0; j < TNo; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = wn + j * 32 + (r & 3) + 8 * (r >> 2) + hrow;
+                    if (mok && co < a.Cout) ob[(size_t)co * a.HW] = acc[i][j][r] * sc[co] + sh[co];
+                }
+        }
+    }
+}
+
+template <bool HAS_L1, int N3>
+static int launch_mlp(const MlpArgs &a, hipStream_t stream)
+{
+    constexpr size_t smem = (size_t)(MLP_BM * MLP_LDA) * sizeof(float);
+    auto kern = head_mlp_kernel<HAS_L1, N3>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        M3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(cdiv(a.M, MLP_BM)), dim3(256), smem, stream, a);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+extern "C" int m3d_head_mlp_forward(const m3d_mlp_desc *d, m3d_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    M3D_REQUIRE(d && d->in && d->w2 && d->w3 && d->out, "head_mlp: null pointer");
+    M3D_REQUIRE(d->s2 && d->t2 && d->s3 && d->t3, "head_mlp: scale/shift of layers 2 and 3 are required");
+    M3D_REQUIRE((d->Cin == 128 && d->w1 && d->s1 && d->t1) || (d->Cin == 256 && !d->w1),
+                "head_mlp: Cin must be 128 (3 layers, w1 given) or 256 (2 layers, w1 NULL)");
+    M3D_REQUIRE(d->in_cs % 4 == 0 && d->in_cs >= d->Cin && ((uintptr_t)d->in & 15) == 0, "head_mlp: input alignment");
+    M3D_REQUIRE(d->Cout >= 1 && d->Cout <= d->Cout_pad && (d->Cout_pad == 64 || d->Cout_pad == 256),
+                "head_mlp: Cout_pad must be 64 or 256 (got %d)", d->Cout_pad);
+    M3D_REQUIRE(d->M > 0 && d->M < (1ll << 30) && d->HW > 0, "head_mlp: bad M / HW");
+    MlpArgs a;
+    a.in = d->in; a.in_cs = d->in_cs; a.M = (int)d->M; a.HW = d->HW; a.Cin = d->Cin;
+    a.w[0] = d->w1; a.w[1] = d->w2; a.w[2] = d->w3;
+    a.scale[0] = d->s1; a.scale[1] = d->s2; a.scale[2] = d->s3;
+    a.shift[0] = d->t1; a.shift[1] = d->t2; a.shift[2] = d->t3;
+    a.out = d->out; a.out_img_stride = d->out_img_stride; a.Cout = d->Cout; a.Cout_pad = d->Cout_pad;
+    if (d->w1) {
+        if (d->Cout_pad == 64) return launch_mlp<true, 64>(a, stream);
+        return launch_mlp<true, 256>(a, stream);
+    }
+    if (d->Cout_pad == 64) return launch_mlp<false, 64>(a, stream);
+    return launch_mlp<false, 256>(a, stream);
+}

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _hip
-from ._hip import ConvDesc
+from ._hip import ConvDesc, MlpDesc
 
 BN_EPS = 1e-5
 PSP_SIZES = (1, 4, 8, 16)
@@ -78,6 +78,16 @@ class PackedConv:
             scale = s
         self.scale, self.shift = scale.contiguous(), shift.contiguous()
         self.has_affine = (bias is not None) or (bn is not None)
+
+
+def pack_frag(weight2d, rows_pad, device):
+    """[R, K] -> MFMA-fragment order for m3d_head_mlp_forward: [R/32][K/8][h=2][r=32][t=4] (rows zero-padded)."""
+    w = weight2d.detach().to(device, torch.float32)
+    r, k = w.shape
+    assert k % 8 == 0 and rows_pad % 32 == 0 and rows_pad >= r
+    if rows_pad != r:
+        w = torch.cat([w, w.new_zeros(rows_pad - r, k)], 0)
+    return w.view(rows_pad // 32, 32, k // 8, 2, 4).permute(0, 2, 3, 1, 4).contiguous().view(-1)
 
 
 class _Plan:
@@ -187,7 +197,11 @@ class Engine:
         def head(p):
             P[p + ".0"] = self._pc(p + ".0", p + ".1")
             P[p + ".3"] = self._pc(p + ".3", p + ".4")
-            P[p + ".6"] = self._pc(p + ".6")
+            P[p + ".6"] = self._pc(p + ".6", cout_pad_to=256 if p == "cls" else 64)   # fused-MLP output tile
+            for li, rows in ((".0", 256), (".3", 256), (".6", P[p + ".6"].cout_pad)):
+                wt = sd[p + li + ".weight"]
+                if wt.shape[2] == 1:                                                    # 1x1 layers only
+                    P[p + li + ".frag"] = pack_frag(wt.reshape(wt.shape[0], wt.shape[1]), rows, dev)
 
         self.box_heads = ["bbox_x", "bbox_y", "bbox_w", "bbox_h", "bbox_x3d", "bbox_y3d", "bbox_z3d", "bbox_w3d",
                           "bbox_h3d", "bbox_l3d", "bbox_rY3d"]
@@ -396,11 +410,28 @@ class Engine:
         plan.named["cls_planar"], plan.named["box_planar"] = cls_pl, box_pl
 
         def head(p, x, planar, k0=1):
-            h1 = self._buf(plan, B, fh, fw, 256)
-            self._conv(plan, p + ".0", P[p + ".0"], x, h1, 1, k0 // 2, act=1)
-            h2 = self._buf(plan, B, fh, fw, 256)
-            self._conv(plan, p + ".3", P[p + ".3"], h1, h2, 1, 0, act=1)
-            self._conv(plan, p + ".6", P[p + ".6"], h2, None, 1, 0, act=0, planar=planar)
+            """3-layer head.  1x1 heads run as ONE fused-MLP launch; the cls head runs its 3x3 conv through the
+            igemm and the remaining two 1x1 layers fused."""
+            t, img_stride, ch_off = planar
+            if k0 != 1:
+                h1 = self._buf(plan, B, fh, fw, 256)
+                self._conv(plan, p + ".0", P[p + ".0"], x, h1, 1, k0 // 2, act=1)
+                x, first = h1, None
+            else:
+                first = P[p + ".0"]
+            d = MlpDesc()
+            d.inp, d.in_cs, d.M, d.Cin = x.ptr, x.cs, B * HW, x.c
+            if first is not None:
+                d.w1, d.s1, d.t1 = P[p + ".0.frag"].data_ptr(), first.scale.data_ptr(), first.shift.data_ptr()
+            mid, last = P[p + ".3"], P[p + ".6"]
+            d.w2, d.s2, d.t2 = P[p + ".3.frag"].data_ptr(), mid.scale.data_ptr(), mid.shift.data_ptr()
+            d.w3, d.s3, d.t3 = P[p + ".6.frag"].data_ptr(), last.scale.data_ptr(), last.shift.data_ptr()
+            d.Cout, d.Cout_pad = last.cout, last.cout_pad
+            d.out, d.out_img_stride, d.HW = t.data_ptr() + 4 * ch_off * HW, img_stride, HW
+            ref = ctypes.byref(d)
+            flops = 2.0 * B * HW * ((x.c * 256 if first is not None else 0) + 256 * 256 + 256 * last.cout)
+            plan.ops.append((p + ".mlp", "head_mlp<%s,%d>" % ("3" if first is not None else "2", last.cout_pad), flops,
+                             lambda st: _hip.check(L.m3d_head_mlp_forward(ref, st)), d))
 
         head("cls", feats0, (cls_pl, NC * A * HW, 0), 3)
         sel_idx = torch.empty(B * HW, device=self.device, dtype=torch.int32)

@@ -87,7 +87,11 @@ class RPN(nn.Module):
         assert feat_h == self.feat_size[0], "x.shape is {}".format(x.shape)
         with torch.no_grad():
             cls, prob, bbox_2d, bbox_3d = self.engine().forward(x.float())
-        feat_size = torch.tensor([feat_h, feat_w], dtype=torch.float, device=x.device)
+        key = (feat_h, feat_w, x.device)
+        if getattr(self, "_feat_size_key", None) != key:       # cached: a fresh host->device copy per call would
+            self._feat_size_t = torch.tensor([feat_h, feat_w], dtype=torch.float, device=x.device)  # break graph capture
+            self._feat_size_key = key
+        feat_size = self._feat_size_t
         if self.feat_size[0] != feat_h or self.feat_size[1] != feat_w:
             self.feat_size = [feat_h, feat_w]
             self.rois = rpn_util.locate_anchors(self.anchors, self.feat_size, self.feat_stride, convert_tensor=True)

@@ -416,3 +416,84 @@ def test_dlaseg_standalone_matches_oracle():
     got = m.to(dev)(x.to(dev)).cpu()
     assert got.shape == ref.shape == (1, 128, 16, 40)
     assert _relerr(got, ref) < 1e-3
+
+
+# ------------------------------------------------------------------------------------ fused head + graph
+@pytest.mark.parametrize("cin,cout,cpad", [(128, 36, 64), (256, 144, 256), (128, 5, 64)])
+def test_fused_head_mlp_matches_torch(cin, cout, cpad):
+    """m3d_head_mlp_forward vs the unfused conv/BN/LeakyReLU chain in torch (M3d_inference_align.py:77-85)."""
+    import ctypes
+    from m3dssd_amd import _hip
+    from m3dssd_amd.host import standalone as S
+    dev = _dev()
+    g = torch.Generator().manual_seed(cin + cout)
+    n, h, w = 2, 13, 21                                  # M = 546: not a multiple of the 64-pixel tile
+    x = torch.randn(n, cin, h, w, generator=g)
+    layers = []
+    ref = x
+    chans = ([cin, 256] if cin == 128 else [256]) + [256, cout]
+    for li in range(len(chans) - 1):
+        wt = torch.randn(chans[li + 1], chans[li], 1, 1, generator=g) / chans[li] ** 0.5
+        b = torch.randn(chans[li + 1], generator=g) * 0.1
+        last = li == len(chans) - 2
+        bn = None
+        ref = F.conv2d(ref, wt, b)
+        if not last:
+            bn = torch.nn.BatchNorm2d(chans[li + 1]).eval()
+            with torch.no_grad():
+                bn.weight.uniform_(0.5, 1.5, generator=g)
+                bn.bias.normal_(0, 0.2, generator=g)
+                bn.running_mean.normal_(0, 0.2, generator=g)
+                bn.running_var.uniform_(0.5, 1.5, generator=g)
+            ref = F.leaky_relu(bn(ref), 0.01)
+        layers.append((wt, b, bn, last))
+    v, _ = S._to_nhwc(x.to(dev))
+    d = _hip.MlpDesc()
+    keep = []
+    d.inp, d.in_cs, d.M, d.Cin = v.ptr, v.cs, n * h * w, cin
+    slots = ["1", "2", "3"] if cin == 128 else ["2", "3"]
+    for slot, (wt, b, bn, last) in zip(slots, layers):
+        from m3dssd_amd.engine import pack_frag
+        co = wt.shape[0]
+        wp = pack_frag(wt.reshape(co, wt.shape[1]), cpad if last else 256, dev)
+        sc, sh = S._affine(co, b.to(dev), None if bn is None else bn.to(dev), dev)
+        keep += [wp, sc, sh]
+        setattr(d, "w" + slot, wp.data_ptr())
+        setattr(d, "s" + slot, sc.data_ptr())
+        setattr(d, "t" + slot, sh.data_ptr())
+    out = torch.zeros(n, cout, h * w, device=dev)
+    d.Cout, d.Cout_pad, d.out, d.out_img_stride, d.HW = cout, cpad, out.data_ptr(), cout * h * w, h * w
+    _hip.check(_hip.lib().m3d_head_mlp_forward(ctypes.byref(d), S._stream()))
+    got = out.view(n, cout, h, w).cpu()
+    assert _relerr(got, ref.detach()) < 2e-4
+
+
+def test_graph_replay_matches_eager():
+    """The whole step (forward + bundle + top-k + decode + NMS) captured in a hipGraph replays bit-identically."""
+    from lib.rpn_util import detect_batch
+    from model.M3d_inference_align import build
+    dev = _dev()
+    conf = synth.synth_conf((128, 320), 0, batch_size=2, device="cuda:0")
+    net = build(conf, "test")
+    net.load_state_dict(synth.synth_state_dict(0))
+    net = net.to(dev)
+    x = synth.synth_frames(2, (128, 320), 3).to(dev)
+    d0, c0 = detect_batch(net, x, conf)
+    d0, c0 = d0.clone(), c0.clone()
+    graph = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        detect_batch(net, x, conf)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=s):
+            gd, gc = detect_batch(net, x, conf)
+    torch.cuda.current_stream().wait_stream(s)
+    x2 = synth.synth_frames(2, (128, 320), 4).to(dev)
+    e1, n1 = detect_batch(net, x2, conf)
+    e1, n1 = e1.clone(), n1.clone()
+    x.copy_(x2)                       # the graph reads the captured input buffer
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(gd, e1) and torch.equal(gc, n1)
+    assert not torch.equal(e1, d0)
