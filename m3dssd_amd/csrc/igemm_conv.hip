@@ -31,6 +31,7 @@ struct IgemmArgs {
     const float *shift;
     const float *res;
     const float *om;
+    const float *zero;        // 16 bytes of zeros in device memory
     long long wgt_img_stride;
     long long out_img_stride;
     int in_cs, out_cs, res_cs, om_cs;
@@ -102,24 +103,32 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
     f32x4 ra[PA][DEFORM ? 4 : 1];
     f32x4 rb[PB];
 
+    // k-tile cursor, advanced incrementally (no integer division in the loop): tiles are loaded in order 0,1,2,...
+    int cur_tap = 0, cur_c = 0, cur_ti = 0, cur_tj = 0;
+
     auto load_tile = [&](int kt) {
         const int k0 = kt * BK;
-        const int tap = k0 / a.Cin;
-        const int c0 = k0 - tap * a.Cin + csub;
-        const int ti = tap / a.kw, tj = tap - ti * a.kw;
+        const int tap = cur_tap;
+        const int c0 = cur_c + csub;
+        const int ti = cur_ti, tj = cur_tj;
+        const bool first_of_tap = cur_c == 0;
+        cur_c += BK;
+        if (cur_c >= a.Cin) {
+            cur_c = 0;
+            ++cur_tap;
+            if (++cur_tj == a.kw) { cur_tj = 0; ++cur_ti; }
+        }
         if constexpr (!DEFORM) {
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
                 const int hi = hi0[p] + ti * a.dil, wi = wi0[p] + tj * a.dil;
                 const bool ok = rvalid[p] && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ok)
-                    v = *reinterpret_cast<const f32x4 *>(
-                        a.in + (size_t)(pix_base[p] + hi * a.W + wi) * a.in_cs + c0);
-                ra[p][0] = v;
+                // out-of-image taps read a zero page instead of branching around the load
+                const float *src = ok ? a.in + (size_t)(pix_base[p] + hi * a.W + wi) * a.in_cs + c0 : a.zero;
+                ra[p][0] = *reinterpret_cast<const f32x4 *>(src);
             }
         } else {
-            if (k0 == tap * a.Cin) {   // first k-tile of a tap: refresh the sampling state
+            if (first_of_tap) {   // first k-tile of a tap: refresh the sampling state
                 const int KK = a.kh * a.kw;
 #pragma unroll
                 for (int p = 0; p < PA; ++p) {
@@ -347,6 +356,21 @@ extern "C" int m3d_conv2d_tile(const m3d_conv_desc *d, int *bm, int *bn, int *bk
     return M3D_OK;
 }
 
+// 256 zero bytes per device: padding taps of the igemm load from here (hipMalloc'ed once, never freed).
+static const float *zero_page()
+{
+    static const float *pages[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!pages[dev]) {
+        void *p = nullptr;
+        if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+        pages[dev] = (const float *)p;
+    }
+    return pages[dev];
+}
+
 extern "C" int m3d_conv2d_forward(const m3d_conv_desc *d, m3d_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
@@ -369,7 +393,9 @@ extern "C" int m3d_conv2d_forward(const m3d_conv_desc *d, m3d_stream_t stream_)
 
     IgemmArgs a;
     a.in = d->in; a.wgt = d->wgt; a.out = d->out; a.scale = d->scale; a.shift = d->shift; a.res = d->res;
-    a.om = d->dcn_offmask; a.wgt_img_stride = d->wgt_img_stride; a.out_img_stride = d->out_img_stride;
+    a.om = d->dcn_offmask; a.zero = zero_page();
+    M3D_REQUIRE(a.zero != nullptr, "conv2d: could not allocate the zero page");
+    a.wgt_img_stride = d->wgt_img_stride; a.out_img_stride = d->out_img_stride;
     a.in_cs = d->in_cs; a.out_cs = d->out_cs; a.res_cs = d->res_cs; a.om_cs = d->dcn_om_cs;
     a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.HoWo = d->Ho * d->Wo;
     a.Cout = d->Cout; a.Cout_pad = d->Cout_pad;

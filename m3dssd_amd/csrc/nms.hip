@@ -83,16 +83,17 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(int n, const unsigned lo
         if ((keepbits >> lane) & 1ULL)
             keep[base + __popcll(keepbits & ((1ULL << lane) - 1ULL))] = blk * NMS_TPB + lane;
         base += __popcll(keepbits);
-        // propagate the kept boxes' suppression rows to the later column tiles
+        // propagate the kept boxes' suppression rows to the later column tiles: all 64 row words of this lane's
+        // column are fetched with independent loads (one memory latency per tile, not 64), then OR-ed if kept
         const int j = lane;
         if (j > blk && j < col_blocks) {
-            unsigned long long acc = 0;
             const unsigned long long *rowp = mask + (size_t)(blk * NMS_TPB) * col_blocks + j;
-#pragma unroll 16
-            for (int i = 0; i < NMS_TPB; ++i) {
-                const unsigned long long m = (i < nb) ? rowp[(size_t)i * col_blocks] : 0ULL;
-                acc |= ((keepbits >> i) & 1ULL) ? m : 0ULL;
-            }
+            unsigned long long rows[NMS_TPB];
+#pragma unroll
+            for (int i = 0; i < NMS_TPB; ++i) rows[i] = (i < nb) ? rowp[(size_t)i * col_blocks] : 0ULL;
+            unsigned long long acc = 0;
+#pragma unroll
+            for (int i = 0; i < NMS_TPB; ++i) acc |= ((keepbits >> i) & 1ULL) ? rows[i] : 0ULL;
             remv |= acc;
         }
     }

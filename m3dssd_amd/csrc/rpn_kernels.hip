@@ -151,8 +151,10 @@ extern "C" int m3d_anab_pool_partial(const float *kv, int kv_cs, const float *s,
                                      int B, int H, int W, int C, m3d_stream_t stream)
 {
     M3D_REQUIRE(kv && s && items && bin_scale && partial && n_items > 0 && n_bins > 0, "anab_pool_partial: bad arguments");
-    hipLaunchKernelGGL(anab_pool_partial_kernel, dim3(n_items, B), dim3(256), 0, (hipStream_t)stream, kv, kv_cs, s, s_cs,
-                       items, bin_scale, partial, n_bins, max_slots, H, W, C);
+    // one thread per channel where possible (C = 296 on the M3DSSD path -> 320 threads, a single pass)
+    const int threads = C <= 1024 ? ((C + 63) / 64) * 64 : 256;
+    hipLaunchKernelGGL(anab_pool_partial_kernel, dim3(n_items, B), dim3(threads), 0, (hipStream_t)stream, kv, kv_cs, s,
+                       s_cs, items, bin_scale, partial, n_bins, max_slots, H, W, C);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
 }

@@ -555,10 +555,11 @@ class Engine:
         return out
 
     @staticmethod
-    def _anab_items(H, W, max_rows=None):
+    def _anab_items(H, W):
         """Work items of the pyramid pooling: AdaptiveAvgPool2d windows (start = floor(i*H/s),
-        end = ceil((i+1)*H/s)) split into row chunks of ceil(H/16) rows."""
-        chunk = max(1, math.ceil(H / 16))
+        end = ceil((i+1)*H/s)) split into chunks of ceil(H/16) rows x ceil(W/4) columns, so that the
+        whole-map "size 1" bin is spread over 64 workgroups instead of serialising on one."""
+        rchunk, cchunk = max(1, math.ceil(H / 16)), max(1, math.ceil(W / 4))
         items, bin_scale, bin_slots, bin_inv = [], [], [], []
         b = 0
         for si, s in enumerate(PSP_SIZES):
@@ -567,9 +568,10 @@ class Engine:
                 for j in range(s):
                     w0, w1 = (j * W) // s, -((-(j + 1) * W) // s)
                     slot = 0
-                    for r0 in range(h0, h1, chunk):
-                        items.append((b, r0, min(r0 + chunk, h1), w0, w1, slot))
-                        slot += 1
+                    for r0 in range(h0, h1, rchunk):
+                        for c0 in range(w0, w1, cchunk):
+                            items.append((b, r0, min(r0 + rchunk, h1), c0, min(c0 + cchunk, w1), slot))
+                            slot += 1
                     bin_scale.append(si)
                     bin_slots.append(slot)
                     bin_inv.append(1.0 / ((h1 - h0) * (w1 - w0)))
