@@ -45,7 +45,7 @@ struct IgemmArgs {
 };
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool DEFORM, bool SWAP>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
 {
     constexpr int TM = BM / (32 * WAVES_M);
     constexpr int TN = BN / (32 * WAVES_N);
@@ -98,13 +98,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
     }
     // deformable: bilinear state of the current tap
     float bw[DEFORM ? PA : 1][4], bmask[DEFORM ? PA : 1];
-    int boff[DEFORM ? PA : 1][4];
+    int doff[DEFORM ? PA : 1][4];
 
     f32x4 ra[PA][DEFORM ? 4 : 1];
     f32x4 rb[PB];
 
     // k-tile cursor, advanced incrementally (no integer division in the loop): tiles are loaded in order 0,1,2,...
     int cur_tap = 0, cur_c = 0, cur_ti = 0, cur_tj = 0;
+    unsigned aoff[PA];
+    bool aok[PA];
+    unsigned boff[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p)   // rows past Cout_pad are clamped (their products land in never-stored channels)
+        boff[p] = ((unsigned)min(n0 + p * RPP + rsub, a.Cout_pad - 1) * (unsigned)a.Ktot + (unsigned)csub) * 4u;
 
     auto load_tile = [&](int kt) {
         const int k0 = kt * BK;
@@ -119,14 +125,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
             if (++cur_tj == a.kw) { cur_tj = 0; ++cur_ti; }
         }
         if constexpr (!DEFORM) {
+            // addresses = uniform base (SGPR pair, advanced by BK floats per k-tile) + a 32-bit per-thread byte offset
+            // that only changes when the tap changes -> no per-load 64-bit VALU address math; padding taps read a
+            // clamped in-image address and are zeroed when the tile is written to LDS
+            if (first_of_tap) {
 #pragma unroll
-            for (int p = 0; p < PA; ++p) {
-                const int hi = hi0[p] + ti * a.dil, wi = wi0[p] + tj * a.dil;
-                const bool ok = rvalid[p] && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-                // out-of-image taps read a zero page instead of branching around the load
-                const float *src = ok ? a.in + (size_t)(pix_base[p] + hi * a.W + wi) * a.in_cs + c0 : a.zero;
-                ra[p][0] = *reinterpret_cast<const f32x4 *>(src);
+                for (int p = 0; p < PA; ++p) {
+                    const int hi = hi0[p] + ti * a.dil, wi = wi0[p] + tj * a.dil;
+                    aok[p] = rvalid[p] && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+                    const int hc = min(max(hi, 0), a.H - 1), wc = min(max(wi, 0), a.W - 1);
+                    aoff[p] = ((unsigned)(pix_base[p] + hc * a.W + wc) * (unsigned)a.in_cs + (unsigned)csub) * 4u;
+                }
             }
+            const char *abase = reinterpret_cast<const char *>(a.in + (c0 - csub));
+#pragma unroll
+            for (int p = 0; p < PA; ++p) ra[p][0] = *reinterpret_cast<const f32x4 *>(abase + aoff[p]);
         } else {
             if (first_of_tap) {   // first k-tile of a tap: refresh the sampling state
                 const int KK = a.kh * a.kw;
@@ -152,7 +165,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
                         }
                     }
                     bw[p][0] = w1; bw[p][1] = w2; bw[p][2] = w3; bw[p][3] = w4;
-                    boff[p][0] = o1; boff[p][1] = o2; boff[p][2] = o3; boff[p][3] = o4;
+                    doff[p][0] = o1; doff[p][1] = o2; doff[p][2] = o3; doff[p][3] = o4;
                     bmask[p] = mk;
                 }
             }
@@ -161,17 +174,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     ra[p][q] = *reinterpret_cast<const f32x4 *>(
-                        a.in + (size_t)(pix_base[p] + boff[p][q]) * a.in_cs + c0);
+                        a.in + (size_t)(pix_base[p] + doff[p][q]) * a.in_cs + c0);
             }
         }
+        const char *bbase = reinterpret_cast<const char *>(wgt + k0);
 #pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            const int r = p * RPP + rsub;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < BN && n0 + r < a.Cout_pad)
-                v = *reinterpret_cast<const f32x4 *>(wgt + (size_t)(n0 + r) * a.Ktot + k0 + csub);
-            rb[p] = v;
-        }
+        for (int p = 0; p < PB; ++p) rb[p] = *reinterpret_cast<const f32x4 *>(bbase + boff[p]);
     };
 
     auto store_tile = [&](int buf) {
@@ -182,6 +190,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
             f32x4 v;
             if constexpr (!DEFORM) {
                 v = ra[p][0];
+                if (!aok[p]) v = f32x4{0.f, 0.f, 0.f, 0.f};
             } else {
                 // (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask   -- dcn_v2_im2col_cuda.cu:44-46,174
                 v = bw[p][0] * ra[p][0] + bw[p][1] * ra[p][1] + bw[p][2] * ra[p][2] + bw[p][3] * ra[p][3];
@@ -214,25 +223,40 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
         if (kt + 1 < a.KT && !(a.ablate & 1)) load_tile(kt + 1);
         const float *Ab = As + buf * BM * LDK + (wm + l31) * LDK + lh4;
         const float *Bb = Bs + buf * BN * LDK + (wn + l31) * LDK + lh4;
-        if (!(a.ablate & 2))
+        if (!(a.ablate & 2)) {
+            // fragment reads are software-pipelined one k-group ahead of the MFMAs that consume them, so the LDS
+            // latency hides behind 16*TM*TN/4 MFMAs instead of stalling the (in-order) wave twice per k-tile
+            f32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-            f32x4 fa[TM], fb[TN];
+            for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * LDK);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * LDK + g * 8);
+            for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * LDK);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * LDK + g * 8);
+            for (int g = 0; g < BK / 8; ++g) {
+                const int cur = g & 1, nxt = cur ^ 1;
+                if (g + 1 < BK / 8) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                    for (int i = 0; i < TM; ++i)
+                        fa[nxt][i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * LDK + (g + 1) * 8);
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int j = 0; j < TN; ++j)
+                        fb[nxt][j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * LDK + (g + 1) * 8);
+                }
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        if constexpr (SWAP)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][t], fa[i][t], acc[i][j], 0, 0, 0);
-                        else
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
-                    }
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            if constexpr (SWAP)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[cur][j][t], fa[cur][i][t], acc[i][j], 0, 0, 0);
+                            else
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][t], fb[cur][j][t], acc[i][j], 0, 0, 0);
+                        }
+                // pin the issue order: the reads of group g+1 first, then the MFMAs of group g that cover their latency
+                if (g + 1 < BK / 8) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+            }
         }
         if (kt + 1 < a.KT && !(a.ablate & 4)) store_tile(buf ^ 1);
         if (!(a.ablate & 4)) __syncthreads();
@@ -384,7 +408,8 @@ extern "C" int m3d_conv2d_forward(const m3d_conv_desc *d, m3d_stream_t stream_)
     M3D_REQUIRE(ho == d->Ho && wo == d->Wo, "conv2d: Ho/Wo mismatch (%d,%d) vs (%d,%d)", d->Ho, d->Wo, ho, wo);
     const long long M = (long long)d->N * d->Ho * d->Wo;
     M3D_REQUIRE(M > 0 && M < (1ll << 31) / 4, "conv2d: M out of range");
-    M3D_REQUIRE((long long)d->N * d->H * d->W * d->in_cs < (1ll << 40), "conv2d: input too large");
+    M3D_REQUIRE((long long)d->N * d->H * d->W * d->in_cs * 4 < (1ll << 32), "conv2d: input view must be < 4 GiB (32-bit offsets)");
+    M3D_REQUIRE((long long)d->Cout_pad * d->kh * d->kw * d->Cin * 4 < (1ll << 32), "conv2d: weights must be < 4 GiB");
     if (d->dcn_offmask) M3D_REQUIRE(!d->out_nchw && d->Cout_pad % 64 == 0, "deformable conv: NHWC out, Cout_pad %% 64");
     if (d->out_nchw) M3D_REQUIRE(!d->res, "planar output does not take a residual");
 
