@@ -60,6 +60,25 @@ def cpu_baseline(sd, conf_cpu, budget_s=15.0):
                       % (n, dt, threads)}
 
 
+def pmc_traffic(kernel_label):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_hbm_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 wide-read correction applied); None if the
+    kernel was not profiled.  PMC counters cannot be collected inside the timed run itself."""
+    import glob
+    import re
+    nums = re.findall(r"\d+", kernel_label)[:3]
+    flags = ("true" if "deform" in kernel_label else "false", "true" if "planar" in kernel_label else "false")
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), reverse=True):
+        try:
+            ks = json.load(open(f))["kernels"]
+        except Exception:
+            continue
+        for name, v in ks.items():
+            if name.startswith("void igemm_kernel<%s, %s, %s," % tuple(nums)) and name.endswith("%s, %s>(IgemmArgs)" % flags):
+                return v["hbm_bytes_per_launch"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,6 +193,17 @@ def main():
     dom_n = len(eng.profile)
     eng.profile, eng.profile_kinds = None, None
 
+    # algorithmic HBM bytes of the dominant kernel's launches: input + output (+ residual) + weights, once each
+    plan = eng.plan_for(B, CROP[0], CROP[1])
+    ab, an = 0.0, 0
+    for op in plan.ops:
+        if op[1] == dominant and op[4] is not None:
+            d = op[4]
+            o = d.N * d.Ho * d.Wo * d.Cout * 4
+            ab += d.N * d.H * d.W * d.Cin * 4 + o + (o if d.res else 0) + d.Cout * d.kh * d.kw * d.Cin * 4
+            an += 1
+    alg_bytes = int(ab / an) if an else None
+
     if rank == 0:
         value = world * B * args.steps / dt
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
@@ -190,7 +220,8 @@ def main():
             "launch": "hipGraph replay" if use_graph else "eager",
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel" + dominant[5:], "achieved": round(achieved, 2),
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "traffic": None, "launches_timed": dom_n,
+                         "traffic": pmc_traffic(dominant), "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
+                         "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": dom_n,
                          "avg_launch_ms": round(dom_ms / max(dom_n, 1), 4),
                          "avg_launch_gflop": round(dom_flops / max(dom_n, 1) / 1e9, 3),
                          "share_of_gpu_time": round(igemm[dominant][0] / gpu_ms_all, 3)},

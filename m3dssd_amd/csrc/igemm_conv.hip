@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
     }
     // deformable: bilinear state of the current tap
     float bw[DEFORM ? PA : 1][4], bmask[DEFORM ? PA : 1];
-    int doff[DEFORM ? PA : 1][4];
+    unsigned doff[DEFORM ? PA : 1][4];   // byte offsets of the 4 corners (pixel + channel sub-offset)
 
     f32x4 ra[PA][DEFORM ? 4 : 1];
     f32x4 rb[PB];
@@ -165,16 +165,18 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
                         }
                     }
                     bw[p][0] = w1; bw[p][1] = w2; bw[p][2] = w3; bw[p][3] = w4;
-                    doff[p][0] = o1; doff[p][1] = o2; doff[p][2] = o3; doff[p][3] = o4;
+                    doff[p][0] = ((unsigned)(pix_base[p] + o1) * (unsigned)a.in_cs + (unsigned)csub) * 4u;
+                    doff[p][1] = ((unsigned)(pix_base[p] + o2) * (unsigned)a.in_cs + (unsigned)csub) * 4u;
+                    doff[p][2] = ((unsigned)(pix_base[p] + o3) * (unsigned)a.in_cs + (unsigned)csub) * 4u;
+                    doff[p][3] = ((unsigned)(pix_base[p] + o4) * (unsigned)a.in_cs + (unsigned)csub) * 4u;
                     bmask[p] = mk;
                 }
             }
+            const char *dbase = reinterpret_cast<const char *>(a.in + (c0 - csub));
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    ra[p][q] = *reinterpret_cast<const f32x4 *>(
-                        a.in + (size_t)(pix_base[p] + doff[p][q]) * a.in_cs + c0);
+                for (int q = 0; q < 4; ++q) ra[p][q] = *reinterpret_cast<const f32x4 *>(dbase + doff[p][q]);
             }
         }
         const char *bbase = reinterpret_cast<const char *>(wgt + k0);
@@ -354,7 +356,7 @@ static int choose_tile(const m3d_conv_desc *d, TileChoice *t)
     t->bm = 128;
     if (t->bn >= 64) {
         static int thr = -1;                     // tuning knob (experiments only): M3D_BM_THRESHOLD
-        if (thr < 0) { const char *e = getenv("M3D_BM_THRESHOLD"); thr = e ? atoi(e) : 2 * 256; }
+        if (thr < 0) { const char *e = getenv("M3D_BM_THRESHOLD"); thr = e ? atoi(e) : 400; }
         const long long blocks128 = ((M + 127) / 128) * ((d->Cout_pad + t->bn - 1) / t->bn);
         if (blocks128 < thr) t->bm = 64;         // under two blocks per CU: smaller tiles fill the chip
     }
