@@ -21,6 +21,7 @@
  *                                 chains of model/pose_dla_dcn.py:107-121,261-269,379-389 and the RPN
  *                                 heads model/M3d_inference_align.py:66-210, plus (deformable mode)
  *                                 the fused im2col+GEMM of dcn_v2_cuda.c:80-96 without `columns`
+ *   m3d_wino_conv3x3_forward ... the same Conv2d 3x3 stride-1 layers through Winograd F(2x2,3x3)
  *   m3d_head_mlp_forward ....... the 3-layer 1x1 heads, model/M3d_inference_align.py:77-210 (one launch per head)
  *   m3d_stem_conv7x7 ........... DLA.base_layer, model/pose_dla_dcn.py:336-340
  *   m3d_maxpool2x2 ............. Tree.downsample nn.MaxPool2d(2,2), pose_dla_dcn.py:306,316
@@ -93,6 +94,11 @@ typedef struct m3d_conv_desc {
 } m3d_conv_desc;
 
 int m3d_conv2d_forward(const m3d_conv_desc *d, m3d_stream_t stream);
+
+/* Winograd F(2x2,3x3) variant for 3x3 / stride 1 / pad 1 / even H,W plain convolutions (same descriptor; `wgt`
+ * must point to the Winograd-transformed weights U = G g G^T packed in fragment order
+ * [16 xi][Cout_pad/32][Cin/8][64][4], see m3dssd_amd/engine.py:pack_wino).  2.25x fewer MFMA FLOPs, fp32. */
+int m3d_wino_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t stream);
 
 /* Average launch geometry chosen for a descriptor (for roofline bookkeeping / tests). */
 int m3d_conv2d_tile(const m3d_conv_desc *d, int *bm, int *bn, int *bk, int *grid);

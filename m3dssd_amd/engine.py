@@ -15,6 +15,7 @@ model/module/attention.py:183-216.
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -78,6 +79,9 @@ class PackedConv:
             scale = s
         self.scale, self.shift = scale.contiguous(), shift.contiguous()
         self.has_affine = (bias is not None) or (bn is not None)
+        self.wino = None
+        if USE_WINO and self.kh == 3 and self.kw == 3 and self.cin_pad == self.cin and self.cin % 16 == 0:
+            self.wino = pack_wino(w, self.cout_pad, eng.device)
 
 
 def pack_frag(weight2d, rows_pad, device):
@@ -88,6 +92,25 @@ def pack_frag(weight2d, rows_pad, device):
     if rows_pad != r:
         w = torch.cat([w, w.new_zeros(rows_pad - r, k)], 0)
     return w.view(rows_pad // 32, 32, k // 8, 2, 4).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+
+
+_WINO_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+
+
+def pack_wino(weight, cout_pad, device):
+    """[Cout, Cin, 3, 3] -> Winograd F(2x2,3x3) weights U = G g G^T (computed in fp64, rounded once to fp32) in
+    MFMA-fragment order [16 xi][Cout_pad/32][Cin/8][h=2][r=32][t=4] for m3d_wino_conv3x3_forward."""
+    g = weight.detach().to("cpu", torch.float64)
+    co, ci = g.shape[0], g.shape[1]
+    assert g.shape[2:] == (3, 3) and ci % 8 == 0 and cout_pad % 32 == 0 and cout_pad >= co
+    u = torch.einsum("ai,ocij,bj->aboc", _WINO_G, g, _WINO_G).reshape(16, co, ci)
+    if cout_pad != co:
+        u = torch.cat([u, u.new_zeros(16, cout_pad - co, ci)], 1)
+    u = u.view(16, cout_pad // 32, 32, ci // 8, 2, 4).permute(0, 1, 3, 4, 2, 5).contiguous()
+    return u.to(torch.float32).reshape(-1).to(device)
+
+
+USE_WINO = os.environ.get("M3D_WINO", "1") != "0"
 
 
 class _Plan:
@@ -276,6 +299,13 @@ class Engine:
             d.dcn_offmask, d.dcn_om_cs = om.ptr, om.cs
         L = self.L
         ref = ctypes.byref(d)
+        if (pc is not None and wgt_ptr is None and getattr(pc, "wino", None) is not None and kh == 3 and kw == 3
+                and stride == 1 and pad == 1 and om is None and planar is None and x.h % 2 == 0 and x.w % 2 == 0):
+            # Winograd F(2x2,3x3): 2.25x fewer MFMA FLOPs for the plain 3x3 stride-1 layers
+            d.wgt = pc.wino.data_ptr()
+            flops = 2.0 * x.n * d.Ho * d.Wo * d.Cout * 9 * pc.cin
+            plan.ops.append((name, "wino<32,32,16>", flops, lambda st: _hip.check(L.m3d_wino_conv3x3_forward(ref, st)), d))
+            return
         bm, bn, bk, grid = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         _hip.check(L.m3d_conv2d_tile(ref, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(bk), ctypes.byref(grid)))
         kind = "igemm<%d,%d,%d%s%s>" % (bm.value, bn.value, bk.value, ",deform" if om is not None else "",

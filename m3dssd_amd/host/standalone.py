@@ -47,9 +47,14 @@ def _affine(co, bias, bn, dev):
 
 
 def conv_nhwc(v, weight, bias=None, bn=None, stride=1, pad=0, act=0, res=None, res_mode=0, sigmoid_from=-1, om=None,
-              cout_pad_to=32, out_cs_to=4):
-    """One m3d_conv2d_forward launch on an NHWC view; returns (View, keepalive)."""
+              cout_pad_to=32, out_cs_to=4, wino=False):
+    """One m3d_conv2d_forward (or, with wino=True, m3d_wino_conv3x3_forward) launch on an NHWC view;
+    returns (View, keepalive)."""
     wp, co, cop, kh, kw = _pack(weight, v.c, cout_pad_to)
+    if wino:
+        from ..engine import pack_wino
+        assert weight.shape[1] == v.c, "wino path: no channel padding"
+        wp = pack_wino(weight, cop, v.t.device)
     scale, shift = _affine(co, bias, bn, v.t.device)
     ho = (v.h + 2 * pad - kh) // stride + 1
     wo = (v.w + 2 * pad - kw) // stride + 1
@@ -67,7 +72,8 @@ def conv_nhwc(v, weight, bias=None, bn=None, stride=1, pad=0, act=0, res=None, r
     d.act, d.sigmoid_from = act, sigmoid_from
     if om is not None:
         d.dcn_offmask, d.dcn_om_cs = om.ptr, om.cs
-    _hip.check(_hip.lib().m3d_conv2d_forward(ctypes.byref(d), _stream()))
+    fn = _hip.lib().m3d_wino_conv3x3_forward if wino else _hip.lib().m3d_conv2d_forward
+    _hip.check(fn(ctypes.byref(d), _stream()))
     return out, (wp, scale, shift)
 
 
