@@ -34,12 +34,12 @@ struct WinoArgs {
 
 #define WINO_T 32            // tiles per workgroup
 #define WINO_BK 16           // input channels per k-step
-#define WINO_LDV (WINO_BK + 4)
+#define WINO_VBUF (16 * WINO_T * WINO_BK)   // floats per V buffer: V[xi][tile][16], unpadded, XOR-swizzled quads
 #define WINO_LDM 33
 
 __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // V[16][32][20]  then  M[16][32][33]
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // V[2][16][32][16]  then  M[16][32][33]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh4 = (lane >> 5) * 4, hrow = 4 * (lane >> 5);
 
@@ -82,7 +82,10 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs a)
 #pragma unroll
         for (int i = 0; i < 12; ++i) d[i] = *reinterpret_cast<const f32x4 *>(base + poff[i]);
     };
-    auto transform_store = [&]() {
+    // V element (xi, tile, quad q) lives at ((xi*32 + tile)*16 + 4*(q ^ ((tile >> 2) & 3))): 64-byte rows without
+    // padding; the XOR spreads the 16 tiles of a ds_read_b128 lane group over all 64 banks (conflict-free)
+    const int wq = (((item & 3) ^ ((ltile >> 2) & 3))) * 4;
+    auto transform_store = [&](int buf) {
         if (pmask != 0xFFFu) {
 #pragma unroll
             for (int i = 0; i < 12; ++i)
@@ -99,17 +102,17 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs a)
             }
             const f32x4 v0 = t[0] - t[2], v1 = t[1] + t[2], v2 = t[2] - t[1], v3 = t[1] - t[3];
             const int r = half * 2 + rr;
-            float *vb = smem + ((r * 4) * WINO_T + ltile) * WINO_LDV + lquad;
+            float *vb = smem + buf * WINO_VBUF + ((r * 4) * WINO_T + ltile) * WINO_BK + wq;
             *reinterpret_cast<f32x4 *>(vb) = v0;
-            *reinterpret_cast<f32x4 *>(vb + 1 * WINO_T * WINO_LDV) = v1;
-            *reinterpret_cast<f32x4 *>(vb + 2 * WINO_T * WINO_LDV) = v2;
-            *reinterpret_cast<f32x4 *>(vb + 3 * WINO_T * WINO_LDV) = v3;
+            *reinterpret_cast<f32x4 *>(vb + 1 * WINO_T * WINO_BK) = v1;
+            *reinterpret_cast<f32x4 *>(vb + 2 * WINO_T * WINO_BK) = v2;
+            *reinterpret_cast<f32x4 *>(vb + 3 * WINO_T * WINO_BK) = v3;
         }
     };
 
     // ---- U fragments of this wave's 4 xi: [xi][g] -----------------------------------------------------------
     const int kgroups = a.Cin / 8;
-    f32x4 fb[4][2];
+    f32x4 fb[4][2], fbn[4][2];
     auto load_u = [&](int ks, f32x4 (&dst)[4][2]) {
 #pragma unroll
         for (int x = 0; x < 4; ++x)
@@ -125,28 +128,40 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
 
+    // software pipeline, ONE barrier per k-step: while the MFMAs of step ks run, the patch of step ks+1 (already in
+    // registers) is transformed into the other V buffer, the patch of ks+2 and the U fragments of ks+1 are in flight
     load_patch(0);
+    load_u(0, fb);
+    transform_store(0);
+    if (KS > 1) load_patch(1);
+    __syncthreads();
+    const int rq0 = (((lane >> 5)) ^ ((l31 >> 2) & 3)) * 4;          // swizzled quad of k-group 0 (q = h)
+    const int rq1 = ((2 + (lane >> 5)) ^ ((l31 >> 2) & 3)) * 4;      // k-group 1 (q = 2 + h)
     for (int ks = 0; ks < KS; ++ks) {
-        load_u(ks, fb);                        // latency hides behind the transform + the two barriers
-        __syncthreads();                       // every wave finished reading V of the previous k-step
-        transform_store();
-        __syncthreads();                       // V[.] of this k-step visible
-        if (ks + 1 < KS) load_patch(ks + 1);
+        const int buf = ks & 1;
+        if (ks + 1 < KS) load_u(ks + 1, fbn);
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-            const float *vb = smem + ((wave * 4 + x) * WINO_T + l31) * WINO_LDV + lh4;
+            const float *vb = smem + buf * WINO_VBUF + ((wave * 4 + x) * WINO_T + l31) * WINO_BK;
+            const f32x4 fa0 = *reinterpret_cast<const f32x4 *>(vb + rq0);
+            const f32x4 fa1 = *reinterpret_cast<const f32x4 *>(vb + rq1);
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const f32x4 fa = *reinterpret_cast<const f32x4 *>(vb + g * 8);
+            for (int s = 0; s < 4; ++s) acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[s], fb[x][0][s], acc[x], 0, 0, 0);
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[x][g][s], acc[x], 0, 0, 0);
-            }
+            for (int s = 0; s < 4; ++s) acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[s], fb[x][1][s], acc[x], 0, 0, 0);
         }
+        if (ks + 1 < KS) {
+            transform_store(buf ^ 1);          // independent of the MFMAs above: the scheduler interleaves them
+            if (ks + 2 < KS) load_patch(ks + 2);
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) fb[x][g] = fbn[x][g];
+        }
+        __syncthreads();
     }
 
-    // ---- gather the 16 M[xi] in LDS: M[xi][tile][cout] ------------------------------------------------------
-    __syncthreads();
+    // ---- gather the 16 M[xi] in LDS: M[xi][tile][cout] (the loop ended with a barrier) ------------------------
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
         float *mb = smem + (size_t)(wave * 4 + x) * WINO_T * WINO_LDM + l31;
@@ -217,7 +232,7 @@ extern "C" int m3d_wino_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t str
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cout_pad = d->Cout_pad;
     a.TH = d->H / 2; a.TW = d->W / 2; a.NT = d->N * a.TH * a.TW; a.tiles_n = d->Cout_pad / 32;
     a.act = d->act; a.sigmoid_from = d->sigmoid_from; a.res_mode = d->res_mode;
-    constexpr size_t smem = (size_t)16 * WINO_T * WINO_LDM * sizeof(float);   // 67,584 B (>= V: 40,960 B)
+    constexpr size_t smem = (size_t)16 * WINO_T * WINO_LDM * sizeof(float);   // 67,584 B (>= 2 V buffers: 65,536 B)
     static bool attr_set = false;
     if (!attr_set) {
         M3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -80,7 +80,7 @@ class PackedConv:
         self.scale, self.shift = scale.contiguous(), shift.contiguous()
         self.has_affine = (bias is not None) or (bn is not None)
         self.wino = None
-        if USE_WINO and self.kh == 3 and self.kw == 3 and self.cin_pad == self.cin and self.cin % 16 == 0:
+        if USE_WINO and self.kh == 3 and self.kw == 3 and self.cin_pad == self.cin and self.cin % 16 == 0 and self.cin >= 32:
             self.wino = pack_wino(w, self.cout_pad, eng.device)
 
 
