@@ -7,15 +7,17 @@
 // model/pose_dla_dcn.py:96-103 and the cls head).  The 16 transform positions xi = (a, b) are 16 independent GEMMs
 // M[xi] (tiles x Cout) = V[xi] (tiles x Cin) . U[xi] (Cin x Cout).
 //
-// One workgroup = 32 output tiles (128 output pixels) x 32 output channels, 4 waves, each wave owns 4 of the 16 xi:
-//   * every thread loads 3 rows x 4 columns of a 4x4 input patch for one (tile, channel quad) (12 x 16-byte loads;
-//     offsets constant over the whole K loop, SGPR channel base advances), applies its half of B^T d B in registers
-//     and writes 8 of the 16 V[xi][tile][quad] to LDS;
+// One workgroup = 64 output tiles (256 output pixels) x 32 output channels, 8 waves, wave-specialised:
+//   * waves 4-7: one (tile, channel quad) per thread: 16 x 16-byte loads of the 4x4 input patch (offsets constant over
+//     the whole K loop, SGPR channel base advances), B^T d B in registers, V[xi][tile][quad] to the idle LDS buffer;
+//   * waves 0-3: each owns 4 of the 16 xi for all 64 tiles x 32 couts (8 accumulators);
 //   * U = G g G^T is transformed offline (fp64 -> fp32) and packed in MFMA-fragment order, so every wave reads the B
 //     fragments of ITS xi straight global->register (coalesced 1 KB loads, no LDS, no reuse lost);
 //   * v_mfma_f32_32x32x2_f32 with the k-permuted fragment order (lane half h, step t -> k = 8g + 4h + t);
 //   * the 16 accumulated M[xi] meet in LDS, A^T M A + affine/residual/LeakyReLU/sigmoid are applied per (tile, cout)
 //     and written NHWC with lanes along channels.
+#include <stdlib.h>
+
 #include "common.h"
 
 struct WinoArgs {
@@ -30,18 +32,49 @@ struct WinoArgs {
     int TH, TW, NT;          // tiles per image (rows, cols), total tiles
     int tiles_n;             // Cout_pad / 32
     int act, sigmoid_from, res_mode;
+    int ablate;   // diagnostics (M3D_ABLATE): 1 = loader skips steady-state loads, 2 = no MFMA, 4 = loader skips transform+store, 8 = no U loads
 };
 
-#define WINO_T 32            // tiles per workgroup
+#define WINO_T 64            // tiles per workgroup (two 32-row MFMA tiles per compute wave)
 #define WINO_BK 16           // input channels per k-step
 #define WINO_VBUF (16 * WINO_T * WINO_BK)   // floats per V buffer: V[xi][tile][16], unpadded, XOR-swizzled quads
 #define WINO_LDM 33
 
-__global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs a)
+// LDS read whose completion is tracked BY HAND (hipcc does not count asm memory ops, cdna_hip_programming.md 5.7):
+// lets the V fragments of the next MFMA group be in flight while the current group's MFMAs issue; the consumer
+// runs `lds_wait()` first.  addr = LDS byte address.
+__device__ __forceinline__ f32x4 lds_read_b128_async(unsigned addr)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // V[2][16][32][16]  then  M[16][32][33]
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+__device__ __forceinline__ void lds_wait()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);      // MFMAs must not be hoisted above the wait (rule 18)
+}
+
+// Workgroup barrier that only waits for this wave's LDS traffic.  __syncthreads() would also emit s_waitcnt vmcnt(0)
+// and drain the global prefetch loads issued just before it, serialising HBM/L2 latency into every k-step.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// 512 threads, wave-specialised: waves 0-3 compute (each owns 4 of the 16 xi, 64 tiles x 32 couts = 8 accumulators,
+// U fragments straight from global and reused for both tile groups), waves 4-7 load the 4x4 input patches (one
+// (tile, channel quad) per thread, 16 x 16-byte loads with constant offsets), apply B^T d B and fill the other V buffer.
+// One barrier per k-step; per MFMA the CU moves ~3.4x fewer bytes through its vector-memory path than a
+// 32-tile x 32-cout block where every wave both loads and computes.
+__global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // V[2][16][64][16]  then  M[16][64][33]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lh4 = (lane >> 5) * 4, hrow = 4 * (lane >> 5);
+    const int l31 = lane & 31, hrow = 4 * (lane >> 5);
+    const bool is_loader = wave >= 4;
 
     int tile_blk;
     {
@@ -53,124 +86,166 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs a)
     const int t0 = bm * WINO_T, n0 = bn * 32;
     const int KS = a.Cin / WINO_BK;
 
-    // ---- loader state: thread = (tile, channel quad, half).  half 0 produces V rows 0,1 from input rows 0..2,
-    //      half 1 produces V rows 2,3 from input rows 1..3 (B^T d needs rows {0,2},{1,2} / {2,1},{1,3}) ---------
-    const int half = tid & 1, item = tid >> 1;
-    const int ltile = item >> 2, lquad = (item & 3) * 4;
-    unsigned poff[12];
-    unsigned pmask = 0;          // bit e*4+c set = position inside the image (e = 0..2 -> input row half+e)
-    {
-        const int t = t0 + ltile;
-        const bool tv = t < a.NT;
-        const int tt = tv ? t : 0;
-        const int n = tt / (a.TH * a.TW), rem = tt - n * a.TH * a.TW;
-        const int ty = rem / a.TW, tx = rem - ty * a.TW;
-#pragma unroll
-        for (int e = 0; e < 3; ++e)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int hi = 2 * ty - 1 + half + e, wi = 2 * tx - 1 + c;
-                const bool ok = tv && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-                const int hc = min(max(hi, 0), a.H - 1), wc = min(max(wi, 0), a.W - 1);
-                poff[e * 4 + c] = ((unsigned)((n * a.H + hc) * a.W + wc) * (unsigned)a.in_cs + (unsigned)lquad) * 4u;
-                if (ok) pmask |= 1u << (e * 4 + c);
-            }
-    }
-    f32x4 d[12];
-    auto load_patch = [&](int ks) {
-        const char *base = reinterpret_cast<const char *>(a.in + ks * WINO_BK);
-#pragma unroll
-        for (int i = 0; i < 12; ++i) d[i] = *reinterpret_cast<const f32x4 *>(base + poff[i]);
-    };
-    // V element (xi, tile, quad q) lives at ((xi*32 + tile)*16 + 4*(q ^ ((tile >> 2) & 3))): 64-byte rows without
+    // V element (xi, tile, quad q) lives at ((xi*64 + tile)*16 + 4*(q ^ ((tile >> 2) & 3))): 64-byte rows without
     // padding; the XOR spreads the 16 tiles of a ds_read_b128 lane group over all 64 banks (conflict-free)
-    const int wq = (((item & 3) ^ ((ltile >> 2) & 3))) * 4;
-    auto transform_store = [&](int buf) {
-        if (pmask != 0xFFFu) {
+    if (is_loader) {
+        // ================================ loader / input-transform waves ======================================
+        const int lt = tid - 256;
+        const int ltile = lt >> 2, lq = lt & 3;
+        const int wq = (lq ^ ((ltile >> 2) & 3)) * 4;
+        unsigned poff[16];
+        unsigned pmask = 0;          // bit r*4+c set = position inside the image
+        {
+            const int t = t0 + ltile;
+            const bool tv = t < a.NT;
+            const int tt = tv ? t : 0;
+            const int n = tt / (a.TH * a.TW), rem = tt - n * a.TH * a.TW;
+            const int ty = rem / a.TW, tx = rem - ty * a.TW;
 #pragma unroll
-            for (int i = 0; i < 12; ++i)
-                if (!((pmask >> i) & 1u)) d[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int hi = 2 * ty - 1 + r, wi = 2 * tx - 1 + c;
+                    const bool ok = tv && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+                    const int hc = min(max(hi, 0), a.H - 1), wc = min(max(wi, 0), a.W - 1);
+                    poff[r * 4 + c] = ((unsigned)((n * a.H + hc) * a.W + wc) * (unsigned)a.in_cs + (unsigned)(lq * 4)) * 4u;
+                    if (ok) pmask |= 1u << (r * 4 + c);
+                }
         }
-        // B^T d for this thread's two V rows (per column c), then (.) B along the columns
+        // two patches in flight (these waves hold no accumulators, registers are plentiful): the loads of step ks+2
+        // and ks+3 are outstanding while step ks computes, so HBM/L2 latency never reaches the barrier
+        f32x4 dA[16], dB[16];
+        auto load_patch = [&](int ks, f32x4 (&d)[16]) {
+            const char *base = reinterpret_cast<const char *>(a.in + ks * WINO_BK);
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            f32x4 t[4];
+            for (int i = 0; i < 16; ++i) d[i] = *reinterpret_cast<const f32x4 *>(base + poff[i]);
+        };
+        auto transform_store = [&](int buf, f32x4 (&d)[16]) {
+            if (pmask != 0xFFFFu) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (half == 0) t[c] = (rr == 0) ? d[0 * 4 + c] - d[2 * 4 + c] : d[1 * 4 + c] + d[2 * 4 + c];
-                else           t[c] = (rr == 0) ? d[1 * 4 + c] - d[0 * 4 + c] : d[0 * 4 + c] - d[2 * 4 + c];
+                for (int i = 0; i < 16; ++i)
+                    if (!((pmask >> i) & 1u)) d[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            const f32x4 v0 = t[0] - t[2], v1 = t[1] + t[2], v2 = t[2] - t[1], v3 = t[1] - t[3];
-            const int r = half * 2 + rr;
-            float *vb = smem + buf * WINO_VBUF + ((r * 4) * WINO_T + ltile) * WINO_BK + wq;
-            *reinterpret_cast<f32x4 *>(vb) = v0;
-            *reinterpret_cast<f32x4 *>(vb + 1 * WINO_T * WINO_BK) = v1;
-            *reinterpret_cast<f32x4 *>(vb + 2 * WINO_T * WINO_BK) = v2;
-            *reinterpret_cast<f32x4 *>(vb + 3 * WINO_T * WINO_BK) = v3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {      // V row r: (B^T d)[r] per column, then (.) B along the columns
+                f32x4 t[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (r == 0) t[c] = d[0 * 4 + c] - d[2 * 4 + c];
+                    else if (r == 1) t[c] = d[1 * 4 + c] + d[2 * 4 + c];
+                    else if (r == 2) t[c] = d[2 * 4 + c] - d[1 * 4 + c];
+                    else t[c] = d[1 * 4 + c] - d[3 * 4 + c];
+                }
+                float *vb = smem + buf * WINO_VBUF + ((r * 4) * WINO_T + ltile) * WINO_BK + wq;
+                *reinterpret_cast<f32x4 *>(vb) = t[0] - t[2];
+                *reinterpret_cast<f32x4 *>(vb + 1 * WINO_T * WINO_BK) = t[1] + t[2];
+                *reinterpret_cast<f32x4 *>(vb + 2 * WINO_T * WINO_BK) = t[2] - t[1];
+                *reinterpret_cast<f32x4 *>(vb + 3 * WINO_T * WINO_BK) = t[1] - t[3];
+            }
+        };
+        load_patch(0, dA);
+        if (KS > 1) load_patch(1, dB);
+        transform_store(0, dA);
+        if (KS > 2) load_patch(2, dA);
+        lds_barrier();                                   // V(0) visible
+        for (int ks = 0; ks < KS; ks += 2) {
+            // step ks: produce V(ks+1) from dB, refill dB with patch ks+3
+            if (ks + 1 < KS) {
+                if (!(a.ablate & 4)) transform_store((ks + 1) & 1, dB);   // buffer last read in step ks-1 (barrier passed)
+                if (ks + 3 < KS && !(a.ablate & 1)) load_patch(ks + 3, dB);
+            }
+            lds_barrier();
+            // step ks+1: produce V(ks+2) from dA, refill dA with patch ks+4
+            if (ks + 1 < KS) {
+                if (ks + 2 < KS) {
+                    if (!(a.ablate & 4)) transform_store((ks + 2) & 1, dA);
+                    if (ks + 4 < KS && !(a.ablate & 1)) load_patch(ks + 4, dA);
+                }
+                lds_barrier();
+            }
         }
-    };
-
-    // ---- U fragments of this wave's 4 xi: [xi][g] -----------------------------------------------------------
-    const int kgroups = a.Cin / 8;
-    f32x4 fb[4][2], fbn[4][2];
-    auto load_u = [&](int ks, f32x4 (&dst)[4][2]) {
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-                dst[x][g] = *reinterpret_cast<const f32x4 *>(
-                    a.U + ((size_t)(((wave * 4 + x) * a.tiles_n + bn) * kgroups + ks * 2 + g) * 64 + lane) * 4);
-    };
-
-    f32x16 acc[4];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
-
-    // software pipeline, ONE barrier per k-step: while the MFMAs of step ks run, the patch of step ks+1 (already in
-    // registers) is transformed into the other V buffer, the patch of ks+2 and the U fragments of ks+1 are in flight
-    load_patch(0);
-    load_u(0, fb);
-    transform_store(0);
-    if (KS > 1) load_patch(1);
-    __syncthreads();
-    const int rq0 = (((lane >> 5)) ^ ((l31 >> 2) & 3)) * 4;          // swizzled quad of k-group 0 (q = h)
-    const int rq1 = ((2 + (lane >> 5)) ^ ((l31 >> 2) & 3)) * 4;      // k-group 1 (q = 2 + h)
-    for (int ks = 0; ks < KS; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < KS) load_u(ks + 1, fbn);
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const float *vb = smem + buf * WINO_VBUF + ((wave * 4 + x) * WINO_T + l31) * WINO_BK;
-            const f32x4 fa0 = *reinterpret_cast<const f32x4 *>(vb + rq0);
-            const f32x4 fa1 = *reinterpret_cast<const f32x4 *>(vb + rq1);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[s], fb[x][0][s], acc[x], 0, 0, 0);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[s], fb[x][1][s], acc[x], 0, 0, 0);
-        }
-        if (ks + 1 < KS) {
-            transform_store(buf ^ 1);          // independent of the MFMAs above: the scheduler interleaves them
-            if (ks + 2 < KS) load_patch(ks + 2);
+    } else {
+        // ======================================= compute waves ================================================
+        const int kgroups = a.Cin / 8;
+        // two U-fragment register sets used alternately (loop unrolled by two, no copies): the loads of step ks+1 are
+        // issued before the MFMAs of step ks and only waited for one full step later
+        f32x4 fbA[4][2], fbB[4][2];
+        auto load_u = [&](int ks, f32x4 (&dst)[4][2]) {
 #pragma unroll
             for (int x = 0; x < 4; ++x)
 #pragma unroll
-                for (int g = 0; g < 2; ++g) fb[x][g] = fbn[x][g];
+                for (int g = 0; g < 2; ++g)
+                    dst[x][g] = *reinterpret_cast<const f32x4 *>(
+                        a.U + ((size_t)(((wave * 4 + x) * a.tiles_n + bn) * kgroups + ks * 2 + g) * 64 + lane) * 4);
+        };
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[x][m][r] = 0.f;
+        const int rq0 = ((lane >> 5) ^ ((l31 >> 2) & 3)) * 4;          // swizzled quad of k-group 0 (q = h)
+        const int rq1 = ((2 + (lane >> 5)) ^ ((l31 >> 2) & 3)) * 4;    // k-group 1 (q = 2 + h)
+        const unsigned lds0 = (unsigned)(uintptr_t)smem;   // LDS byte address of the dynamic segment
+        auto compute = [&](int buf, f32x4 (&fb)[4][2]) {
+            // 8 groups (xi x, k-group g) of 8 MFMAs; the V fragments of group i+1 are requested from LDS (hand-counted
+            // asm reads) before the MFMAs of group i issue and waited for after them: the single compute wave of a
+            // SIMD never stalls on LDS latency
+            const unsigned vbase = lds0 + (unsigned)(buf * WINO_VBUF + (wave * 4 * WINO_T + l31) * WINO_BK) * 4u;
+            f32x4 fa[2][2];                                // [parity][m]
+            fa[0][0] = lds_read_b128_async(vbase + rq0 * 4);
+            fa[0][1] = lds_read_b128_async(vbase + (32 * WINO_BK + rq0) * 4);
+            lds_wait();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int x = i >> 1, g = i & 1, cur = i & 1, nxt = cur ^ 1;
+                if (i + 1 < 8) {
+                    const int xn = (i + 1) >> 1, gn = (i + 1) & 1;
+                    const unsigned vb = vbase + (unsigned)(xn * WINO_T * WINO_BK + (gn ? rq1 : rq0)) * 4u;
+                    fa[nxt][0] = lds_read_b128_async(vb);
+                    fa[nxt][1] = lds_read_b128_async(vb + 32 * WINO_BK * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        acc[x][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m][s], fb[x][g][s], acc[x][m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                lds_wait();
+            }
+        };
+        // NOTE: the prefetch loads are UNCONDITIONAL (index clamped on the last step).  With a conditional load the
+        // compiler cannot know how many loads are in flight and emits pessimistic s_waitcnt vmcnt(N) that also wait
+        // for the loads just issued -- which serialises the full memory latency into every k-step.
+        load_u(0, fbA);
+        lds_barrier();                                     // V(0) visible
+        for (int ks = 0; ks < KS; ks += 2) {
+            if (!(a.ablate & 8)) load_u(min(ks + 1, KS - 1), fbB);
+            __builtin_amdgcn_sched_barrier(0);             // keep the loads ahead of the MFMAs (the scheduler sinks them)
+            if (!(a.ablate & 2)) compute(0, fbA);
+            lds_barrier();
+            if (ks + 1 < KS) {
+                if (!(a.ablate & 8)) load_u(min(ks + 2, KS - 1), fbA);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(a.ablate & 2)) compute(1, fbB);
+                lds_barrier();
+            }
         }
-        __syncthreads();
-    }
-
-    // ---- gather the 16 M[xi] in LDS: M[xi][tile][cout] (the loop ended with a barrier) ------------------------
+        // ---- gather the 16 M[xi] in LDS: M[xi][tile][cout] (the loop ended with a barrier: V is dead) -----------
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        float *mb = smem + (size_t)(wave * 4 + x) * WINO_T * WINO_LDM + l31;
+        for (int x = 0; x < 4; ++x)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mb[((r & 3) + 8 * (r >> 2) + hrow) * WINO_LDM] = acc[x][r];
+            for (int m = 0; m < 2; ++m) {
+                float *mb = smem + ((size_t)(wave * 4 + x) * WINO_T + m * 32) * WINO_LDM + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mb[((r & 3) + 8 * (r >> 2) + hrow) * WINO_LDM] = acc[x][m][r];
+            }
     }
     __syncthreads();
 
-    // ---- A^T M A + epilogue: thread = (tile, cout) ----------------------------------------------------------
+    // ---- A^T M A + epilogue: thread = (tile, cout), all 512 threads -------------------------------------------
     const int co = n0 + (tid & 31);
     const bool cok = co < a.Cout;
     const float sc = (cok && a.scale) ? a.scale[co] : 1.f;
@@ -178,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs a)
     const bool sg = a.sigmoid_from >= 0 && co >= a.sigmoid_from;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int tl = (tid >> 5) + 8 * q;
+        const int tl = (tid >> 5) + 16 * q;
         const int t = t0 + tl;
         if (t >= a.NT || !cok) continue;
         float m[16];
@@ -232,7 +307,12 @@ extern "C" int m3d_wino_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t str
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cout_pad = d->Cout_pad;
     a.TH = d->H / 2; a.TW = d->W / 2; a.NT = d->N * a.TH * a.TW; a.tiles_n = d->Cout_pad / 32;
     a.act = d->act; a.sigmoid_from = d->sigmoid_from; a.res_mode = d->res_mode;
-    constexpr size_t smem = (size_t)16 * WINO_T * WINO_LDM * sizeof(float);   // 67,584 B (>= 2 V buffers: 65,536 B)
+    {
+        static int abl = -1;
+        if (abl < 0) { const char *e = getenv("M3D_ABLATE"); abl = e ? atoi(e) : 0; }
+        a.ablate = abl;
+    }
+    constexpr size_t smem = (size_t)16 * WINO_T * WINO_LDM * sizeof(float);   // 135,168 B (>= 2 V buffers: 131,072 B)
     static bool attr_set = false;
     if (!attr_set) {
         M3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -240,7 +320,7 @@ extern "C" int m3d_wino_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t str
         attr_set = true;
     }
     const int grid = cdiv(a.NT, WINO_T) * a.tiles_n;
-    hipLaunchKernelGGL(wino_kernel, dim3(grid), dim3(256), smem, stream, a);
+    hipLaunchKernelGGL(wino_kernel, dim3(grid), dim3(512), smem, stream, a);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
 }

@@ -304,7 +304,7 @@ class Engine:
             # Winograd F(2x2,3x3): 2.25x fewer MFMA FLOPs for the plain 3x3 stride-1 layers
             d.wgt = pc.wino.data_ptr()
             flops = 2.0 * x.n * d.Ho * d.Wo * d.Cout * 9 * pc.cin
-            plan.ops.append((name, "wino<32,32,16>", flops, lambda st: _hip.check(L.m3d_wino_conv3x3_forward(ref, st)), d))
+            plan.ops.append((name, "wino<64,32,16>", flops, lambda st: _hip.check(L.m3d_wino_conv3x3_forward(ref, st)), d))
             return
         bm, bn, bk, grid = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         _hip.check(L.m3d_conv2d_tile(ref, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(bk), ctypes.byref(grid)))

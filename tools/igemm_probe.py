@@ -23,6 +23,11 @@ for name, n, ci, h, w, co, k, stride in SHAPES:
     v = S.View(x, n, h, w, ci, ci)
     wt = torch.randn(co, ci, k, k, device=dev) / (ci * k * k) ** 0.5
     wp, co_, cop, kh, kw = S._pack(wt, ci, 32)
+    use_wino = os.environ.get("PROBE_WINO", "0") == "1" and k == 3 and stride == 1
+    if use_wino:
+        from m3dssd_amd.engine import pack_wino
+        wp = pack_wino(wt, cop, dev)
+    fn = L.m3d_wino_conv3x3_forward if use_wino else L.m3d_conv2d_forward
     ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
     out = torch.empty(n, ho, wo, co, device=dev)
     d = _hip.ConvDesc()
@@ -34,13 +39,13 @@ for name, n, ci, h, w, co, k, stride in SHAPES:
     bm, bn, bk, grid = (ctypes.c_int() for _ in range(4))
     L.m3d_conv2d_tile(ctypes.byref(d), ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(bk), ctypes.byref(grid))
     for _ in range(3):
-        _hip.check(L.m3d_conv2d_forward(ctypes.byref(d), st))
+        _hip.check(fn(ctypes.byref(d), st))
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     iters = 20
     e0.record()
     for _ in range(iters):
-        _hip.check(L.m3d_conv2d_forward(ctypes.byref(d), st))
+        _hip.check(fn(ctypes.byref(d), st))
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
