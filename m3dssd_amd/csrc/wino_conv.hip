@@ -72,7 +72,8 @@ __device__ __forceinline__ void lds_barrier()
 __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // V[2][16][64][16]  then  M[16][64][33]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform -> SGPR, scalar branches
     const int l31 = lane & 31, hrow = 4 * (lane >> 5);
     const bool is_loader = wave >= 4;
 
@@ -170,13 +171,18 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
         // two U-fragment register sets used alternately (loop unrolled by two, no copies): the loads of step ks+1 are
         // issued before the MFMAs of step ks and only waited for one full step later
         f32x4 fbA[4][2], fbB[4][2];
+        // U fragment (xi, k-group G) of this cout block sits at ub + xi_local*xstride + G*256 floats (+ lane*4):
+        // a uniform SGPR base plus a constant 32-bit lane offset -> one instruction per load, no per-load VALU math
+        const size_t xstride = (size_t)a.tiles_n * kgroups * 256;
+        const float *ub = a.U + ((size_t)(wave * 4) * a.tiles_n + bn) * kgroups * 256;
+        const unsigned ulane = (unsigned)lane * 16u;
         auto load_u = [&](int ks, f32x4 (&dst)[4][2]) {
 #pragma unroll
             for (int x = 0; x < 4; ++x)
 #pragma unroll
                 for (int g = 0; g < 2; ++g)
                     dst[x][g] = *reinterpret_cast<const f32x4 *>(
-                        a.U + ((size_t)(((wave * 4 + x) * a.tiles_n + bn) * kgroups + ks * 2 + g) * 64 + lane) * 4);
+                        reinterpret_cast<const char *>(ub + x * xstride + (size_t)(ks * 2 + g) * 256) + ulane);
         };
         f32x16 acc[4][2];
 #pragma unroll
