@@ -24,6 +24,7 @@
  *   m3d_wino_conv3x3_forward ... the same Conv2d 3x3 stride-1 layers through Winograd F(2x2,3x3)
  *   m3d_head_mlp_forward ....... the 3-layer 1x1 heads, model/M3d_inference_align.py:77-210 (one launch per head)
  *   m3d_stem_conv7x7 ........... DLA.base_layer, model/pose_dla_dcn.py:336-340
+ *   m3d_conv3x3_c16 ............ DLA.level0 (3x3 16->16 at full resolution), model/pose_dla_dcn.py:341-342
  *   m3d_maxpool2x2 ............. Tree.downsample nn.MaxPool2d(2,2), pose_dla_dcn.py:306,316
  *   m3d_upsample2x_add ......... IDAUp: depthwise ConvTranspose2d(4, s2, p1) + skip add,
  *                                 pose_dla_dcn.py:536-538,550-552
@@ -154,6 +155,10 @@ int m3d_nhwc_to_nchw(const float *in, int in_cs, float *out, int N, int C, int H
 /* 7x7, 3->16, stride 1, pad 3 on an NCHW image; fused affine (folded BN) + LeakyReLU; NHWC out. */
 int m3d_stem_conv7x7(const float *img_nchw, const float *wgt /*[7*7*3][16]*/, const float *scale,
                      const float *shift, float *out, int out_cs, int N, int H, int W, m3d_stream_t stream);
+/* 3x3, 16 -> 16, stride 1, pad 1 (DLA level0, pose_dla_dcn.py:341-342) as a direct VALU convolution: NHWC in/out,
+ * wgt [(i*3+j)*16 + cin][16 cout], fused affine (folded BN) + LeakyReLU. */
+int m3d_conv3x3_c16(const float *in, int in_cs, const float *wgt, const float *scale, const float *shift, float *out,
+                    int out_cs, int N, int H, int W, m3d_stream_t stream);
 int m3d_maxpool2x2(const float *in, int in_cs, float *out, int out_cs, int N, int H, int W, int C,
                    m3d_stream_t stream);
 /* out = ConvTranspose2d_depthwise(in, wgt[4][4][C], stride 2, pad 1) + skip ;  in is [N,H,W,C], out/skip [N,2H,2W,C] */

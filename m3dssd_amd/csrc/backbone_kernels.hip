@@ -147,6 +147,79 @@ extern "C" int m3d_stem_conv7x7(const float *img_nchw, const float *wgt, const f
 }
 
 // ---------------------------------------------------------------------------------------
+// level0: 3x3, 16 -> 16, stride 1, pad 1 at full resolution (model/pose_dla_dcn.py:341-342), NHWC in/out.
+// 16 output channels cannot fill a 32-wide MFMA tile (the igemm pads to 32 and wastes half the pipe) and the
+// layer moves 0.5 GB at bs=8, so it runs as a direct convolution on the VALU like the stem: one thread = one output
+// pixel x 16 channels, the (8+2)x(32+2)x16 input tile in LDS (pixel stride 20 floats: conflict-free b128 reads),
+// the 2304 weights through the scalar cache (wave-uniform index -> SGPR operands of v_fma).
+// wgt layout [(i*3 + j)*16 + cin][16 cout].
+#define L0_TH 8
+#define L0_TW 32
+#define L0_PS 20
+__global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restrict__ in, int in_cs,
+                                                          const float *__restrict__ wgt, const float *__restrict__ scale,
+                                                          const float *__restrict__ shift, float *__restrict__ out,
+                                                          int out_cs, int H, int W)
+{
+    constexpr int PH = L0_TH + 2, PW = L0_TW + 2;
+    __shared__ __attribute__((aligned(16))) float tile[PH * PW * L0_PS];
+    const int n = blockIdx.z, h0 = blockIdx.y * L0_TH, w0 = blockIdx.x * L0_TW;
+    for (int i = threadIdx.x; i < PH * PW * 4; i += 256) {
+        const int q = i & 3, p = i >> 2;
+        const int r = p / PW, c = p - r * PW;
+        const int h = h0 + r - 1, w = w0 + c - 1;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (h >= 0 && h < H && w >= 0 && w < W)
+            v = *reinterpret_cast<const f32x4 *>(in + ((size_t)(n * H + h) * W + w) * in_cs + q * 4);
+        *reinterpret_cast<f32x4 *>(tile + p * L0_PS + q * 4) = v;
+    }
+    __syncthreads();
+    const int ty = threadIdx.x / L0_TW, tx = threadIdx.x % L0_TW;
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float *px = tile + ((ty + i) * PW + tx + j) * L0_PS;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 x4 = *reinterpret_cast<const f32x4 *>(px + q * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float *wp = wgt + (((i * 3 + j) * 16) + q * 4 + e) * 16;   // uniform -> s_load
+#pragma unroll
+                    for (int o = 0; o < 16; ++o) acc[o] = fmaf(x4[e], wp[o], acc[o]);
+                }
+            }
+        }
+    }
+    const int h = h0 + ty, w = w0 + tx;
+    if (h < H && w < W) {
+        float *op = out + ((size_t)(n * H + h) * W + w) * out_cs;
+#pragma unroll
+        for (int o4 = 0; o4 < 4; ++o4) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = leaky(acc[o4 * 4 + e] * scale[o4 * 4 + e] + shift[o4 * 4 + e]);
+            *reinterpret_cast<f32x4 *>(op + o4 * 4) = v;
+        }
+    }
+}
+
+extern "C" int m3d_conv3x3_c16(const float *in, int in_cs, const float *wgt, const float *scale, const float *shift,
+                               float *out, int out_cs, int N, int H, int W, m3d_stream_t stream)
+{
+    M3D_REQUIRE(in && wgt && scale && shift && out && in_cs % 4 == 0 && out_cs % 4 == 0 && in_cs >= 16 && out_cs >= 16,
+                "conv3x3_c16: bad arguments");
+    hipLaunchKernelGGL(conv3x3_c16_kernel, dim3(cdiv(W, L0_TW), cdiv(H, L0_TH), N), dim3(256), 0, (hipStream_t)stream, in,
+                       in_cs, wgt, scale, shift, out, out_cs, H, W);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // MaxPool2d(2, 2) (floor mode), float4 along channels.
 __global__ void maxpool2x2_kernel(const float *__restrict__ in, int in_cs, float *__restrict__ out, int out_cs, int N,
                                   int H, int W, int C4)

@@ -162,6 +162,9 @@ class Engine:
         s = g / torch.sqrt(v + BN_EPS)
         P["stem.scale"], P["stem.shift"] = s.contiguous(), (be - m * s).contiguous()
         P["level0"] = self._pc(b + ".level0.0", b + ".level0.1")
+        # level0 also as a direct VALU conv: weights [(i*3+j)*16 + cin][cout]
+        w0 = sd[b + ".level0.0.weight"].detach().to(dev, torch.float32)
+        P["level0.direct"] = w0.permute(2, 3, 1, 0).contiguous() if tuple(w0.shape) == (16, 16, 3, 3) else None
         P["level1"] = self._pc(b + ".level1.0", b + ".level1.1")
 
         def block(p):
@@ -332,7 +335,13 @@ class Engine:
             in_ptr[0], P["stem.w"].data_ptr(), P["stem.scale"].data_ptr(), P["stem.shift"].data_ptr(), s0.ptr,
             s0.cs, B, H, W, st)))
         l0 = self._buf(plan, B, H, W, 16, name="level0")
-        self._conv(plan, "level0", P["level0"], s0, l0, 1, 1, act=1)
+        if P["level0.direct"] is not None and os.environ.get("M3D_LEVEL0_IGEMM", "0") != "1":
+            pc0 = P["level0"]
+            self._op(plan, "level0", "conv3x3_c16", lambda st: _hip.check(L.m3d_conv3x3_c16(
+                s0.ptr, s0.cs, P["level0.direct"].data_ptr(), pc0.scale.data_ptr(), pc0.shift.data_ptr(), l0.ptr, l0.cs,
+                B, H, W, st)))
+        else:
+            self._conv(plan, "level0", P["level0"], s0, l0, 1, 1, act=1)
         l1 = self._buf(plan, B, H // 2, W // 2, 32, name="level1")
         self._conv(plan, "level1", P["level1"], l0, l1, 2, 1, act=1)
 
