@@ -650,15 +650,17 @@ class Engine:
         self.run_plan(plan)
         return plan.named["feats0"]
 
-    def run_plan(self, plan):
+    def run_plan(self, plan, start=0, end=None):
+        """Issue plan.ops[start:end] on the current stream (the whole forward by default)."""
         st = _Stream.current()
+        ops = plan.ops[start:end]
         if self.profile is None:
-            for op in plan.ops:
+            for op in ops:
                 op[3](st)
             return
         L = self.L
         evs = []
-        for op in plan.ops:
+        for op in ops:
             if self.profile_kinds is not None and op[1] not in self.profile_kinds:
                 op[3](st)
                 continue

@@ -20,9 +20,32 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def detect_from_outputs(eng, plan, prob, bbox_2d, bbox_3d, rois, conf):
+    """decode -> top-N-pre -> NMS on the engine's output buffers (current stream).
+    -> (aboxes [B, n_pre, 14] score-sorted, keep [B, n_pre] int32 positions, num_keep [B] int32)."""
+    L = _hip.lib()
+    dev = prob.device
+    B, R = prob.shape[0], prob.shape[1]
+    keys = plan.named["score_key"]
+    n_pre = min(int(conf.nms_topN_pre), R)
+    top = torch.topk(keys, n_pre, dim=1, largest=True, sorted=True)[0]
+    rows = (0xFFFFFFFF - (top & 0xFFFFFFFF)).contiguous()              # int64 row ids, score-descending
+    aboxes = torch.empty(B, n_pre, 14, device=dev, dtype=torch.float32)
+    P = eng.P
+    with torch.cuda.device(dev):
+        _hip.check(L.m3d_decode_rows(rows.data_ptr(), prob.data_ptr(), bbox_2d.data_ptr(), bbox_3d.data_ptr(),
+                                     rois.data_ptr(), P["anchors"].data_ptr(), P["means"].data_ptr(),
+                                     P["stds"].data_ptr(), aboxes.data_ptr(), B, R, n_pre, _stream()))
+        keep = torch.empty(B, n_pre, device=dev, dtype=torch.int32)
+        num = torch.zeros(B, device=dev, dtype=torch.int32)
+        ws = torch.empty(L.m3d_nms_workspace_bytes(B, n_pre), device=dev, dtype=torch.uint8)
+        _hip.check(L.m3d_nms_sorted_dev(aboxes.data_ptr(), B, n_pre, 14, float(conf.nms_thres), ws.data_ptr(),
+                                        keep.data_ptr(), num.data_ptr(), _stream()))
+    return aboxes, keep, num
+
+
 def detect_device(net, im, conf, top_post=None):
     """-> (aboxes [B, n_pre, 14] score-sorted, keep [B, n_pre] int32 positions, num_keep [B] int32), device tensors."""
-    L = _hip.lib()
     if im.dim() == 3:
         im = im[None]
     dev = next(net.parameters()).device
@@ -31,24 +54,8 @@ def detect_device(net, im, conf, top_post=None):
         net.eval()
         cls, prob, bbox_2d, bbox_3d, feat_size, rois = net(im)
         eng = net.engine()
-        B, R = prob.shape[0], prob.shape[1]
-        plan = eng.plan_for(B, im.shape[2], im.shape[3])
-        keys = plan.named["score_key"]
-        n_pre = min(int(conf.nms_topN_pre), R)
-        top = torch.topk(keys, n_pre, dim=1, largest=True, sorted=True)[0]
-        rows = (0xFFFFFFFF - (top & 0xFFFFFFFF)).contiguous()              # int64 row ids, score-descending
-        aboxes = torch.empty(B, n_pre, 14, device=dev, dtype=torch.float32)
-        P = eng.P
-        with torch.cuda.device(dev):
-            _hip.check(L.m3d_decode_rows(rows.data_ptr(), prob.data_ptr(), bbox_2d.data_ptr(), bbox_3d.data_ptr(),
-                                         rois.data_ptr(), P["anchors"].data_ptr(), P["means"].data_ptr(),
-                                         P["stds"].data_ptr(), aboxes.data_ptr(), B, R, n_pre, _stream()))
-            keep = torch.empty(B, n_pre, device=dev, dtype=torch.int32)
-            num = torch.zeros(B, device=dev, dtype=torch.int32)
-            ws = torch.empty(L.m3d_nms_workspace_bytes(B, n_pre), device=dev, dtype=torch.uint8)
-            _hip.check(L.m3d_nms_sorted_dev(aboxes.data_ptr(), B, n_pre, 14, float(conf.nms_thres), ws.data_ptr(),
-                                            keep.data_ptr(), num.data_ptr(), _stream()))
-    return aboxes, keep, num
+        plan = eng.plan_for(prob.shape[0], im.shape[2], im.shape[3])
+        return detect_from_outputs(eng, plan, prob, bbox_2d, bbox_3d, rois, conf)
 
 
 def im_detect_3d(im, net, rpn_conf, obj=None, gpu=0, synced=False):
@@ -69,9 +76,8 @@ def im_detect_3d(im, net, rpn_conf, obj=None, gpu=0, synced=False):
     return out
 
 
-def detect_batch(net, im, conf):
-    """-> (dets [B, nms_topN_post, 14] zero-padded, counts [B] int32) device tensors."""
-    aboxes, keep, num = detect_device(net, im, conf)
+def select_post(aboxes, keep, num, conf):
+    """Kept rows -> fixed-size blocks (dets [B, nms_topN_post, 14] zero-padded, counts [B] int32)."""
     B = aboxes.shape[0]
     post = int(conf.nms_topN_post)
     idx = keep[:, :post].long().clamp_(min=0, max=aboxes.shape[1] - 1)
@@ -82,3 +88,8 @@ def detect_batch(net, im, conf):
     if dets.shape[1] < post:
         dets = torch.cat([dets, dets.new_zeros(B, post - dets.shape[1], 14)], 1)
     return dets.contiguous(), counts.to(torch.int32)
+
+
+def detect_batch(net, im, conf):
+    """-> (dets [B, nms_topN_post, 14] zero-padded, counts [B] int32) device tensors."""
+    return select_post(*detect_device(net, im, conf), conf)

@@ -548,3 +548,32 @@ def test_winograd_conv3x3_matches_torch(case):
         got = S._to_nchw(out, co).cpu()
     assert got.shape == ref.shape
     assert _relerr(got, ref.detach()) < 2e-4
+
+
+def test_pipelined_detector_matches_detect_batch():
+    """forward(k) overlapped with detect(k-1) in one hipGraph: same detections as the sequential path."""
+    from lib.rpn_util import detect_batch
+    from m3dssd_amd.pipeline import PipelinedDetector
+    from model.M3d_inference_align import build
+    dev = _dev()
+    conf = synth.synth_conf((128, 320), 0, batch_size=2, device="cuda:0")
+    net = build(conf, "test")
+    net.load_state_dict(synth.synth_state_dict(0))
+    net = net.to(dev)
+    xs = [synth.synth_frames(2, (128, 320), 20 + i).to(dev) for i in range(3)]
+    ref = []
+    for x in xs:
+        d, c = detect_batch(net, x, conf)
+        ref.append((d.clone(), c.clone()))
+    pipe = PipelinedDetector(net, conf, 2, 128, 320)
+    got = []
+    for x in xs:
+        r = pipe.step(x)
+        if r is not None:
+            got.append((r[0].clone(), r[1].clone()))
+    r = pipe.flush()
+    got.append((r[0].clone(), r[1].clone()))
+    assert pipe.flush() is None
+    assert len(got) == 3
+    for (gd, gc), (rd, rc) in zip(got, ref):
+        assert torch.equal(gc, rc) and torch.equal(gd, rd)
