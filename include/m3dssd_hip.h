@@ -127,6 +127,9 @@ typedef struct m3d_mlp_desc {
     int HW;
 } m3d_mlp_desc;
 int m3d_head_mlp_forward(const m3d_mlp_desc *d, m3d_stream_t stream);
+/* n (<= 16) independent heads of the same depth, M and Cout_pad in ONE launch (grid.y = head): the regression heads
+ * that read the same aligned feature map (M3d_inference_align.py:139-176) have no mutual dependency. */
+int m3d_head_mlp_forward_batched(const m3d_mlp_desc *d, int n, m3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Drop-in for dcn_v2_cuda_forward: NCHW contiguous fp32 device tensors, exactly the reference

@@ -23,6 +23,7 @@ struct MlpArgs {
     float *out;
     long long out_img_stride;
     int in_cs, M, HW, Cin, Cout, Cout_pad;
+    int ablate;   // diagnostics (M3D_ABLATE): 1 = no weight loads, 2 = no MFMA, 4 = no input staging, 8 = no LDS epilogue writes
 };
 
 #define MLP_BM 64
@@ -30,9 +31,15 @@ struct MlpArgs {
 #define MLP_LDA (MLP_H + 4)
 #define MLP_BK 32
 
+#define MLP_MAX_HEADS 16
+struct MlpBatch {
+    MlpArgs head[MLP_MAX_HEADS];                      // blockIdx.y selects the head (same M for all of them)
+};
+
 template <bool HAS_L1, int N3>
-__global__ __launch_bounds__(256) void head_mlp_kernel(const MlpArgs a)
+__global__ __launch_bounds__(256) void head_mlp_kernel(const MlpBatch batch)
 {
+    const MlpArgs &a = batch.head[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) float act[];   // [64][260]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -45,8 +52,12 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpArgs a)
 
     // ---- B-fragment stream: tile t of the concatenated layers -> 2 row-tiles x 4 k-groups per wave --------
     // packed weight element W[J*32 + l31][G*8 + h*4 + 0..3] sits at ((J*(K/8) + G)*64 + lane)*4
-    f32x4 fb[2][4], fbn[2][4];
-    auto load_frags = [&](int t, f32x4 (&dst)[2][4]) {
+    // two register sets used alternately (k loops unrolled by two, every layer starts on an even stream position).
+    // The prefetch is UNCONDITIONAL (stream position clamped at the end): with a conditional load or a set-to-set copy
+    // hipcc emits s_waitcnt vmcnt(0) for the loads just issued, serialising the memory latency into every k-tile.
+    f32x4 fbA[2][4], fbB[2][4];
+    auto load_frags = [&](int t_req, f32x4 (&dst)[2][4]) {
+        const int t = min(t_req, n_tiles - 1);
         const float *w;
         int kgroups, kt, j0, nj;
         if (HAS_L1 && t < kt1) { w = a.w[0]; kgroups = a.Cin / 8; kt = t; j0 = wave * 2; nj = 2; }
@@ -56,19 +67,19 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpArgs a)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                if (j < nj)
+                if (j < nj && !(a.ablate & 1))
                     dst[j][g] = *reinterpret_cast<const f32x4 *>(
                         w + ((size_t)((j0 + j) * kgroups + kt * 4 + g) * 64 + lane) * 4);
     };
 
-    load_frags(0, fb);
+    load_frags(0, fbA);
     // ---- stage the input tile: act[row][0..Cin) ----------------------------------------------------------
     {
         const int c4n = a.Cin / 4;                    // float4 per row
         for (int i = tid; i < MLP_BM * c4n; i += 256) {
             const int row = i / c4n, c4 = i - row * c4n;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m0 + row < a.M) v = *reinterpret_cast<const f32x4 *>(a.in + (size_t)(m0 + row) * a.in_cs + c4 * 4);
+            if (m0 + row < a.M && !(a.ablate & 4)) v = *reinterpret_cast<const f32x4 *>(a.in + (size_t)(m0 + row) * a.in_cs + c4 * 4);
             *reinterpret_cast<f32x4 *>(act + row * MLP_LDA + c4 * 4) = v;
         }
     }
@@ -85,8 +96,7 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         const int wn = wave * 64;
-        for (int kt = 0; kt < KT; ++kt, ++t) {
-            if (t + 1 < n_tiles) load_frags(t + 1, fbn);
+        auto tile = [&](int kt, f32x4 (&fb)[2][4]) {
             const float *Ab = act + l31 * MLP_LDA + kt * MLP_BK + lh4;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -99,12 +109,18 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpArgs a)
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][g][s], acc[i][j], 0, 0, 0);
+                            if (!(a.ablate & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][g][s], acc[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) fb[j][g] = fbn[j][g];
+        };
+        for (int kt = 0; kt < KT; kt += 2) {          // KT is even (Cin and 256 are multiples of 64)
+            load_frags(t + 1, fbB);
+            __builtin_amdgcn_sched_barrier(0);        // keep the prefetch ahead of the MFMAs
+            tile(kt, fbA);
+            ++t;
+            load_frags(t + 1, fbA);
+            __builtin_amdgcn_sched_barrier(0);
+            tile(kt + 1, fbB);
+            ++t;
         }
         // affine + LeakyReLU in registers, then overwrite the activation tile in place
         const float *sc = a.scale[layer], *sh = a.shift[layer];
@@ -118,7 +134,7 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = i * 32 + (r & 3) + 8 * (r >> 2) + hrow;
-                    act[row * MLP_LDA + co] = leaky(acc[i][j][r] * s + b);
+                    if (!(a.ablate & 8)) act[row * MLP_LDA + co] = leaky(acc[i][j][r] * s + b);
                 }
         }
         __syncthreads();
@@ -138,8 +154,7 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpArgs a)
             for (int j = 0; j < TNo; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        for (int kt = 0; kt < kt3; ++kt, ++t) {
-            if (t + 1 < n_tiles) load_frags(t + 1, fbn);
+        auto tile = [&](int kt, f32x4 (&fb)[2][4]) {
             const float *Ab = act + (wm + l31) * MLP_LDA + kt * MLP_BK + lh4;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -152,12 +167,18 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpArgs a)
                     for (int i = 0; i < TMo; ++i)
 #pragma unroll
                         for (int j = 0; j < TNo; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][g][s], fa[i][s], acc[i][j], 0, 0, 0);
+                            if (!(a.ablate & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][g][s], fa[i][s], acc[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int j = 0; j < TNo; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) fb[j][g] = fbn[j][g];
+        };
+        for (int kt = 0; kt < kt3; kt += 2) {
+            load_frags(t + 1, fbB);
+            __builtin_amdgcn_sched_barrier(0);
+            tile(kt, fbA);
+            ++t;
+            load_frags(t + 1, fbA);
+            __builtin_amdgcn_sched_barrier(0);
+            tile(kt + 1, fbB);
+            ++t;
         }
         const float *sc = a.scale[2], *sh = a.shift[2];
 #pragma unroll
@@ -179,7 +200,7 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpArgs a)
 }
 
 template <bool HAS_L1, int N3>
-static int launch_mlp(const MlpArgs &a, hipStream_t stream)
+static int launch_mlp(const MlpBatch &b, int n, hipStream_t stream)
 {
     constexpr size_t smem = (size_t)(MLP_BM * MLP_LDA) * sizeof(float);
     auto kern = head_mlp_kernel<HAS_L1, N3>;
@@ -189,15 +210,14 @@ static int launch_mlp(const MlpArgs &a, hipStream_t stream)
                                     (int)smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(cdiv(a.M, MLP_BM)), dim3(256), smem, stream, a);
+    hipLaunchKernelGGL(kern, dim3(cdiv(b.head[0].M, MLP_BM), n), dim3(256), smem, stream, b);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
 }
 
-extern "C" int m3d_head_mlp_forward(const m3d_mlp_desc *d, m3d_stream_t stream_)
+static int fill_mlp_args(const m3d_mlp_desc *d, MlpArgs &a)
 {
-    hipStream_t stream = (hipStream_t)stream_;
-    M3D_REQUIRE(d && d->in && d->w2 && d->w3 && d->out, "head_mlp: null pointer");
+    M3D_REQUIRE(d->in && d->w2 && d->w3 && d->out, "head_mlp: null pointer");
     M3D_REQUIRE(d->s2 && d->t2 && d->s3 && d->t3, "head_mlp: scale/shift of layers 2 and 3 are required");
     M3D_REQUIRE((d->Cin == 128 && d->w1 && d->s1 && d->t1) || (d->Cin == 256 && !d->w1),
                 "head_mlp: Cin must be 128 (3 layers, w1 given) or 256 (2 layers, w1 NULL)");
@@ -205,16 +225,38 @@ extern "C" int m3d_head_mlp_forward(const m3d_mlp_desc *d, m3d_stream_t stream_)
     M3D_REQUIRE(d->Cout >= 1 && d->Cout <= d->Cout_pad && (d->Cout_pad == 64 || d->Cout_pad == 256),
                 "head_mlp: Cout_pad must be 64 or 256 (got %d)", d->Cout_pad);
     M3D_REQUIRE(d->M > 0 && d->M < (1ll << 30) && d->HW > 0, "head_mlp: bad M / HW");
-    MlpArgs a;
     a.in = d->in; a.in_cs = d->in_cs; a.M = (int)d->M; a.HW = d->HW; a.Cin = d->Cin;
     a.w[0] = d->w1; a.w[1] = d->w2; a.w[2] = d->w3;
     a.scale[0] = d->s1; a.scale[1] = d->s2; a.scale[2] = d->s3;
     a.shift[0] = d->t1; a.shift[1] = d->t2; a.shift[2] = d->t3;
     a.out = d->out; a.out_img_stride = d->out_img_stride; a.Cout = d->Cout; a.Cout_pad = d->Cout_pad;
-    if (d->w1) {
-        if (d->Cout_pad == 64) return launch_mlp<true, 64>(a, stream);
-        return launch_mlp<true, 256>(a, stream);
+    static int abl = -1;
+    if (abl < 0) { const char *e = getenv("M3D_ABLATE_MLP"); abl = e ? atoi(e) : 0; }
+    a.ablate = abl;
+    return M3D_OK;
+}
+
+extern "C" int m3d_head_mlp_forward_batched(const m3d_mlp_desc *d, int n, m3d_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    M3D_REQUIRE(d && n >= 1 && n <= MLP_MAX_HEADS, "head_mlp: 1..%d heads per launch (got %d)", MLP_MAX_HEADS, n);
+    MlpBatch b;
+    for (int i = 0; i < n; ++i) {
+        const int rc = fill_mlp_args(d + i, b.head[i]);
+        if (rc != M3D_OK) return rc;
+        M3D_REQUIRE(d[i].M == d[0].M && (d[i].w1 != nullptr) == (d[0].w1 != nullptr) && d[i].Cout_pad == d[0].Cout_pad,
+                    "head_mlp: heads of one launch must share M, depth and Cout_pad (head %d differs)", i);
     }
-    if (d->Cout_pad == 64) return launch_mlp<false, 64>(a, stream);
-    return launch_mlp<false, 256>(a, stream);
+    for (int i = n; i < MLP_MAX_HEADS; ++i) b.head[i] = b.head[0];
+    if (d->w1) {
+        if (d->Cout_pad == 64) return launch_mlp<true, 64>(b, n, stream);
+        return launch_mlp<true, 256>(b, n, stream);
+    }
+    if (d->Cout_pad == 64) return launch_mlp<false, 64>(b, n, stream);
+    return launch_mlp<false, 256>(b, n, stream);
+}
+
+extern "C" int m3d_head_mlp_forward(const m3d_mlp_desc *d, m3d_stream_t stream)
+{
+    return m3d_head_mlp_forward_batched(d, 1, stream);
 }

@@ -448,16 +448,8 @@ class Engine:
         plan.keep += [cls_pl, box_pl]
         plan.named["cls_planar"], plan.named["box_planar"] = cls_pl, box_pl
 
-        def head(p, x, planar, k0=1):
-            """3-layer head.  1x1 heads run as ONE fused-MLP launch; the cls head runs its 3x3 conv through the
-            igemm and the remaining two 1x1 layers fused."""
+        def head_desc(p, x, planar, first):
             t, img_stride, ch_off = planar
-            if k0 != 1:
-                h1 = self._buf(plan, B, fh, fw, 256)
-                self._conv(plan, p + ".0", P[p + ".0"], x, h1, 1, k0 // 2, act=1)
-                x, first = h1, None
-            else:
-                first = P[p + ".0"]
             d = MlpDesc()
             d.inp, d.in_cs, d.M, d.Cin = x.ptr, x.cs, B * HW, x.c
             if first is not None:
@@ -467,9 +459,31 @@ class Engine:
             d.w3, d.s3, d.t3 = P[p + ".6.frag"].data_ptr(), last.scale.data_ptr(), last.shift.data_ptr()
             d.Cout, d.Cout_pad = last.cout, last.cout_pad
             d.out, d.out_img_stride, d.HW = t.data_ptr() + 4 * ch_off * HW, img_stride, HW
-            ref = ctypes.byref(d)
             flops = 2.0 * B * HW * ((x.c * 256 if first is not None else 0) + 256 * 256 + 256 * last.cout)
-            plan.ops.append((p + ".mlp", "head_mlp<%s,%d>" % ("3" if first is not None else "2", last.cout_pad), flops,
+            return d, flops
+
+        def heads(items):
+            """1x1 heads with no mutual dependency as ONE fused-MLP launch (grid.y = head): items = [(p, x, planar)]."""
+            arr = (MlpDesc * len(items))()
+            flops = 0.0
+            for i, (p, x, planar) in enumerate(items):
+                arr[i], f = head_desc(p, x, planar, P[p + ".0"])
+                flops += f
+            n = len(items)
+            name = "+".join(p for p, _, _ in items) + ".mlp"
+            plan.ops.append((name, "head_mlp<3,%d>" % arr[0].Cout_pad, flops,
+                             lambda st: _hip.check(L.m3d_head_mlp_forward_batched(arr, n, st)), arr))
+
+        def head(p, x, planar, k0=1):
+            """3-layer head.  A 1x1 head runs as one fused-MLP launch; the cls head runs its 3x3 conv through the
+            Winograd kernel and the remaining two 1x1 layers fused."""
+            if k0 == 1:
+                return heads([(p, x, planar)])
+            h1 = self._buf(plan, B, fh, fw, 256)
+            self._conv(plan, p + ".0", P[p + ".0"], x, h1, 1, k0 // 2, act=1)
+            d, flops = head_desc(p, h1, planar, None)
+            ref = ctypes.byref(d)
+            plan.ops.append((p + ".mlp", "head_mlp<2,%d>" % d.Cout_pad, flops,
                              lambda st: _hip.check(L.m3d_head_mlp_forward(ref, st)), d))
 
         head("cls", feats0, (cls_pl, NC * A * HW, 0), 3)
@@ -496,8 +510,10 @@ class Engine:
             1.0, om_sa.ptr, om_sa.cs, B, A, HW, 9, 0, st)))
         feats = self._buf(plan, B, fh, fw, 128, name="feats")
         self._conv(plan, "shape_align.dcn", P["shape_align"], feats0, feats, 1, 1, act=0, res=feats0, om=om_sa)
-        head("bbox_x", feats, box_planar(0))
-        head("bbox_y", feats, box_planar(1))
+        # heads are grouped by the feature map they read (M3d_inference_align.py:139-176): the four centre heads first,
+        # then both centre alignments, then the six size / orientation heads.
+        heads([("bbox_x", feats, box_planar(0)), ("bbox_y", feats, box_planar(1)),
+               ("bbox_x3d", feats, box_planar(4)), ("bbox_y3d", feats, box_planar(5))])
 
         def center_align(p, x, kx, ky, mi, out):
             om = self._buf(plan, B, fh, fw, 3, 4)
@@ -509,16 +525,11 @@ class Engine:
 
         f2d = self._buf(plan, B, fh, fw, 128, name="feats_align2d")
         center_align("center_align2d", feats, 0, 1, 0, f2d)
-        head("bbox_w", f2d, box_planar(2))
-        head("bbox_h", f2d, box_planar(3))
-        head("bbox_x3d", feats, box_planar(4))
-        head("bbox_y3d", feats, box_planar(5))
         f3d = self._buf(plan, B, fh, fw, 128, name="feats_align3d")
         center_align("center_align3d", feats, 4, 5, 4, f3d)
-        head("bbox_w3d", f3d, box_planar(7))
-        head("bbox_h3d", f3d, box_planar(8))
-        head("bbox_l3d", f3d, box_planar(9))
-        head("bbox_rY3d", f3d, box_planar(10))
+        heads([("bbox_w", f2d, box_planar(2)), ("bbox_h", f2d, box_planar(3)),
+               ("bbox_w3d", f3d, box_planar(7)), ("bbox_h3d", f3d, box_planar(8)),
+               ("bbox_l3d", f3d, box_planar(9)), ("bbox_rY3d", f3d, box_planar(10))])
 
         # ---- ANAB ---------------------------------------------------------------------
         gl = self._buf(plan, B, fh, fw, 128, name="feats_gl")

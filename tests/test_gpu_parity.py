@@ -420,15 +420,12 @@ def test_dlaseg_standalone_matches_oracle():
 
 
 # ------------------------------------------------------------------------------------ fused head + graph
-@pytest.mark.parametrize("cin,cout,cpad", [(128, 36, 64), (256, 144, 256), (128, 5, 64)])
-def test_fused_head_mlp_matches_torch(cin, cout, cpad):
-    """m3d_head_mlp_forward vs the unfused conv/BN/LeakyReLU chain in torch (M3d_inference_align.py:77-85)."""
-    import ctypes
+def _head_case(seed, cin, cout, cpad, dev, n=2, h=13, w=21):
+    """One 3-/2-layer head: returns (MlpDesc, device output, torch reference, keep-alive list)."""
     from m3dssd_amd import _hip
+    from m3dssd_amd.engine import pack_frag
     from m3dssd_amd.host import standalone as S
-    dev = _dev()
-    g = torch.Generator().manual_seed(cin + cout)
-    n, h, w = 2, 13, 21                                  # M = 546: not a multiple of the 64-pixel tile
+    g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, cin, h, w, generator=g)
     layers = []
     ref = x
@@ -450,11 +447,10 @@ def test_fused_head_mlp_matches_torch(cin, cout, cpad):
         layers.append((wt, b, bn, last))
     v, _ = S._to_nhwc(x.to(dev))
     d = _hip.MlpDesc()
-    keep = []
+    keep = [v]
     d.inp, d.in_cs, d.M, d.Cin = v.ptr, v.cs, n * h * w, cin
     slots = ["1", "2", "3"] if cin == 128 else ["2", "3"]
     for slot, (wt, b, bn, last) in zip(slots, layers):
-        from m3dssd_amd.engine import pack_frag
         co = wt.shape[0]
         wp = pack_frag(wt.reshape(co, wt.shape[1]), cpad if last else 256, dev)
         sc, sh = S._affine(co, b.to(dev), None if bn is None else bn.to(dev), dev)
@@ -464,9 +460,42 @@ def test_fused_head_mlp_matches_torch(cin, cout, cpad):
         setattr(d, "t" + slot, sh.data_ptr())
     out = torch.zeros(n, cout, h * w, device=dev)
     d.Cout, d.Cout_pad, d.out, d.out_img_stride, d.HW = cout, cpad, out.data_ptr(), cout * h * w, h * w
+    return d, out, ref.detach(), keep
+
+
+@pytest.mark.parametrize("cin,cout,cpad", [(128, 36, 64), (256, 144, 256), (128, 5, 64)])
+def test_fused_head_mlp_matches_torch(cin, cout, cpad):
+    """m3d_head_mlp_forward vs the unfused conv/BN/LeakyReLU chain in torch (M3d_inference_align.py:77-85)."""
+    import ctypes
+    from m3dssd_amd import _hip
+    from m3dssd_amd.host import standalone as S
+    dev = _dev()
+    d, out, ref, keep = _head_case(cin + cout, cin, cout, cpad, dev)
     _hip.check(_hip.lib().m3d_head_mlp_forward(ctypes.byref(d), S._stream()))
-    got = out.view(n, cout, h, w).cpu()
-    assert _relerr(got, ref.detach()) < 2e-4
+    assert _relerr(out.view(ref.shape).cpu(), ref) < 2e-4
+
+
+def test_fused_head_mlp_batched_launch():
+    """m3d_head_mlp_forward_batched: five heads with their own inputs / weights / Cout in one launch, each equal to the
+    torch chain and bit-identical to its single-head launch; mismatched heads are refused."""
+    from m3dssd_amd import _hip
+    from m3dssd_amd.host import standalone as S
+    dev = _dev()
+    L = _hip.lib()
+    cases = [_head_case(100 + i, 128, co, 64, dev) for i, co in enumerate([36, 36, 1, 64, 17])]
+    arr = (_hip.MlpDesc * len(cases))(*[c[0] for c in cases])
+    _hip.check(L.m3d_head_mlp_forward_batched(arr, len(cases), S._stream()))
+    torch.cuda.synchronize()
+    batched = [c[1].clone() for c in cases]
+    for (d, out, ref, _), got in zip(cases, batched):
+        assert _relerr(got.view(ref.shape).cpu(), ref) < 2e-4
+        out.zero_()
+        _hip.check(L.m3d_head_mlp_forward(d, S._stream()))
+        assert torch.equal(out, got)
+    odd = _head_case(7, 256, 144, 256, dev)
+    bad = (_hip.MlpDesc * 2)(cases[0][0], odd[0])
+    assert L.m3d_head_mlp_forward_batched(bad, 2, S._stream()) != 0
+    assert L.m3d_head_mlp_forward_batched(arr, 17, S._stream()) != 0
 
 
 def test_graph_replay_matches_eager():
