@@ -67,7 +67,7 @@ def kernel_symbol(label):
         return "wino_kernel(WinoArgs)"
     if label.startswith("head_mlp"):
         layers, n3 = re.findall(r"\d+", label)[:2]
-        return "void head_mlp_kernel<%s, %s>(MlpArgs)" % ("true" if layers == "3" else "false", n3)
+        return "void head_mlp_kernel<%s, %s>(MlpBatch)" % ("true" if layers == "3" else "false", n3)
     nums = re.findall(r"\d+", label)[:3]
     wm, wn = (4, 1) if nums[1] == "32" else (2, 2)
     return "void igemm_kernel<%s, %s, %s, %d, %d, %s, %s>(IgemmArgs)" % (

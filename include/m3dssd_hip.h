@@ -92,9 +92,16 @@ typedef struct m3d_conv_desc {
     int sigmoid_from;         /* channels >= this get sigmoid instead of act; <0: none          */
     const float *dcn_offmask; /* NHWC [.., 3*kh*kw]: 2k=dh, 2k+1=dw, 2*kh*kw+k=mask; NULL=plain */
     int dcn_om_cs;
+    float *splitk_ws;         /* optional scratch for split-K (small-M layers); NULL = never split   */
+    long long splitk_ws_bytes;
 } m3d_conv_desc;
 
 int m3d_conv2d_forward(const m3d_conv_desc *d, m3d_stream_t stream);
+/* Split-K plan of m3d_conv2d_forward for this descriptor: *splits (1 = no split) and the scratch bytes
+ * (splits * N*Ho*Wo * Cout_pad * 4) the caller should provide through splitk_ws to enable it.  A layer whose
+ * output tiles cannot give each of the 256 CUs a workgroup is split along K; partial sums are added in split
+ * order by a second launch (deterministic), which also applies the epilogue. */
+int m3d_conv2d_splitk_plan(const m3d_conv_desc *d, int *splits, long long *ws_bytes);
 
 /* Winograd F(2x2,3x3) variant for 3x3 / stride 1 / pad 1 / even H,W plain convolutions (same descriptor; `wgt`
  * must point to the Winograd-transformed weights U = G g G^T packed in fragment order

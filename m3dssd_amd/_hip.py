@@ -31,6 +31,7 @@ class ConvDesc(ctypes.Structure):
         ("res", c_void_p), ("res_cs", c_int), ("res_mode", c_int),
         ("act", c_int), ("sigmoid_from", c_int),
         ("dcn_offmask", c_void_p), ("dcn_om_cs", c_int),
+        ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_ll),
     ]
 
 
@@ -56,6 +57,7 @@ SIGNATURES = {
     "m3d_head_mlp_forward_batched": (c_int, [ctypes.POINTER(MlpDesc), c_int, P]),
     "m3d_wino_conv3x3_forward": (c_int, [ctypes.POINTER(ConvDesc), P]),
     "m3d_conv2d_tile": (c_int, [ctypes.POINTER(ConvDesc)] + [ctypes.POINTER(c_int)] * 4),
+    "m3d_conv2d_splitk_plan": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int), ctypes.POINTER(c_ll)]),
     "m3d_dcn_v2_workspace_bytes": (c_ll, [c_int] * 10),
     "m3d_dcn_v2_forward": (c_int, [P] * 6 + [c_int] * 14 + [P, c_ll, P]),
     "m3d_pack_conv_weight": (c_int, [P, P] + [c_int] * 6 + [P]),

@@ -42,6 +42,11 @@ struct IgemmArgs {
     int tiles_m, tiles_n;
     int act, sigmoid_from, res_mode;
     int ablate;   // diagnostics only (M3D_ABLATE): 1 = no steady-state global loads, 2 = no MFMA, 4 = no LDS refill
+    // split-K (small-M layers that cannot fill 256 CUs): grid = splits x tiles, split s accumulates k-tiles
+    // [s*kt_per, (s+1)*kt_per) and stores raw partial sums to ws[s][M][Cout_pad]; splitk_reduce_kernel adds them in
+    // split order (deterministic) and applies the epilogue.
+    float *ws;
+    int splits, kt_per;
 };
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool DEFORM, bool SWAP>
@@ -74,6 +79,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
+    int split = 0;
+    if (a.splits > 1) {
+        const int ntiles = a.tiles_m * a.tiles_n;
+        split = tile / ntiles;
+        tile -= split * ntiles;
+    }
+    const int kt_begin = split * a.kt_per, kt_end = min(a.KT, kt_begin + a.kt_per);
     const int tile_m = tile / a.tiles_n, tile_n = tile - tile_m * a.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -104,7 +116,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
     f32x4 rb[PB];
 
     // k-tile cursor, advanced incrementally (no integer division in the loop): tiles are loaded in order 0,1,2,...
+    // (a split may start in the middle of a tap: the first load refreshes the per-tap state regardless of cur_c)
     int cur_tap = 0, cur_c = 0, cur_ti = 0, cur_tj = 0;
+    bool tap_fresh = true;
+    if (kt_begin) {
+        const int k0 = kt_begin * BK;
+        cur_tap = k0 / a.Cin;
+        cur_c = k0 - cur_tap * a.Cin;
+        cur_ti = cur_tap / a.kw;
+        cur_tj = cur_tap - cur_ti * a.kw;
+    }
     unsigned aoff[PA];
     bool aok[PA];
     unsigned boff[PB];
@@ -117,7 +138,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
         const int tap = cur_tap;
         const int c0 = cur_c + csub;
         const int ti = cur_ti, tj = cur_tj;
-        const bool first_of_tap = cur_c == 0;
+        const bool first_of_tap = cur_c == 0 || tap_fresh;
+        tap_fresh = false;
         cur_c += BK;
         if (cur_c >= a.Cin) {
             cur_c = 0;
@@ -215,14 +237,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tile(0);
+    load_tile(kt_begin);
     store_tile(0);
     __syncthreads();
 
     const int l31 = lane & 31, lh4 = (lane >> 5) * 4;
-    for (int kt = 0; kt < a.KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < a.KT && !(a.ablate & 1)) load_tile(kt + 1);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end && !(a.ablate & 1)) load_tile(kt + 1);
         const float *Ab = As + buf * BM * LDK + (wm + l31) * LDK + lh4;
         const float *Bb = Bs + buf * BN * LDK + (wn + l31) * LDK + lh4;
         if (!(a.ablate & 2)) {
@@ -260,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
                 __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
             }
         }
-        if (kt + 1 < a.KT && !(a.ablate & 4)) store_tile(buf ^ 1);
+        if (kt + 1 < kt_end && !(a.ablate & 4)) store_tile(buf ^ 1);
         if (!(a.ablate & 4)) __syncthreads();
     }
 
@@ -268,6 +290,21 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
     // D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
     const int hrow = 4 * (lane >> 5);
     if constexpr (!SWAP) {
+        if (a.splits > 1) {               // raw partial sums; the reduce kernel owns the epilogue
+            float *wsp = a.ws + (size_t)split * a.M * a.Cout_pad;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int co = n0 + wn + j * 32 + l31;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + hrow;
+                        if (co < a.Cout_pad && m < a.M) wsp[(size_t)m * a.Cout_pad + co] = acc[i][j][r];
+                    }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int co = n0 + wn + j * 32 + l31;
@@ -323,6 +360,47 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
     }
 }
 
+// Sum the split-K partials in split order and apply the igemm epilogue; one thread per 4 channels of a pixel.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs a, int vec_out)
+{
+    const int c4n = a.Cout_pad >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)a.M * c4n) return;
+    const int m = (int)(i / c4n), co0 = (int)(i - (long long)m * c4n) * 4;
+    if (co0 >= a.Cout) return;
+    const size_t stride = (size_t)a.M * a.Cout_pad;
+    const float *p = a.ws + (size_t)m * a.Cout_pad + co0;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(p);
+    for (int s = 1; s < a.splits; ++s) v = v + *reinterpret_cast<const f32x4 *>(p + s * stride);
+    f32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int co = co0 + q;
+        float x = v[q];
+        if (co < a.Cout) {
+            const float sc = a.scale ? a.scale[co] : 1.f;
+            const float sh = a.shift ? a.shift[co] : 0.f;
+            if (a.res) {
+                const float rv = a.res[(size_t)m * a.res_cs + co];
+                x = a.res_mode ? (x + rv) * sc + sh : x * sc + sh + rv;
+            } else {
+                x = x * sc + sh;
+            }
+            if (a.sigmoid_from >= 0 && co >= a.sigmoid_from) x = sigmoidf_(x);
+            else if (a.act == 1) x = leaky(x);
+        }
+        o[q] = x;
+    }
+    float *op = a.out + (size_t)m * a.out_cs + co0;
+    if (vec_out && co0 + 3 < a.Cout) {
+        *reinterpret_cast<f32x4 *>(op) = o;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (co0 + q < a.Cout) op[q] = o[q];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool DEFORM, bool SWAP>
 static int launch_igemm(const IgemmArgs &a, hipStream_t stream)
@@ -338,12 +416,38 @@ static int launch_igemm(const IgemmArgs &a, hipStream_t stream)
     IgemmArgs b = a;
     b.tiles_m = cdiv(a.M, BM);
     b.tiles_n = cdiv(a.Cout_pad, BN);
-    hipLaunchKernelGGL(kern, dim3(b.tiles_m * b.tiles_n), dim3(256), smem, stream, b);
+    hipLaunchKernelGGL(kern, dim3(b.tiles_m * b.tiles_n * b.splits), dim3(256), smem, stream, b);
     M3D_LAUNCH_CHECK();
+    if (b.splits > 1) {
+        const long long n4 = (long long)b.M * (b.Cout_pad >> 2);
+        const int vec_out = (b.out_cs % 4 == 0) && (((uintptr_t)b.out & 15) == 0);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, b, vec_out);
+        M3D_LAUNCH_CHECK();
+    }
     return M3D_OK;
 }
 
 struct TileChoice { int bm, bn, bk; };
+
+// Split-K factor for a layer whose tile count cannot give every CU a workgroup: as many splits as keep the
+// whole grid co-resident (<= 2 workgroups per CU), at least 8 k-tiles per split.
+static int choose_split(const m3d_conv_desc *d, const TileChoice &t, int *kt_per)
+{
+    const long long M = (long long)d->N * d->Ho * d->Wo;
+    const int KT = d->kh * d->kw * d->Cin / t.bk;
+    *kt_per = KT;
+    static int enabled = -1;                     // tuning knob (experiments only): M3D_SPLITK=0 disables
+    if (enabled < 0) { const char *e = getenv("M3D_SPLITK"); enabled = e ? atoi(e) : 1; }
+    if (!enabled || d->out_nchw || d->wgt_img_stride) return 1;
+    const long long blocks = ((M + t.bm - 1) / t.bm) * ((d->Cout_pad + t.bn - 1) / t.bn);
+    if (blocks > 256) return 1;
+    int s = (int)(512 / blocks);
+    if (s > KT / 8) s = KT / 8;
+    if (s > 16) s = 16;
+    if (s < 2) return 1;
+    *kt_per = (KT + s - 1) / s;
+    return (KT + *kt_per - 1) / *kt_per;
+}
 
 static int choose_tile(const m3d_conv_desc *d, TileChoice *t)
 {
@@ -370,6 +474,17 @@ static int choose_tile(const m3d_conv_desc *d, TileChoice *t)
         if ((d->Ho * d->Wo) % 64 != 0) return -1;
     }
     return 0;
+}
+
+extern "C" int m3d_conv2d_splitk_plan(const m3d_conv_desc *d, int *splits, long long *ws_bytes)
+{
+    TileChoice t;
+    M3D_REQUIRE(d && splits && ws_bytes, "conv2d_splitk_plan: null pointer");
+    M3D_REQUIRE(choose_tile(d, &t) == 0, "per-image weights need Ho*Wo %% 64 == 0");
+    int kt_per;
+    *splits = choose_split(d, t, &kt_per);
+    *ws_bytes = *splits > 1 ? (long long)*splits * d->N * d->Ho * d->Wo * d->Cout_pad * 4 : 0;
+    return M3D_OK;
 }
 
 extern "C" int m3d_conv2d_tile(const m3d_conv_desc *d, int *bm, int *bn, int *bk, int *grid)
@@ -434,6 +549,18 @@ extern "C" int m3d_conv2d_forward(const m3d_conv_desc *d, m3d_stream_t stream_)
         static int abl = -1;
         if (abl < 0) { const char *e = getenv("M3D_ABLATE"); abl = e ? atoi(e) : 0; }
         a.ablate = abl;
+    }
+
+    a.ws = nullptr; a.splits = 1; a.kt_per = a.KT;
+    if (d->splitk_ws) {
+        int kt_per;
+        const int s = choose_split(d, t, &kt_per);
+        if (s > 1) {
+            M3D_REQUIRE((long long)s * M * d->Cout_pad * 4 <= d->splitk_ws_bytes && ((uintptr_t)d->splitk_ws & 15) == 0,
+                        "conv2d: split-K workspace too small (%lld bytes, see m3d_conv2d_splitk_plan) or misaligned",
+                        d->splitk_ws_bytes);
+            a.ws = d->splitk_ws; a.splits = s; a.kt_per = kt_per;
+        }
     }
 
     const bool deform = d->dcn_offmask != nullptr, swap = d->out_nchw != 0;

@@ -110,6 +110,7 @@ def pack_wino(weight, cout_pad, device):
     return u.to(torch.float32).reshape(-1).to(device)
 
 
+WINO_MIN_BLOCKS = int(os.environ.get("M3D_WINO_MIN_BLOCKS", "128"))
 USE_WINO = os.environ.get("M3D_WINO", "1") != "0"
 
 
@@ -302,8 +303,12 @@ class Engine:
             d.dcn_offmask, d.dcn_om_cs = om.ptr, om.cs
         L = self.L
         ref = ctypes.byref(d)
+        # the Winograd kernel works on 256-pixel x 32-channel tiles: a narrow layer (the 27-channel DCN offset/mask
+        # convs) on a small map yields < 128 workgroups and goes to the split-K igemm instead
+        wino_blocks = -(-(x.n * x.h * x.w) // 256) * (d.Cout_pad // 32)
         if (pc is not None and wgt_ptr is None and getattr(pc, "wino", None) is not None and kh == 3 and kw == 3
-                and stride == 1 and pad == 1 and om is None and planar is None and x.h % 2 == 0 and x.w % 2 == 0):
+                and stride == 1 and pad == 1 and om is None and planar is None and x.h % 2 == 0 and x.w % 2 == 0
+                and wino_blocks >= WINO_MIN_BLOCKS):
             # Winograd F(2x2,3x3): 2.25x fewer MFMA FLOPs for the plain 3x3 stride-1 layers
             d.wgt = pc.wino.data_ptr()
             flops = 2.0 * x.n * d.Ho * d.Wo * d.Cout * 9 * pc.cin
@@ -311,8 +316,15 @@ class Engine:
             return
         bm, bn, bk, grid = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         _hip.check(L.m3d_conv2d_tile(ref, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(bk), ctypes.byref(grid)))
-        kind = "igemm<%d,%d,%d%s%s>" % (bm.value, bn.value, bk.value, ",deform" if om is not None else "",
-                                        ",planar" if planar is not None else "")
+        splits, ws_bytes = ctypes.c_int(), ctypes.c_longlong()
+        _hip.check(L.m3d_conv2d_splitk_plan(ref, ctypes.byref(splits), ctypes.byref(ws_bytes)))
+        if splits.value > 1:
+            ws = torch.empty(ws_bytes.value // 4, device=self.device, dtype=torch.float32)
+            plan.keep.append(ws)
+            d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws_bytes.value
+        kind = "igemm<%d,%d,%d%s%s%s>" % (bm.value, bn.value, bk.value, ",deform" if om is not None else "",
+                                          ",planar" if planar is not None else "",
+                                          ",splitk%d" % splits.value if splits.value > 1 else "")
         # algorithmic FLOPs of the layer: 2 * pixels * Cout * taps * Cin (true channel counts, no padding)
         if cin_true is None:
             cin_true = pc.cin if (pc is not None and wgt_ptr is None) else x.c

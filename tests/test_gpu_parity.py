@@ -96,6 +96,50 @@ def test_conv_igemm_matches_torch(case):
         got = S._to_nchw(out, co).cpu()
     assert got.shape == ref.shape
     assert _relerr(got, ref.detach()) < 2e-4
+    with torch.no_grad():                      # small-M cases split along K by default: the unsplit launch must agree
+        out1, keep1 = S.conv_nhwc(v, wt.to(dev), None if b is None else b.to(dev), None if bnm is None else bnm.to(dev),
+                                  stride, pad, act=act, res=rv, splitk=False)
+        one = S._to_nchw(out1, co).cpu()
+    assert _relerr(one, ref.detach()) < 2e-4
+    assert (one - got).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_conv_splitk_plan_and_workspace_check():
+    """m3d_conv2d_splitk_plan: a 512->256 3x3 on a 12x40 map (120 tiles) is split, a 96x320 map is not; a short
+    workspace is refused; the split result is deterministic run to run."""
+    import ctypes
+    from m3dssd_amd import _hip
+    from m3dssd_amd.host import standalone as S
+    dev = _dev()
+    L = _hip.lib()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(8, 512, 12, 40, generator=g).to(dev)
+    wt = (torch.randn(256, 512, 3, 3, generator=g) / 68.0).to(dev)
+    v, _ = S._to_nhwc(x)
+    out_a, ka = S.conv_nhwc(v, wt, None, None, 1, 1, cout_pad_to=64)
+    out_b, kb = S.conv_nhwc(v, wt, None, None, 1, 1, cout_pad_to=64)
+    assert ka[3] is not None, "expected a split-K launch"
+    assert torch.equal(out_a.t, out_b.t)
+    ref = F.conv2d(x, wt, None, padding=1)
+    assert _relerr(S._to_nchw(out_a, 256).cpu(), ref.cpu()) < 2e-4
+    d = _hip.ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.Cout, d.Cout_pad = 8, 96, 320, 64, 64, 64
+    d.kh = d.kw = 3
+    d.stride, d.pad, d.dil, d.Ho, d.Wo = 1, 1, 1, 96, 320
+    splits, nbytes = ctypes.c_int(), ctypes.c_longlong()
+    _hip.check(L.m3d_conv2d_splitk_plan(ctypes.byref(d), ctypes.byref(splits), ctypes.byref(nbytes)))
+    assert splits.value == 1 and nbytes.value == 0
+    d.H, d.W, d.Ho, d.Wo, d.Cin, d.Cout, d.Cout_pad = 12, 40, 12, 40, 512, 256, 256
+    _hip.check(L.m3d_conv2d_splitk_plan(ctypes.byref(d), ctypes.byref(splits), ctypes.byref(nbytes)))
+    assert splits.value >= 2 and nbytes.value == splits.value * 8 * 12 * 40 * 256 * 4
+    wp, co, cop, kh, kw = S._pack(wt, 512, 64)
+    out = torch.empty(8 * 12 * 40 * 256, device=dev)
+    ws = torch.empty(16, device=dev)
+    d.inp, d.in_cs, d.wgt, d.out, d.out_cs = v.ptr, v.cs, wp.data_ptr(), out.data_ptr(), 256
+    d.sigmoid_from = -1
+    d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), 64
+    assert L.m3d_conv2d_forward(ctypes.byref(d), S._stream()) != 0
+    assert b"workspace" in L.m3d_last_error()
 
 
 def test_conv_planar_output_and_sigmoid_channels():
