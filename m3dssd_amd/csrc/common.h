@@ -8,6 +8,43 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- raw buffer access (gfx950) -------------------------------------------------------------------------------
+// A buffer resource makes the address of a load  base(SGPR x4) + voffset(VGPR, 32 bit) + soffset(SGPR): no per-load
+// 64-bit VALU address arithmetic, and a lane whose voffset is >= num_records reads 0.0f -- out-of-image taps cost no
+// v_cndmask.  Every VALU instruction saved matters: on this part a VALU instruction of ANY wave of a SIMD delays that
+// SIMD's MFMA stream by ~8 cycles (tools/ubench/mfma_valu_overlap.hip), i.e. VALU work does not hide under MFMAs.
+#define M3D_BUF_OOB 0x80000000u          // voffset of a masked lane (views are < 2 GiB)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load_f32x4(__amdgpu_buffer_rsrc_t r, unsigned voffset, unsigned soffset)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voffset, soffset, 0));
+}
+// f32x4 add / subtract as two packed v_pk_add_f32.  hipcc scalarises a <4 x float> fsub into four v_sub_f32 (and folds
+// shuffles / fneg back into that fsub), so the subtraction is spelled in asm; it is not volatile: free to schedule.
+__device__ __forceinline__ f32x2 pk_sub2(f32x2 a, f32x2 b)
+{
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b)
+{
+    const f32x2 lo = pk_sub2(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1));
+    const f32x2 hi = pk_sub2(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+__device__ __forceinline__ f32x4 pk_add(f32x4 a, f32x4 b)
+{
+    const f32x2 lo = __builtin_shufflevector(a, a, 0, 1) + __builtin_shufflevector(b, b, 0, 1);
+    const f32x2 hi = __builtin_shufflevector(a, a, 2, 3) + __builtin_shufflevector(b, b, 2, 3);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
 
 #define M3D_LEAKY_SLOPE 0.01f
 

@@ -28,12 +28,24 @@ struct WinoArgs {
     const float *shift;
     const float *res;
     int in_cs, out_cs, res_cs;
+    unsigned in_bytes;       // extent of the input view from `in` (buffer range check)
     int N, H, W, Cin, Cout, Cout_pad;
     int TH, TW, NT;          // tiles per image (rows, cols), total tiles
     int tiles_n;             // Cout_pad / 32
     int act, sigmoid_from, res_mode;
     int ablate;   // diagnostics (M3D_ABLATE): 1 = loader skips steady-state loads, 2 = no MFMA, 4 = loader skips transform+store, 8 = no U loads
+#ifdef WINO_TRACE
+    long long *trace;   // [block][wave][64] s_memtime stamps (diagnostic build only, tools/wino_trace.py)
+#endif
 };
+
+#ifdef WINO_TRACE
+#define TRACE_INIT() long long *trp = a.trace ? a.trace + ((size_t)blockIdx.x * 8 + wave) * 64 : nullptr; int tri = 0
+#define TRACE() do { if (trp && lane == 0 && tri < 64) trp[tri++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TRACE_INIT()
+#define TRACE()
+#endif
 
 #define WINO_T 64            // tiles per workgroup (two 32-row MFMA tiles per compute wave)
 #define WINO_BK 16           // input channels per k-step
@@ -76,6 +88,8 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform -> SGPR, scalar branches
     const int l31 = lane & 31, hrow = 4 * (lane >> 5);
     const bool is_loader = wave >= 4;
+    TRACE_INIT();
+    TRACE();
 
     int tile_blk;
     {
@@ -94,8 +108,8 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
         const int lt = tid - 256;
         const int ltile = lt >> 2, lq = lt & 3;
         const int wq = (lq ^ ((ltile >> 2) & 3)) * 4;
+        // byte offsets of the 4x4 patch; positions outside the image get the out-of-range marker and read as 0.0f
         unsigned poff[16];
-        unsigned pmask = 0;          // bit r*4+c set = position inside the image
         {
             const int t = t0 + ltile;
             const bool tv = t < a.NT;
@@ -108,61 +122,62 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
                 for (int c = 0; c < 4; ++c) {
                     const int hi = 2 * ty - 1 + r, wi = 2 * tx - 1 + c;
                     const bool ok = tv && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-                    const int hc = min(max(hi, 0), a.H - 1), wc = min(max(wi, 0), a.W - 1);
-                    poff[r * 4 + c] = ((unsigned)((n * a.H + hc) * a.W + wc) * (unsigned)a.in_cs + (unsigned)(lq * 4)) * 4u;
-                    if (ok) pmask |= 1u << (r * 4 + c);
+                    poff[r * 4 + c] = ok ? ((unsigned)((n * a.H + hi) * a.W + wi) * (unsigned)a.in_cs + (unsigned)(lq * 4)) * 4u
+                                         : M3D_BUF_OOB;
                 }
         }
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
         // two patches in flight (these waves hold no accumulators, registers are plentiful): the loads of step ks+2
         // and ks+3 are outstanding while step ks computes, so HBM/L2 latency never reaches the barrier
         f32x4 dA[16], dB[16];
         auto load_patch = [&](int ks, f32x4 (&d)[16]) {
-            const char *base = reinterpret_cast<const char *>(a.in + ks * WINO_BK);
+            const unsigned soff = (unsigned)(ks * WINO_BK) * 4u;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) d[i] = *reinterpret_cast<const f32x4 *>(base + poff[i]);
+            for (int i = 0; i < 16; ++i) d[i] = buf_load_f32x4(rin, poff[i], soff);
         };
         auto transform_store = [&](int buf, f32x4 (&d)[16]) {
-            if (pmask != 0xFFFFu) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (!((pmask >> i) & 1u)) d[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {      // V row r: (B^T d)[r] per column, then (.) B along the columns
                 f32x4 t[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    if (r == 0) t[c] = d[0 * 4 + c] - d[2 * 4 + c];
-                    else if (r == 1) t[c] = d[1 * 4 + c] + d[2 * 4 + c];
-                    else if (r == 2) t[c] = d[2 * 4 + c] - d[1 * 4 + c];
-                    else t[c] = d[1 * 4 + c] - d[3 * 4 + c];
+                    if (r == 0) t[c] = pk_sub(d[0 * 4 + c], d[2 * 4 + c]);
+                    else if (r == 1) t[c] = pk_add(d[1 * 4 + c], d[2 * 4 + c]);
+                    else if (r == 2) t[c] = pk_sub(d[2 * 4 + c], d[1 * 4 + c]);
+                    else t[c] = pk_sub(d[1 * 4 + c], d[3 * 4 + c]);
                 }
                 float *vb = smem + buf * WINO_VBUF + ((r * 4) * WINO_T + ltile) * WINO_BK + wq;
-                *reinterpret_cast<f32x4 *>(vb) = t[0] - t[2];
-                *reinterpret_cast<f32x4 *>(vb + 1 * WINO_T * WINO_BK) = t[1] + t[2];
-                *reinterpret_cast<f32x4 *>(vb + 2 * WINO_T * WINO_BK) = t[2] - t[1];
-                *reinterpret_cast<f32x4 *>(vb + 3 * WINO_T * WINO_BK) = t[1] - t[3];
+                *reinterpret_cast<f32x4 *>(vb) = pk_sub(t[0], t[2]);
+                *reinterpret_cast<f32x4 *>(vb + 1 * WINO_T * WINO_BK) = pk_add(t[1], t[2]);
+                *reinterpret_cast<f32x4 *>(vb + 2 * WINO_T * WINO_BK) = pk_sub(t[2], t[1]);
+                *reinterpret_cast<f32x4 *>(vb + 3 * WINO_T * WINO_BK) = pk_sub(t[1], t[3]);
             }
         };
         load_patch(0, dA);
         if (KS > 1) load_patch(1, dB);
         transform_store(0, dA);
         if (KS > 2) load_patch(2, dA);
+        TRACE();
         lds_barrier();                                   // V(0) visible
+        TRACE();
         for (int ks = 0; ks < KS; ks += 2) {
             // step ks: produce V(ks+1) from dB, refill dB with patch ks+3
             if (ks + 1 < KS) {
                 if (!(a.ablate & 4)) transform_store((ks + 1) & 1, dB);   // buffer last read in step ks-1 (barrier passed)
                 if (ks + 3 < KS && !(a.ablate & 1)) load_patch(ks + 3, dB);
             }
+            TRACE();
             lds_barrier();
+            TRACE();
             // step ks+1: produce V(ks+2) from dA, refill dA with patch ks+4
             if (ks + 1 < KS) {
                 if (ks + 2 < KS) {
                     if (!(a.ablate & 4)) transform_store((ks + 2) & 1, dA);
                     if (ks + 4 < KS && !(a.ablate & 1)) load_patch(ks + 4, dA);
                 }
+                TRACE();
                 lds_barrier();
+                TRACE();
             }
         }
     } else {
@@ -173,16 +188,17 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
         f32x4 fbA[4][2], fbB[4][2];
         // U fragment (xi, k-group G) of this cout block sits at ub + xi_local*xstride + G*256 floats (+ lane*4):
         // a uniform SGPR base plus a constant 32-bit lane offset -> one instruction per load, no per-load VALU math
-        const size_t xstride = (size_t)a.tiles_n * kgroups * 256;
+        const unsigned xstride = (unsigned)(a.tiles_n * kgroups) * 1024u;          // bytes between consecutive xi
         const float *ub = a.U + ((size_t)(wave * 4) * a.tiles_n + bn) * kgroups * 256;
-        const unsigned ulane = (unsigned)lane * 16u;
+        const __amdgpu_buffer_rsrc_t ru = make_rsrc(ub, 4u * xstride);
+        unsigned uoff[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) uoff[x] = (unsigned)lane * 16u + x * xstride;
         auto load_u = [&](int ks, f32x4 (&dst)[4][2]) {
 #pragma unroll
             for (int x = 0; x < 4; ++x)
 #pragma unroll
-                for (int g = 0; g < 2; ++g)
-                    dst[x][g] = *reinterpret_cast<const f32x4 *>(
-                        reinterpret_cast<const char *>(ub + x * xstride + (size_t)(ks * 2 + g) * 256) + ulane);
+                for (int g = 0; g < 2; ++g) dst[x][g] = buf_load_f32x4(ru, uoff[x], (unsigned)(ks * 2 + g) * 1024u);
         };
         f32x16 acc[4][2];
 #pragma unroll
@@ -226,17 +242,23 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
         // compiler cannot know how many loads are in flight and emits pessimistic s_waitcnt vmcnt(N) that also wait
         // for the loads just issued -- which serialises the full memory latency into every k-step.
         load_u(0, fbA);
+        TRACE();
         lds_barrier();                                     // V(0) visible
+        TRACE();
         for (int ks = 0; ks < KS; ks += 2) {
             if (!(a.ablate & 8)) load_u(min(ks + 1, KS - 1), fbB);
             __builtin_amdgcn_sched_barrier(0);             // keep the loads ahead of the MFMAs (the scheduler sinks them)
             if (!(a.ablate & 2)) compute(0, fbA);
+            TRACE();
             lds_barrier();
+            TRACE();
             if (ks + 1 < KS) {
                 if (!(a.ablate & 8)) load_u(min(ks + 2, KS - 1), fbA);
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(a.ablate & 2)) compute(1, fbB);
+                TRACE();
                 lds_barrier();
+                TRACE();
             }
         }
         // ---- gather the 16 M[xi] in LDS: M[xi][tile][cout] (the loop ended with a barrier: V is dead) -----------
@@ -249,7 +271,9 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
                 for (int r = 0; r < 16; ++r) mb[((r & 3) + 8 * (r >> 2) + hrow) * WINO_LDM] = acc[x][m][r];
             }
     }
+    TRACE();
     __syncthreads();
+    TRACE();
 
     // ---- A^T M A + epilogue: thread = (tile, cout), all 512 threads -------------------------------------------
     const int co = n0 + (tid & 31);
@@ -295,7 +319,13 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
                 a.out[pix * a.out_cs + co] = v;
             }
     }
+    TRACE();
 }
+
+#ifdef WINO_TRACE
+static long long *g_wino_trace = nullptr;
+extern "C" void m3d_wino_set_trace(void *buf) { g_wino_trace = (long long *)buf; }
+#endif
 
 extern "C" int m3d_wino_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t stream_)
 {
@@ -306,10 +336,12 @@ extern "C" int m3d_wino_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t str
     M3D_REQUIRE(d->H % 2 == 0 && d->W % 2 == 0 && d->Ho == d->H && d->Wo == d->W, "wino: even H and W");
     M3D_REQUIRE(!d->out_nchw && !d->dcn_offmask && !d->wgt_img_stride, "wino: NHWC output, plain conv, shared weights");
     M3D_REQUIRE(d->in_cs % 4 == 0 && ((uintptr_t)d->in & 15) == 0 && ((uintptr_t)d->wgt & 15) == 0, "wino: alignment");
-    M3D_REQUIRE((long long)d->N * d->H * d->W * d->in_cs * 4 < (1ll << 32), "wino: input view must be < 4 GiB");
+    M3D_REQUIRE((long long)d->N * d->H * d->W * d->in_cs * 4 < (1ll << 31), "wino: input view must be < 2 GiB");
+    M3D_REQUIRE((long long)16 * d->Cout_pad * d->Cin * 4 < (1ll << 31), "wino: transformed weights must be < 2 GiB");
     WinoArgs a;
     a.in = d->in; a.U = d->wgt; a.out = d->out; a.scale = d->scale; a.shift = d->shift; a.res = d->res;
     a.in_cs = d->in_cs; a.out_cs = d->out_cs; a.res_cs = d->res_cs;
+    a.in_bytes = (unsigned)((long long)d->N * d->H * d->W * d->in_cs * 4);
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cout_pad = d->Cout_pad;
     a.TH = d->H / 2; a.TW = d->W / 2; a.NT = d->N * a.TH * a.TW; a.tiles_n = d->Cout_pad / 32;
     a.act = d->act; a.sigmoid_from = d->sigmoid_from; a.res_mode = d->res_mode;
@@ -318,6 +350,9 @@ extern "C" int m3d_wino_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t str
         if (abl < 0) { const char *e = getenv("M3D_ABLATE"); abl = e ? atoi(e) : 0; }
         a.ablate = abl;
     }
+#ifdef WINO_TRACE
+    a.trace = g_wino_trace;
+#endif
     constexpr size_t smem = (size_t)16 * WINO_T * WINO_LDM * sizeof(float);   // 135,168 B (>= 2 V buffers: 131,072 B)
     static bool attr_set = false;
     if (!attr_set) {
