@@ -17,6 +17,7 @@
 //   * the 16 accumulated M[xi] meet in LDS, A^T M A + affine/residual/LeakyReLU/sigmoid are applied per (tile, cout)
 //     and written NHWC with lanes along channels.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -29,6 +30,7 @@ struct WinoArgs {
     const float *res;
     int in_cs, out_cs, res_cs;
     unsigned in_bytes;       // extent of the input view from `in` (buffer range check)
+    unsigned out_bytes, res_bytes;
     int N, H, W, Cin, Cout, Cout_pad;
     int TH, TW, NT;          // tiles per image (rows, cols), total tiles
     int tiles_n;             // Cout_pad / 32
@@ -40,8 +42,8 @@ struct WinoArgs {
 };
 
 #ifdef WINO_TRACE
-#define TRACE_INIT() long long *trp = a.trace ? a.trace + ((size_t)blockIdx.x * 8 + wave) * 64 : nullptr; int tri = 0
-#define TRACE() do { if (trp && lane == 0 && tri < 64) trp[tri++] = __builtin_readcyclecounter(); } while (0)
+#define TRACE_INIT() long long *trp = a.trace ? a.trace + ((size_t)blockIdx.x * 8 + wave) * 128 : nullptr; int tri = 0
+#define TRACE() do { if (trp && lane == 0 && tri < 128) trp[tri++] = __builtin_readcyclecounter(); } while (0)
 #else
 #define TRACE_INIT()
 #define TRACE()
@@ -87,7 +89,15 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform -> SGPR, scalar branches
     const int l31 = lane & 31, hrow = 4 * (lane >> 5);
+#ifdef WINO_LOADERS_FIRST
+    const bool is_loader = wave < 4;
+    const int cw = wave - 4;                  // compute-wave index
+    const int lt0 = 0;
+#else
     const bool is_loader = wave >= 4;
+    const int cw = wave;
+    const int lt0 = 256;
+#endif
     TRACE_INIT();
     TRACE();
 
@@ -105,7 +115,8 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
     // padding; the XOR spreads the 16 tiles of a ds_read_b128 lane group over all 64 banks (conflict-free)
     if (is_loader) {
         // ================================ loader / input-transform waves ======================================
-        const int lt = tid - 256;
+        if (a.ablate & 16) __builtin_amdgcn_s_setprio(3);
+        const int lt = tid - lt0;
         const int ltile = lt >> 2, lq = lt & 3;
         const int wq = (lq ^ ((ltile >> 2) & 3)) * 4;
         // byte offsets of the 4x4 patch; positions outside the image get the out-of-range marker and read as 0.0f
@@ -136,6 +147,17 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
             for (int i = 0; i < 16; ++i) d[i] = buf_load_f32x4(rin, poff[i], soff);
         };
         auto transform_store = [&](int buf, f32x4 (&d)[16]) {
+#ifdef WINO_TRACE
+            if (a.ablate & 64) {               // diagnostics: LDS writes only (no transform VALU)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float *vb = smem + buf * WINO_VBUF + ((r * 4) * WINO_T + ltile) * WINO_BK + wq;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4 *>(vb + c * WINO_T * WINO_BK) = d[r * 4 + c];
+                }
+                return;
+            }
+#endif
 #pragma unroll
             for (int r = 0; r < 4; ++r) {      // V row r: (B^T d)[r] per column, then (.) B along the columns
                 f32x4 t[4];
@@ -147,6 +169,12 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
                     else t[c] = pk_sub(d[1 * 4 + c], d[3 * 4 + c]);
                 }
                 float *vb = smem + buf * WINO_VBUF + ((r * 4) * WINO_T + ltile) * WINO_BK + wq;
+#ifdef WINO_TRACE
+                if (a.ablate & 128) {          // diagnostics: transform VALU only (results kept alive, no LDS writes)
+                    asm volatile("" :: "v"(pk_sub(t[0], t[2])), "v"(pk_add(t[1], t[2])), "v"(pk_sub(t[2], t[1])), "v"(pk_sub(t[1], t[3])));
+                    continue;
+                }
+#endif
                 *reinterpret_cast<f32x4 *>(vb) = pk_sub(t[0], t[2]);
                 *reinterpret_cast<f32x4 *>(vb + 1 * WINO_T * WINO_BK) = pk_add(t[1], t[2]);
                 *reinterpret_cast<f32x4 *>(vb + 2 * WINO_T * WINO_BK) = pk_sub(t[2], t[1]);
@@ -164,6 +192,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
             // step ks: produce V(ks+1) from dB, refill dB with patch ks+3
             if (ks + 1 < KS) {
                 if (!(a.ablate & 4)) transform_store((ks + 1) & 1, dB);   // buffer last read in step ks-1 (barrier passed)
+                TRACE();
                 if (ks + 3 < KS && !(a.ablate & 1)) load_patch(ks + 3, dB);
             }
             TRACE();
@@ -173,6 +202,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
             if (ks + 1 < KS) {
                 if (ks + 2 < KS) {
                     if (!(a.ablate & 4)) transform_store((ks + 2) & 1, dA);
+                    TRACE();
                     if (ks + 4 < KS && !(a.ablate & 1)) load_patch(ks + 4, dA);
                 }
                 TRACE();
@@ -182,6 +212,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
         }
     } else {
         // ======================================= compute waves ================================================
+        if (a.ablate & 32) __builtin_amdgcn_s_setprio(3);
         const int kgroups = a.Cin / 8;
         // two U-fragment register sets used alternately (loop unrolled by two, no copies): the loads of step ks+1 are
         // issued before the MFMAs of step ks and only waited for one full step later
@@ -189,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
         // U fragment (xi, k-group G) of this cout block sits at ub + xi_local*xstride + G*256 floats (+ lane*4):
         // a uniform SGPR base plus a constant 32-bit lane offset -> one instruction per load, no per-load VALU math
         const unsigned xstride = (unsigned)(a.tiles_n * kgroups) * 1024u;          // bytes between consecutive xi
-        const float *ub = a.U + ((size_t)(wave * 4) * a.tiles_n + bn) * kgroups * 256;
+        const float *ub = a.U + ((size_t)(cw * 4) * a.tiles_n + bn) * kgroups * 256;
         const __amdgpu_buffer_rsrc_t ru = make_rsrc(ub, 4u * xstride);
         unsigned uoff[4];
 #pragma unroll
@@ -214,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
             // 8 groups (xi x, k-group g) of 8 MFMAs; the V fragments of group i+1 are requested from LDS (hand-counted
             // asm reads) before the MFMAs of group i issue and waited for after them: the single compute wave of a
             // SIMD never stalls on LDS latency
-            const unsigned vbase = lds0 + (unsigned)(buf * WINO_VBUF + (wave * 4 * WINO_T + l31) * WINO_BK) * 4u;
+            const unsigned vbase = lds0 + (unsigned)(buf * WINO_VBUF + (cw * 4 * WINO_T + l31) * WINO_BK) * 4u;
             f32x4 fa[2][2];                                // [parity][m]
             fa[0][0] = lds_read_b128_async(vbase + rq0 * 4);
             fa[0][1] = lds_read_b128_async(vbase + (32 * WINO_BK + rq0) * 4);
@@ -266,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
         for (int x = 0; x < 4; ++x)
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                float *mb = smem + ((size_t)(wave * 4 + x) * WINO_T + m * 32) * WINO_LDM + l31;
+                float *mb = smem + ((size_t)(cw * 4 + x) * WINO_T + m * 32) * WINO_LDM + l31;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mb[((r & 3) + 8 * (r >> 2) + hrow) * WINO_LDM] = acc[x][m][r];
             }
@@ -327,6 +358,222 @@ static long long *g_wino_trace = nullptr;
 extern "C" void m3d_wino_set_trace(void *buf) { g_wino_trace = (long long *)buf; }
 #endif
 
+
+// ======================================================================================================================
+// Register-resident variant: ONE WAVE = 32 tiles x 32 couts x all 16 xi, no LDS, no barriers.
+//
+// Why: on gfx950 nothing a second wave does on a SIMD hides under that SIMD's MFMA stream -- VALU instructions of the
+// partner wave cost the stream ~11 cycles each (tools/ubench/mfma_side_cost.hip) and the s_memtime timeline of the
+// wave-specialised kernel above (tools/wino_trace.py) shows its loader wave finishing exactly when the MFMA burst ends,
+// then a ~900-cycle tail (LDS-write drain, load issue, barrier) per k-step: 6300 cycles per 4096 cycles of MFMA.  With the
+// whole 512-register file (256 VGPR + 256 AGPR) one wave holds the 16 accumulators of a 32x32 tile itself, so
+//   * lane (tile i = lane&31, half h = lane>>5) loads the 4x4 patch of ITS tile for channels 8s+4h..+3 (16 x 16 B),
+//     runs B^T d B on it (64 v_pk_add_f32) and the result IS the A operand of the next 64 MFMAs (k = 8s + 4h + t);
+//   * the B operand is the same fragment-packed U as above, one 16-byte load per xi and k-step, re-issued right after the
+//     MFMAs that consumed the previous one;
+//   * all 16 M[xi] of a (tile, cout) sit in the same lane: A^T M A and the epilogue run in registers.
+// Waves are independent units (grid = tile groups x cout groups, 64 threads each): the hardware balances them per SIMD.
+// Buffer load whose completion is counted BY HAND: hipcc joins the waits of a loop-carried prefetch into one
+// s_waitcnt vmcnt(0) at the loop header, which would expose the latency of the loads issued last.  Issue order per k-step is
+// fixed (16 patch loads, then 4 x 4 U loads), so the counts are static: see the s_waitcnt comments in the loop.
+__device__ __forceinline__ void buf_load_async(f32x4 &dst, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm4(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d)
+{
+    // the registers are operands so that no use of them can be scheduled above the wait
+    if constexpr (N == 28) asm volatile("s_waitcnt vmcnt(28)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
+__global__ __launch_bounds__(64) void wino_wave_kernel(const WinoArgs a)
+{
+    __shared__ __attribute__((aligned(16))) int pixb[32];   // first output pixel of each tile (-1: no such tile)
+    const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+#ifdef WINO_TRACE
+    const int wave = 0;
+#endif
+    TRACE_INIT();
+    TRACE();
+    int blk;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+        blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int bm = blk / a.tiles_n, bn = blk - bm * a.tiles_n;
+    const int t0 = bm * 32, n0 = bn * 32;
+    const int KS = a.Cin / 8;
+
+    unsigned poff[16];
+    {
+        const int t = t0 + l31;
+        const bool tv = t < a.NT;
+        const int tt = tv ? t : 0;
+        const int n = tt / (a.TH * a.TW), rem = tt - n * a.TH * a.TW;
+        const int ty = rem / a.TW, tx = rem - ty * a.TW;
+        if (h == 0) pixb[l31] = tv ? (n * a.H + 2 * ty) * a.W + 2 * tx : -1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int hi = 2 * ty - 1 + r, wi = 2 * tx - 1 + c;
+                const bool ok = tv && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+                poff[r * 4 + c] = ok ? ((unsigned)((n * a.H + hi) * a.W + wi) * (unsigned)a.in_cs + (unsigned)(h * 4)) * 4u
+                                     : M3D_BUF_OOB;
+            }
+    }
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
+    const unsigned xstride = (unsigned)(a.tiles_n * KS) * 1024u;               // bytes between consecutive xi
+    const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.U + (size_t)bn * KS * 256, 16u * xstride);
+    const unsigned ulane = (unsigned)lane * 16u;
+
+    f32x4 d[16], V[16], Uf[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) buf_load_async(d[i], rin, poff[i], 0);
+#pragma unroll
+    for (int x = 0; x < 16; ++x) buf_load_async(Uf[x], ru, ulane, x * xstride);
+    __builtin_amdgcn_sched_barrier(0);        // the accumulators are cleared while the first loads are in flight
+    f32x16 acc[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+    TRACE();
+
+    // One k-step (8 input channels).  LAST = no prefetch: the wait counts change, nothing is left in flight at the end.
+    auto step = [&](int s, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        TRACE();
+        // outstanding, oldest first: patch(s) x16, U(s) x16  ->  the patch has landed when <= 16 remain
+        asm volatile("s_waitcnt vmcnt(16)"
+                     : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]),
+                       "+v"(d[8]), "+v"(d[9]), "+v"(d[10]), "+v"(d[11]), "+v"(d[12]), "+v"(d[13]), "+v"(d[14]), "+v"(d[15]));
+        // ---- B^T d B in registers ------------------------------------------------------------------------------
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            f32x4 t[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (r == 0) t[c] = pk_sub(d[0 * 4 + c], d[2 * 4 + c]);
+                else if (r == 1) t[c] = pk_add(d[1 * 4 + c], d[2 * 4 + c]);
+                else if (r == 2) t[c] = pk_sub(d[2 * 4 + c], d[1 * 4 + c]);
+                else t[c] = pk_sub(d[1 * 4 + c], d[3 * 4 + c]);
+            }
+            V[r * 4 + 0] = pk_sub(t[0], t[2]);
+            V[r * 4 + 1] = pk_add(t[1], t[2]);
+            V[r * 4 + 2] = pk_sub(t[2], t[1]);
+            V[r * 4 + 3] = pk_sub(t[1], t[3]);
+        }
+        if constexpr (!LAST) {
+            const unsigned soff = (unsigned)(s + 1) * 32u;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) buf_load_async(d[i], rin, poff[i], soff);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 64 MFMAs; the U fragment of each xi is re-loaded for the next step as soon as its MFMAs are issued ------
+        const unsigned usn = (unsigned)(s + 1) * 1024u;
+        auto group = [&](auto gtag) {
+            constexpr int g = decltype(gtag)::value;
+            // outstanding: U(s) groups g..3, then (if not LAST) patch(s+1) x16 and U(s+1) groups 0..g-1  = 32
+            if constexpr (!LAST) wait_vm4<28>(Uf[4 * g], Uf[4 * g + 1], Uf[4 * g + 2], Uf[4 * g + 3]);
+            else wait_vm4<12 - 4 * g>(Uf[4 * g], Uf[4 * g + 1], Uf[4 * g + 2], Uf[4 * g + 3]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int x = 4 * g; x < 4 * g + 4; ++x)
+                    acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[x][t], Uf[x][t], acc[x], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!LAST) {
+#pragma unroll
+                for (int x = 4 * g; x < 4 * g + 4; ++x) buf_load_async(Uf[x], ru, ulane, x * xstride + usn);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        group(std::integral_constant<int, 0>{});
+        group(std::integral_constant<int, 1>{});
+        group(std::integral_constant<int, 2>{});
+        group(std::integral_constant<int, 3>{});
+    };
+    for (int s = 0; s + 1 < KS; ++s) step(s, std::false_type{});
+    step(KS - 1, std::true_type{});
+    TRACE();
+
+    // ---- A^T M A + epilogue in registers: lane = cout n0 + l31, tiles t0 + 4h + {0..3, 8..11, 16..19, 24..27} -------------
+    const int co = n0 + l31;
+    const bool cok = co < a.Cout;
+    const float sc = (cok && a.scale) ? a.scale[co] : 1.f;
+    const float sh = (cok && a.shift) ? a.shift[co] : 0.f;
+    const f32x2 sc2 = {sc, sc}, sh2 = {sh, sh};
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out, a.out_bytes);
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res ? a.res : a.out, a.res ? a.res_bytes : 0u);
+    // byte offsets of the four output pixels of a tile relative to its first one ride in the SGPR offset of the store
+    const unsigned ocs4 = (unsigned)a.out_cs * 4u, rcs4 = (unsigned)a.res_cs * 4u;
+    unsigned obase[16];
+    float rv[16][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int4 pb = *reinterpret_cast<const int4 *>(&pixb[4 * h + 8 * q]);
+        const int pbv[4] = {pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool ok = cok && pbv[k] >= 0;
+            obase[4 * q + k] = ok ? ((unsigned)pbv[k] * (unsigned)a.out_cs + (unsigned)co) * 4u : M3D_BUF_OOB;
+            if (a.res) {                       // all residual loads are in flight before the arithmetic starts
+                const unsigned rb = ok ? ((unsigned)pbv[k] * (unsigned)a.res_cs + (unsigned)co) * 4u : M3D_BUF_OOB;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        rv[4 * q + k][i * 2 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            rres, rb, (unsigned)(i * a.W + j) * rcs4, 0));
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {          // two tiles at a time on the packed-fp32 VALU
+        f32x2 m[16];
+#pragma unroll
+        for (int x = 0; x < 16; ++x) m[x] = f32x2{acc[x][r], acc[x][r + 1]};
+        f32x2 s0[4], s1[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            s0[b] = m[0 * 4 + b] + m[1 * 4 + b] + m[2 * 4 + b];
+            s1[b] = pk_sub2(pk_sub2(m[1 * 4 + b], m[2 * 4 + b]), m[3 * 4 + b]);
+        }
+        f32x2 y[4];
+        y[0] = s0[0] + s0[1] + s0[2];
+        y[1] = pk_sub2(pk_sub2(s0[1], s0[2]), s0[3]);
+        y[2] = s1[0] + s1[1] + s1[2];
+        y[3] = pk_sub2(pk_sub2(s1[1], s1[2]), s1[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f32x2 v = y[k];
+            if (a.res) {
+                const f32x2 r2 = {rv[r][k], rv[r + 1][k]};
+                if (a.res_mode) v = __builtin_elementwise_fma(v + r2, sc2, sh2);
+                else v = __builtin_elementwise_fma(v, sc2, sh2) + r2;
+            } else {
+                v = __builtin_elementwise_fma(v, sc2, sh2);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float o = v[e];
+                if (a.act == 1) o = fmaxf(o, o * M3D_LEAKY_SLOPE);    // == leaky(o) for 0 < slope < 1
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rout, obase[r + e],
+                                                      (unsigned)((k >> 1) * a.W + (k & 1)) * ocs4, 0);
+            }
+        }
+    }
+    TRACE();
+}
+
 extern "C" int m3d_wino_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
@@ -342,6 +589,8 @@ extern "C" int m3d_wino_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t str
     a.in = d->in; a.U = d->wgt; a.out = d->out; a.scale = d->scale; a.shift = d->shift; a.res = d->res;
     a.in_cs = d->in_cs; a.out_cs = d->out_cs; a.res_cs = d->res_cs;
     a.in_bytes = (unsigned)((long long)d->N * d->H * d->W * d->in_cs * 4);
+    a.out_bytes = (unsigned)((long long)d->N * d->H * d->W * d->out_cs * 4);
+    a.res_bytes = (unsigned)((long long)d->N * d->H * d->W * d->res_cs * 4);
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.Cout_pad = d->Cout_pad;
     a.TH = d->H / 2; a.TW = d->W / 2; a.NT = d->N * a.TH * a.TW; a.tiles_n = d->Cout_pad / 32;
     a.act = d->act; a.sigmoid_from = d->sigmoid_from; a.res_mode = d->res_mode;
@@ -359,6 +608,19 @@ extern "C" int m3d_wino_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t str
         M3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)smem));
         attr_set = true;
+    }
+    static int wave_min = -1;                   // tuning knob (experiments only): M3D_WINO_WAVE_MIN
+    if (wave_min < 0) { const char *e = getenv("M3D_WINO_WAVE_MIN"); wave_min = e ? atoi(e) : 800; }
+    static int variant = -1;                    // tuning knob (experiments only): M3D_WINO_VARIANT=0 selects the LDS kernel
+    if (variant < 0) { const char *e = getenv("M3D_WINO_VARIANT"); variant = e ? atoi(e) : 1; }
+    // the register-resident kernel needs enough waves for the 1024 SIMDs and has no sigmoid epilogue
+    if (variant == 1 && d->sigmoid_from < 0 && (long long)cdiv(a.NT, 32) * a.tiles_n >= wave_min) {
+        M3D_REQUIRE((long long)d->N * d->H * d->W * d->out_cs * 4 < (1ll << 31) &&
+                    (long long)d->N * d->H * d->W * d->res_cs * 4 < (1ll << 31), "wino: output / residual views must be < 2 GiB");
+        M3D_REQUIRE(d->Cin % 8 == 0, "wino: Cin %% 8");
+        hipLaunchKernelGGL(wino_wave_kernel, dim3(cdiv(a.NT, 32) * a.tiles_n), dim3(64), 0, stream, a);
+        M3D_LAUNCH_CHECK();
+        return M3D_OK;
     }
     const int grid = cdiv(a.NT, WINO_T) * a.tiles_n;
     hipLaunchKernelGGL(wino_kernel, dim3(grid), dim3(512), smem, stream, a);

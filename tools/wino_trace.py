@@ -1,6 +1,7 @@
 """In-kernel timeline of the Winograd kernel (diagnostic build -DWINO_TRACE, see csrc/wino_conv.hip):
 python tools/wino_trace.py [Cin] [H] [W] [B]   -> per-wave s_memtime stamps of a first-round and a last-round block."""
 import ctypes
+import os
 import sys
 
 import numpy as np
@@ -29,8 +30,11 @@ d.wgt, d.Cout, d.Cout_pad = U.data_ptr(), cout, cout
 d.kh = d.kw = 3
 d.stride, d.pad, d.dil, d.Ho, d.Wo = 1, 1, 1, H, W
 d.out, d.out_cs, d.act, d.sigmoid_from = out.data_ptr(), cout, 1, -1
-grid = -(-(B * H * W // 4) // 64) * (cout // 32)
-trace = torch.zeros(grid * 8 * 64, dtype=torch.int64, device=dev)
+if os.environ.get("RES"):
+    d.res, d.res_cs = x.data_ptr(), cin
+variant = int(os.environ.get('M3D_WINO_VARIANT', '1'))
+grid = -(-(B * H * W // 4) // (32 if variant == 1 else 64)) * (cout // 32)
+trace = torch.zeros(grid * 8 * 128, dtype=torch.int64, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
     assert L.m3d_wino_conv3x3_forward(ctypes.byref(d), st) == 0
@@ -42,7 +46,7 @@ assert L.m3d_wino_conv3x3_forward(ctypes.byref(d), st) == 0
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
-t = trace.cpu().numpy().reshape(grid, 8, 64)
+t = trace.cpu().numpy().reshape(grid, 8, 128)
 start = t[:, :, 0][t[:, :, 0] > 0].min()
 end = t.max()
 print("grid %d blocks, launch %.4f ms, stamps span %d ticks (%.1f ticks/us)" % (grid, ms, end - start, (end - start) / (ms * 1e3)))
@@ -53,7 +57,7 @@ bend = t.max(axis=(1, 2)) - start
 print("block durations: min %d median %d max %d" % ((bend - bstart).min(), int(np.median(bend - bstart)), (bend - bstart).max()))
 for blk in (int(order[0]), int(order[-1])):
     print("---- block %d (start %d)" % (blk, bstart[blk]))
-    for wv in (0, 4):
+    for wv in ((0,) if variant == 1 else (0, 4)):
         s = t[blk, wv]
         s = s[s > 0] - t[blk, 0, 0]
         print("wave %d: %d stamps" % (wv, len(s)))
