@@ -39,6 +39,20 @@ __device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b)
     const f32x2 hi = pk_sub2(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
+// scalar * f32x4 (+ f32x4) as two packed ops
+__device__ __forceinline__ f32x4 pk_mul_s(float w, f32x4 x)
+{
+    const f32x2 w2 = {w, w};
+    const f32x2 lo = w2 * __builtin_shufflevector(x, x, 0, 1), hi = w2 * __builtin_shufflevector(x, x, 2, 3);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+__device__ __forceinline__ f32x4 pk_fma_s(float w, f32x4 x, f32x4 c)
+{
+    const f32x2 w2 = {w, w};
+    const f32x2 lo = __builtin_elementwise_fma(w2, __builtin_shufflevector(x, x, 0, 1), __builtin_shufflevector(c, c, 0, 1));
+    const f32x2 hi = __builtin_elementwise_fma(w2, __builtin_shufflevector(x, x, 2, 3), __builtin_shufflevector(c, c, 2, 3));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
 __device__ __forceinline__ f32x4 pk_add(f32x4 a, f32x4 b)
 {
     const f32x2 lo = __builtin_shufflevector(a, a, 0, 1) + __builtin_shufflevector(b, b, 0, 1);

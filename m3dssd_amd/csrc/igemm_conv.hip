@@ -47,6 +47,7 @@ struct IgemmArgs {
     // split order (deterministic) and applies the epilogue.
     float *ws;
     int splits, kt_per;
+    unsigned in_bytes, wgt_bytes;   // extents for the buffer-addressed loads (range check: masked lanes read 0.0f)
 };
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool DEFORM, bool SWAP>
@@ -91,6 +92,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
 
     const float *__restrict__ wgt = a.wgt;
     if (a.wgt_img_stride) wgt += (long long)(m0 / a.HoWo) * a.wgt_img_stride;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
+    const __amdgpu_buffer_rsrc_t rwgt = make_rsrc(wgt, a.wgt_bytes);
 
     // ---- per-thread A rows -------------------------------------------------------------
     const int rsub = tid / TPR;            // row within a pass
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
         wi0[p] = wo * a.stride - a.pad;
     }
     // deformable: bilinear state of the current tap
-    float bw[DEFORM ? PA : 1][4], bmask[DEFORM ? PA : 1];
+    float bw[DEFORM ? PA : 1][4];
     unsigned doff[DEFORM ? PA : 1][4];   // byte offsets of the 4 corners (pixel + channel sub-offset)
 
     f32x4 ra[PA][DEFORM ? 4 : 1];
@@ -127,7 +130,6 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
         cur_tj = cur_tap - cur_ti * a.kw;
     }
     unsigned aoff[PA];
-    bool aok[PA];
     unsigned boff[PB];
 #pragma unroll
     for (int p = 0; p < PB; ++p)   // rows past Cout_pad are clamped (their products land in never-stored channels)
@@ -147,21 +149,20 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
             if (++cur_tj == a.kw) { cur_tj = 0; ++cur_ti; }
         }
         if constexpr (!DEFORM) {
-            // addresses = uniform base (SGPR pair, advanced by BK floats per k-tile) + a 32-bit per-thread byte offset
-            // that only changes when the tap changes -> no per-load 64-bit VALU address math; padding taps read a
-            // clamped in-image address and are zeroed when the tile is written to LDS
+            // buffer addressing: resource (SGPR x4) + per-thread 32-bit byte offset that only changes with the tap + SGPR
+            // channel offset -> no per-load VALU address math; padding taps carry the out-of-range offset and read 0.0f
             if (first_of_tap) {
 #pragma unroll
                 for (int p = 0; p < PA; ++p) {
                     const int hi = hi0[p] + ti * a.dil, wi = wi0[p] + tj * a.dil;
-                    aok[p] = rvalid[p] && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-                    const int hc = min(max(hi, 0), a.H - 1), wc = min(max(wi, 0), a.W - 1);
-                    aoff[p] = ((unsigned)(pix_base[p] + hc * a.W + wc) * (unsigned)a.in_cs + (unsigned)csub) * 4u;
+                    const bool ok = rvalid[p] && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+                    aoff[p] = ok ? ((unsigned)(pix_base[p] + hi * a.W + wi) * (unsigned)a.in_cs + (unsigned)csub) * 4u
+                                 : M3D_BUF_OOB;
                 }
             }
-            const char *abase = reinterpret_cast<const char *>(a.in + (c0 - csub));
+            const unsigned asoff = (unsigned)(c0 - csub) * 4u;
 #pragma unroll
-            for (int p = 0; p < PA; ++p) ra[p][0] = *reinterpret_cast<const f32x4 *>(abase + aoff[p]);
+            for (int p = 0; p < PA; ++p) ra[p][0] = buf_load_f32x4(rin, aoff[p], asoff);
         } else {
             if (first_of_tap) {   // first k-tile of a tap: refresh the sampling state
                 const int KK = a.kh * a.kw;
@@ -186,24 +187,24 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
                             if (hh <= a.H - 1 && wh <= a.W - 1) { w4 = lh * lw; o4 = hh * a.W + wh; }
                         }
                     }
-                    bw[p][0] = w1; bw[p][1] = w2; bw[p][2] = w3; bw[p][3] = w4;
+                    // the modulation mask is folded into the corner weights once per tap (dcn_v2_im2col_cuda.cu:174)
+                    bw[p][0] = w1 * mk; bw[p][1] = w2 * mk; bw[p][2] = w3 * mk; bw[p][3] = w4 * mk;
                     doff[p][0] = ((unsigned)(pix_base[p] + o1) * (unsigned)a.in_cs + (unsigned)csub) * 4u;
                     doff[p][1] = ((unsigned)(pix_base[p] + o2) * (unsigned)a.in_cs + (unsigned)csub) * 4u;
                     doff[p][2] = ((unsigned)(pix_base[p] + o3) * (unsigned)a.in_cs + (unsigned)csub) * 4u;
                     doff[p][3] = ((unsigned)(pix_base[p] + o4) * (unsigned)a.in_cs + (unsigned)csub) * 4u;
-                    bmask[p] = mk;
                 }
             }
-            const char *dbase = reinterpret_cast<const char *>(a.in + (c0 - csub));
+            const unsigned dsoff = (unsigned)(c0 - csub) * 4u;
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) ra[p][q] = *reinterpret_cast<const f32x4 *>(dbase + doff[p][q]);
+                for (int q = 0; q < 4; ++q) ra[p][q] = buf_load_f32x4(rin, doff[p][q], dsoff);
             }
         }
-        const char *bbase = reinterpret_cast<const char *>(wgt + k0);
+        const unsigned bsoff = (unsigned)k0 * 4u;
 #pragma unroll
-        for (int p = 0; p < PB; ++p) rb[p] = *reinterpret_cast<const f32x4 *>(bbase + boff[p]);
+        for (int p = 0; p < PB; ++p) rb[p] = buf_load_f32x4(rwgt, boff[p], bsoff);
     };
 
     auto store_tile = [&](int buf) {
@@ -214,11 +215,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
             f32x4 v;
             if constexpr (!DEFORM) {
                 v = ra[p][0];
-                if (!aok[p]) v = f32x4{0.f, 0.f, 0.f, 0.f};
             } else {
-                // (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask   -- dcn_v2_im2col_cuda.cu:44-46,174
-                v = bw[p][0] * ra[p][0] + bw[p][1] * ra[p][1] + bw[p][2] * ra[p][2] + bw[p][3] * ra[p][3];
-                v = v * bmask[p];
+                // (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask   -- dcn_v2_im2col_cuda.cu:44-46,174 -- as 8 packed-fp32 VALU ops
+                v = pk_fma_s(bw[p][0], ra[p][0], pk_fma_s(bw[p][1], ra[p][1], pk_fma_s(bw[p][2], ra[p][2], pk_mul_s(bw[p][3], ra[p][3]))));
             }
             *reinterpret_cast<f32x4 *>(Ab + (p * RPP + rsub) * LDK + csub) = v;
         }
@@ -525,8 +524,8 @@ extern "C" int m3d_conv2d_forward(const m3d_conv_desc *d, m3d_stream_t stream_)
     M3D_REQUIRE(ho == d->Ho && wo == d->Wo, "conv2d: Ho/Wo mismatch (%d,%d) vs (%d,%d)", d->Ho, d->Wo, ho, wo);
     const long long M = (long long)d->N * d->Ho * d->Wo;
     M3D_REQUIRE(M > 0 && M < (1ll << 31) / 4, "conv2d: M out of range");
-    M3D_REQUIRE((long long)d->N * d->H * d->W * d->in_cs * 4 < (1ll << 32), "conv2d: input view must be < 4 GiB (32-bit offsets)");
-    M3D_REQUIRE((long long)d->Cout_pad * d->kh * d->kw * d->Cin * 4 < (1ll << 32), "conv2d: weights must be < 4 GiB");
+    M3D_REQUIRE((long long)d->N * d->H * d->W * d->in_cs * 4 < (1ll << 31), "conv2d: input view must be < 2 GiB (buffer offsets)");
+    M3D_REQUIRE((long long)d->Cout_pad * d->kh * d->kw * d->Cin * 4 < (1ll << 31), "conv2d: weights must be < 2 GiB");
     if (d->dcn_offmask) M3D_REQUIRE(!d->out_nchw && d->Cout_pad % 64 == 0, "deformable conv: NHWC out, Cout_pad %% 64");
     if (d->out_nchw) M3D_REQUIRE(!d->res, "planar output does not take a residual");
 
@@ -552,6 +551,8 @@ extern "C" int m3d_conv2d_forward(const m3d_conv_desc *d, m3d_stream_t stream_)
     }
 
     a.ws = nullptr; a.splits = 1; a.kt_per = a.KT;
+    a.in_bytes = (unsigned)((long long)d->N * d->H * d->W * d->in_cs * 4);
+    a.wgt_bytes = (unsigned)((long long)d->Cout_pad * d->kh * d->kw * d->Cin * 4);
     if (d->splitk_ws) {
         int kt_per;
         const int s = choose_split(d, t, &kt_per);

@@ -79,9 +79,19 @@ class PackedConv:
             scale = s
         self.scale, self.shift = scale.contiguous(), shift.contiguous()
         self.has_affine = (bias is not None) or (bn is not None)
+        self._eng_device = eng.device
+        self._frag = None
         self.wino = None
         if USE_WINO and self.kh == 3 and self.kw == 3 and self.cin_pad == self.cin and self.cin % 16 == 0 and self.cin >= 32:
             self.wino = pack_wino(w, self.cout_pad, eng.device)
+
+
+    def frag(self):
+        """The packed [Cout_pad, kh*kw*Cin_pad] matrix in MFMA-fragment order (m3d_dcn_wave_forward), built on demand."""
+        if self._frag is None:
+            k = self.kh * self.kw * self.cin_pad
+            self._frag = pack_frag(self.wp.view(self.cout_pad, k), self.cout_pad, self._eng_device)
+        return self._frag
 
 
 def pack_frag(weight2d, rows_pad, device):
@@ -111,6 +121,7 @@ def pack_wino(weight, cout_pad, device):
 
 
 WINO_MIN_BLOCKS = int(os.environ.get("M3D_WINO_MIN_BLOCKS", "128"))
+USE_DCN_WAVE = os.environ.get("M3D_DCN_WAVE", "0") != "0"   # experimental: see csrc/dcn_wave.hip
 USE_WINO = os.environ.get("M3D_WINO", "1") != "0"
 
 
@@ -313,6 +324,14 @@ class Engine:
             d.wgt = pc.wino.data_ptr()
             flops = 2.0 * x.n * d.Ho * d.Wo * d.Cout * 9 * pc.cin
             plan.ops.append((name, "wino<64,32,16>", flops, lambda st: _hip.check(L.m3d_wino_conv3x3_forward(ref, st)), d))
+            return
+        flops_true = 2.0 * x.n * d.Ho * d.Wo * d.Cout * kh * kw * (
+            cin_true if cin_true is not None else (pc.cin if (pc is not None and wgt_ptr is None) else x.c))
+        if om is not None and pc is not None and wgt_ptr is None and USE_DCN_WAVE and L.m3d_dcn_wave_applicable(ref) > 0:
+            # enough independent waves to fill the 1024 SIMDs: register-resident deformable conv (csrc/dcn_wave.hip)
+            frag = pc.frag()
+            d.wgt = frag.data_ptr()
+            plan.ops.append((name, "dcn_wave", flops_true, lambda st: _hip.check(L.m3d_dcn_wave_forward(ref, st)), d))
             return
         bm, bn, bk, grid = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         _hip.check(L.m3d_conv2d_tile(ref, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(bk), ctypes.byref(grid)))
