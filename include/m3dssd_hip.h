@@ -103,13 +103,14 @@ int m3d_conv2d_forward(const m3d_conv_desc *d, m3d_stream_t stream);
  * order by a second launch (deterministic), which also applies the epilogue. */
 int m3d_conv2d_splitk_plan(const m3d_conv_desc *d, int *splits, long long *ws_bytes);
 
-/* Register-resident deformable convolution (csrc/dcn_wave.hip): same descriptor as m3d_conv2d_forward with dcn_offmask
- * set, except that `wgt` is the packed [Cout_pad, kh*kw*Cin] matrix in MFMA-fragment order
- * [Cout_pad/32][kh*kw*Cin/8][h=2][r=32][t=4].  Each wave owns 32 or 64 pixels x 128 channels; m3d_dcn_wave_applicable
- * returns the number of waves the layer yields (0: not applicable -- Cin % 32, Cout_pad % 128, NHWC output, no sigmoid,
- * and enough waves to fill the chip), in which case the caller stays on m3d_conv2d_forward. */
-int m3d_dcn_wave_applicable(const m3d_conv_desc *d);
-int m3d_dcn_wave_forward(const m3d_conv_desc *d, m3d_stream_t stream);
+/* Wave-granular convolution / deformable convolution (csrc/dcn_wave.hip): same descriptor as m3d_conv2d_forward
+ * (dcn_offmask optional), except that `wgt` is the packed [Cout_pad, kh*kw*Cin] matrix in MFMA-fragment order
+ * [Cout_pad/32][kh*kw*Cin/8][h=2][r=32][t=4].  Each wave owns 32 pixels x 128 channels and works alone (no workgroup
+ * barrier).  m3d_conv_wave_applicable returns the number of waves the layer yields, or 0 when it does not apply
+ * (needs Cin % 32 == 0, in_cs % 32 == 0, 128-byte aligned input, Cout_pad % 128 == 0, NHWC output, shared weights,
+ * no sigmoid channels) or when there are too few waves to fill the chip; the caller then stays on m3d_conv2d_forward. */
+int m3d_conv_wave_applicable(const m3d_conv_desc *d);
+int m3d_conv_wave_forward(const m3d_conv_desc *d, m3d_stream_t stream);
 
 /* Winograd F(2x2,3x3) variant for 3x3 / stride 1 / pad 1 / even H,W plain convolutions (same descriptor; `wgt`
  * must point to the Winograd-transformed weights U = G g G^T packed in fragment order

@@ -56,8 +56,8 @@ SIGNATURES = {
     "m3d_head_mlp_forward": (c_int, [ctypes.POINTER(MlpDesc), P]),
     "m3d_head_mlp_forward_batched": (c_int, [ctypes.POINTER(MlpDesc), c_int, P]),
     "m3d_wino_conv3x3_forward": (c_int, [ctypes.POINTER(ConvDesc), P]),
-    "m3d_dcn_wave_applicable": (c_int, [ctypes.POINTER(ConvDesc)]),
-    "m3d_dcn_wave_forward": (c_int, [ctypes.POINTER(ConvDesc), P]),
+    "m3d_conv_wave_applicable": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "m3d_conv_wave_forward": (c_int, [ctypes.POINTER(ConvDesc), P]),
     "m3d_conv2d_tile": (c_int, [ctypes.POINTER(ConvDesc)] + [ctypes.POINTER(c_int)] * 4),
     "m3d_conv2d_splitk_plan": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int), ctypes.POINTER(c_ll)]),
     "m3d_dcn_v2_workspace_bytes": (c_ll, [c_int] * 10),

@@ -48,7 +48,20 @@ struct IgemmArgs {
     float *ws;
     int splits, kt_per;
     unsigned in_bytes, wgt_bytes;   // extents for the buffer-addressed loads (range check: masked lanes read 0.0f)
+#ifdef IGEMM_TRACE
+    long long *trace;   // [block][wave][128] s_memtime stamps (diagnostic build only, tools/igemm_trace.py)
+#endif
 };
+
+#ifdef IGEMM_TRACE
+#define TRACE_INIT() long long *trp = a.trace ? a.trace + ((size_t)blockIdx.x * 4 + wave) * 128 : nullptr; int tri = 0
+#define TRACE() do { if (trp && lane == 0 && tri < 128) trp[tri++] = __builtin_readcyclecounter(); } while (0)
+static long long *g_igemm_trace = nullptr;
+extern "C" void m3d_igemm_set_trace(void *buf) { g_igemm_trace = (long long *)buf; }
+#else
+#define TRACE_INIT()
+#define TRACE()
+#endif
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool DEFORM, bool SWAP>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
@@ -72,6 +85,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
     const int wave = tid >> 6;
     const int wm = (wave / WAVES_N) * (TM * 32);
     const int wn = (wave % WAVES_N) * (TN * 32);
+    TRACE_INIT();
+    TRACE();
 
     // XCD-aware tile id: block b runs on XCD b%8; give each XCD a contiguous tile range.
     int tile;
@@ -238,12 +253,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
 
     load_tile(kt_begin);
     store_tile(0);
+    TRACE();
     __syncthreads();
+    TRACE();
 
     const int l31 = lane & 31, lh4 = (lane >> 5) * 4;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int buf = (kt - kt_begin) & 1;
         if (kt + 1 < kt_end && !(a.ablate & 1)) load_tile(kt + 1);
+        TRACE();
         const float *Ab = As + buf * BM * LDK + (wm + l31) * LDK + lh4;
         const float *Bb = Bs + buf * BN * LDK + (wn + l31) * LDK + lh4;
         if (!(a.ablate & 2)) {
@@ -281,8 +299,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
                 __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
             }
         }
+        TRACE();
         if (kt + 1 < kt_end && !(a.ablate & 4)) store_tile(buf ^ 1);
+        TRACE();
         if (!(a.ablate & 4)) __syncthreads();
+        TRACE();
     }
 
     // ---- epilogue ----------------------------------------------------------------------
@@ -551,6 +572,9 @@ extern "C" int m3d_conv2d_forward(const m3d_conv_desc *d, m3d_stream_t stream_)
     }
 
     a.ws = nullptr; a.splits = 1; a.kt_per = a.KT;
+#ifdef IGEMM_TRACE
+    a.trace = g_igemm_trace;
+#endif
     a.in_bytes = (unsigned)((long long)d->N * d->H * d->W * d->in_cs * 4);
     a.wgt_bytes = (unsigned)((long long)d->Cout_pad * d->kh * d->kw * d->Cin * 4);
     if (d->splitk_ws) {

@@ -87,7 +87,7 @@ class PackedConv:
 
 
     def frag(self):
-        """The packed [Cout_pad, kh*kw*Cin_pad] matrix in MFMA-fragment order (m3d_dcn_wave_forward), built on demand."""
+        """The packed [Cout_pad, kh*kw*Cin_pad] matrix in MFMA-fragment order (m3d_conv_wave_forward), built on demand."""
         if self._frag is None:
             k = self.kh * self.kw * self.cin_pad
             self._frag = pack_frag(self.wp.view(self.cout_pad, k), self.cout_pad, self._eng_device)
@@ -121,7 +121,8 @@ def pack_wino(weight, cout_pad, device):
 
 
 WINO_MIN_BLOCKS = int(os.environ.get("M3D_WINO_MIN_BLOCKS", "128"))
-USE_DCN_WAVE = os.environ.get("M3D_DCN_WAVE", "0") != "0"   # experimental: see csrc/dcn_wave.hip
+USE_DCN_WAVE = os.environ.get("M3D_DCN_WAVE", "1") != "0"
+USE_CONV_WAVE = os.environ.get("M3D_CONV_WAVE", "1") != "0"
 USE_WINO = os.environ.get("M3D_WINO", "1") != "0"
 
 
@@ -327,11 +328,13 @@ class Engine:
             return
         flops_true = 2.0 * x.n * d.Ho * d.Wo * d.Cout * kh * kw * (
             cin_true if cin_true is not None else (pc.cin if (pc is not None and wgt_ptr is None) else x.c))
-        if om is not None and pc is not None and wgt_ptr is None and USE_DCN_WAVE and L.m3d_dcn_wave_applicable(ref) > 0:
-            # enough independent waves to fill the 1024 SIMDs: register-resident deformable conv (csrc/dcn_wave.hip)
+        if (pc is not None and wgt_ptr is None and planar is None and (USE_DCN_WAVE if om is not None else USE_CONV_WAVE)
+                and x.cs % 32 == 0 and x.ptr % 128 == 0 and pc.cin_pad == x.c and L.m3d_conv_wave_applicable(ref) > 0):
+            # enough independent waves to fill the SIMDs: wave-granular kernel, no workgroup barriers (csrc/dcn_wave.hip)
             frag = pc.frag()
             d.wgt = frag.data_ptr()
-            plan.ops.append((name, "dcn_wave", flops_true, lambda st: _hip.check(L.m3d_dcn_wave_forward(ref, st)), d))
+            plan.ops.append((name, "conv_wave<deform>" if om is not None else "conv_wave", flops_true,
+                             lambda st: _hip.check(L.m3d_conv_wave_forward(ref, st)), d))
             return
         bm, bn, bk, grid = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         _hip.check(L.m3d_conv2d_tile(ref, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(bk), ctypes.byref(grid)))

@@ -466,7 +466,7 @@ def test_dlaseg_standalone_matches_oracle():
 @pytest.mark.parametrize("shape", [(2, 32, 9, 13, 128, 3, 1, 1), (1, 64, 40, 52, 128, 3, 1, 1), (2, 128, 16, 24, 256, 1, 1, 0),
                                    (1, 48, 11, 7, 100, 3, 2, 1)])
 def test_dcn_wave_kernel_matches_block_kernel_and_oracle(shape):
-    """m3d_dcn_wave_forward (register-resident, one wave per 32/64 px x 128 ch) vs the LDS-tiled igemm on the same
+    """m3d_conv_wave_forward (register-resident, one wave per 32/64 px x 128 ch) vs the LDS-tiled igemm on the same
     descriptor, and vs the oracle im2col + GEMM: ragged M, borders, stride 2, channel padding, fused epilogue."""
     import ctypes
     from m3dssd_amd import _hip
@@ -503,12 +503,12 @@ def test_dcn_wave_kernel_matches_block_kernel_and_oracle(shape):
     d.out, d.out_cs, d.scale, d.shift = out.data_ptr(), co, sc.data_ptr(), sh.data_ptr()
     d.res, d.res_cs, d.res_mode, d.act, d.sigmoid_from = rv.ptr, rv.cs, 0, 1, -1
     d.dcn_offmask, d.dcn_om_cs = om.ptr, om.cs
-    _hip.check(L.m3d_dcn_wave_forward(ctypes.byref(d), S._stream()))
+    _hip.check(L.m3d_conv_wave_forward(ctypes.byref(d), S._stream()))
     got = out.view(n, ho, wo, co).permute(0, 3, 1, 2).cpu()
     assert _relerr(got, want) < 2e-4
     assert (got - blk).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
     d.sigmoid_from = 3                                   # not supported here: refused, the caller stays on the igemm
-    assert L.m3d_dcn_wave_applicable(ctypes.byref(d)) == 0 and L.m3d_dcn_wave_forward(ctypes.byref(d), S._stream()) != 0
+    assert L.m3d_conv_wave_applicable(ctypes.byref(d)) == 0 and L.m3d_conv_wave_forward(ctypes.byref(d), S._stream()) != 0
 
 
 # ------------------------------------------------------------------------------------ fused head + graph
