@@ -116,6 +116,10 @@ int m3d_conv_wave_forward(const m3d_conv_desc *d, m3d_stream_t stream);
  * must point to the Winograd-transformed weights U = G g G^T packed in fragment order
  * [16 xi][Cout_pad/32][Cin/8][64][4], see m3dssd_amd/engine.py:pack_wino).  2.25x fewer MFMA FLOPs, fp32. */
 int m3d_wino_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t stream);
+/* Which kernel m3d_wino_conv3x3_forward runs for this descriptor: 1 = register-resident one-wave kernel (32 tiles x 32
+ * channels x 16 transform positions in 512 registers, no LDS), 0 = LDS kernel (64 tiles x 32 channels per 512-thread
+ * workgroup) -- chosen when the layer yields too few waves for the 1024 SIMDs or needs the sigmoid epilogue. */
+int m3d_wino_conv3x3_variant(const m3d_conv_desc *d);
 
 /* Average launch geometry chosen for a descriptor (for roofline bookkeeping / tests). */
 int m3d_conv2d_tile(const m3d_conv_desc *d, int *bm, int *bn, int *bk, int *grid);

@@ -574,6 +574,19 @@ __global__ __launch_bounds__(64) void wino_wave_kernel(const WinoArgs a)
     TRACE();
 }
 
+// 1: register-resident wave kernel, 0: LDS kernel.  The wave kernel needs enough waves for the 1024 SIMDs and has no sigmoid
+// epilogue.  Tuning knobs (experiments only): M3D_WINO_VARIANT=0 forces the LDS kernel, M3D_WINO_WAVE_MIN the wave threshold.
+static bool wino_use_wave_kernel(const m3d_conv_desc *d)
+{
+    static int wave_min = -1, variant = -1;
+    if (wave_min < 0) { const char *e = getenv("M3D_WINO_WAVE_MIN"); wave_min = e ? atoi(e) : 800; }
+    if (variant < 0) { const char *e = getenv("M3D_WINO_VARIANT"); variant = e ? atoi(e) : 1; }
+    const long long nt = (long long)d->N * (d->H / 2) * (d->W / 2);
+    return variant == 1 && d->sigmoid_from < 0 && ((nt + 31) / 32) * (d->Cout_pad / 32) >= wave_min;
+}
+
+extern "C" int m3d_wino_conv3x3_variant(const m3d_conv_desc *d) { return d && wino_use_wave_kernel(d) ? 1 : 0; }
+
 extern "C" int m3d_wino_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
@@ -609,12 +622,7 @@ extern "C" int m3d_wino_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t str
                                     (int)smem));
         attr_set = true;
     }
-    static int wave_min = -1;                   // tuning knob (experiments only): M3D_WINO_WAVE_MIN
-    if (wave_min < 0) { const char *e = getenv("M3D_WINO_WAVE_MIN"); wave_min = e ? atoi(e) : 800; }
-    static int variant = -1;                    // tuning knob (experiments only): M3D_WINO_VARIANT=0 selects the LDS kernel
-    if (variant < 0) { const char *e = getenv("M3D_WINO_VARIANT"); variant = e ? atoi(e) : 1; }
-    // the register-resident kernel needs enough waves for the 1024 SIMDs and has no sigmoid epilogue
-    if (variant == 1 && d->sigmoid_from < 0 && (long long)cdiv(a.NT, 32) * a.tiles_n >= wave_min) {
+    if (wino_use_wave_kernel(d)) {
         M3D_REQUIRE((long long)d->N * d->H * d->W * d->out_cs * 4 < (1ll << 31) &&
                     (long long)d->N * d->H * d->W * d->res_cs * 4 < (1ll << 31), "wino: output / residual views must be < 2 GiB");
         M3D_REQUIRE(d->Cin % 8 == 0, "wino: Cin %% 8");

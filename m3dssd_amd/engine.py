@@ -324,7 +324,8 @@ class Engine:
             # Winograd F(2x2,3x3): 2.25x fewer MFMA FLOPs for the plain 3x3 stride-1 layers
             d.wgt = pc.wino.data_ptr()
             flops = 2.0 * x.n * d.Ho * d.Wo * d.Cout * 9 * pc.cin
-            plan.ops.append((name, "wino<64,32,16>", flops, lambda st: _hip.check(L.m3d_wino_conv3x3_forward(ref, st)), d))
+            kind = "wino_wave<32,32>" if L.m3d_wino_conv3x3_variant(ref) == 1 else "wino_lds<64,32,16>"
+            plan.ops.append((name, kind, flops, lambda st: _hip.check(L.m3d_wino_conv3x3_forward(ref, st)), d))
             return
         flops_true = 2.0 * x.n * d.Ho * d.Wo * d.Cout * kh * kw * (
             cin_true if cin_true is not None else (pc.cin if (pc is not None and wgt_ptr is None) else x.c))
