@@ -120,6 +120,8 @@ int m3d_wino_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t stream);
  * channels x 16 transform positions in 512 registers, no LDS), 0 = LDS kernel (64 tiles x 32 channels per 512-thread
  * workgroup) -- chosen when the layer yields too few waves for the 1024 SIMDs or needs the sigmoid epilogue. */
 int m3d_wino_conv3x3_variant(const m3d_conv_desc *d);
+/* Same with the kernel chosen by the caller: variant -1 = automatic, 0 = LDS kernel, 1 = wave kernel (tests, tuning). */
+int m3d_wino_conv3x3_forward_ex(const m3d_conv_desc *d, int variant, m3d_stream_t stream);
 
 /* Average launch geometry chosen for a descriptor (for roofline bookkeeping / tests). */
 int m3d_conv2d_tile(const m3d_conv_desc *d, int *bm, int *bn, int *bk, int *grid);

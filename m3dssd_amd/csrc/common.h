@@ -95,5 +95,6 @@ void m3d_set_error(const char *fmt, ...);
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline int imin(int a, int b) { return a < b ? a : b; }
 
-__device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : v * M3D_LEAKY_SLOPE; }
+// LeakyReLU as max(v, slope*v) (identical for 0 < slope < 1, signed zeros included): 2 VALU ops instead of 3
+__device__ __forceinline__ float leaky(float v) { return fmaxf(v, v * M3D_LEAKY_SLOPE); }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }

@@ -13,6 +13,8 @@
 //     k = 8g + 4h + t); the last layer swaps operands so lanes run along pixels and writes the planar [Cout][HW]
 //     layout the RPN outputs need (lib/rpn_util.py:892-901 row order).
 // Arithmetic per output element is the same k-ordered fp32 fma chain as the unfused igemm path.
+#include <type_traits>
+
 #include "common.h"
 
 struct MlpArgs {
@@ -32,7 +34,20 @@ struct MlpArgs {
 #define MLP_BK 32
 
 #define MLP_MAX_HEADS 16
+#ifdef HEAD_TRACE
+static long long *g_head_trace = nullptr;
+extern "C" void m3d_head_set_trace(void *buf) { g_head_trace = (long long *)buf; }
+#define TRACE_INIT() long long *trp = batch.trace ? batch.trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 64 : nullptr; int tri = 0
+#define TRACE() do { if (trp && lane == 0 && tri < 64) trp[tri++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TRACE_INIT()
+#define TRACE()
+#endif
+
 struct MlpBatch {
+#ifdef HEAD_TRACE
+    long long *trace;
+#endif
     MlpArgs head[MLP_MAX_HEADS];                      // blockIdx.y selects the head (same M for all of them)
 };
 
@@ -45,6 +60,8 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpBatch batch)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh4 = (lane >> 5) * 4, hrow = 4 * (lane >> 5);
     const int m0 = blockIdx.x * MLP_BM;
+    TRACE_INIT();
+    TRACE();
     const int kt1 = HAS_L1 ? a.Cin / MLP_BK : 0, kt2 = MLP_H / MLP_BK, kt3 = MLP_H / MLP_BK;
     const int n_tiles = kt1 + kt2 + kt3;
     // output-layer tiling: N3 = 64 -> waves 2 (px) x 2 (ch) of 32x32;  N3 = 256 -> like the hidden layers
@@ -74,29 +91,37 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpBatch batch)
 
     load_frags(0, fbA);
     // ---- stage the input tile: act[row][0..Cin) ----------------------------------------------------------
+    // As few instructions as possible: while the co-resident workgroup streams MFMAs this wave issues roughly one instruction
+    // per MFMA slot (tools/head_probe.py HEAD_TRACE=1 showed 20-30k cycles for the old index arithmetic), so: one
+    // per-thread offset, buffer loads that differ only in the SGPR offset (rows past M read 0.0f), immediate LDS offsets.
     {
-        const int c4n = a.Cin / 4;                    // float4 per row
-        for (int i = tid; i < MLP_BM * c4n; i += 256) {
-            const int row = i / c4n, c4 = i - row * c4n;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m0 + row < a.M && !(a.ablate & 4)) v = *reinterpret_cast<const f32x4 *>(a.in + (size_t)(m0 + row) * a.in_cs + c4 * 4);
-            *reinterpret_cast<f32x4 *>(act + row * MLP_LDA + c4 * 4) = v;
-        }
+        constexpr int CIN = HAS_L1 ? 128 : 256;       // enforced by m3d_head_mlp_forward*
+        constexpr int C4N = CIN / 4, RPP = 256 / C4N, NP = MLP_BM / RPP;
+        const int row0 = tid / C4N, c4 = tid % C4N;
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, (unsigned)a.M * (unsigned)a.in_cs * 4u);
+        const unsigned voff = ((unsigned)(m0 + row0) * (unsigned)a.in_cs + (unsigned)c4 * 4u) * 4u;
+        const unsigned pstep = (unsigned)(RPP * a.in_cs) * 4u;
+        f32x4 v[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) v[k] = (a.ablate & 4) ? f32x4{0.f, 0.f, 0.f, 0.f} : buf_load_f32x4(rin, voff, k * pstep);
+        float *dst = act + row0 * MLP_LDA + c4 * 4;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) *reinterpret_cast<f32x4 *>(dst + k * RPP * MLP_LDA) = v[k];
     }
+    TRACE();
     __syncthreads();
+    TRACE();
 
     int t = 0;   // position in the weight stream
     // ---- hidden layers: each wave computes 64 px x 64 ch -------------------------------------------------
     auto hidden_layer = [&](int layer, int KT) {
+        // the accumulators are never cleared: the very first MFMA of a layer takes a zero literal as C (clearing 64 AGPRs per
+        // layer would be 64 VALU instructions, each of which stalls the SIMD's MFMA stream -- tools/ubench/mfma_side_cost.hip)
         f32x16 acc[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int wn = wave * 64;
-        auto tile = [&](int kt, f32x4 (&fb)[2][4]) {
+        auto tile = [&](int kt, f32x4 (&fb)[2][4], auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             const float *Ab = act + l31 * MLP_LDA + kt * MLP_BK + lh4;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -109,35 +134,59 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpBatch batch)
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
-                            if (!(a.ablate & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][g][s], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][g][s],
+                                                                             (FIRST && g == 0 && s == 0) ? zero16 : acc[i][j], 0, 0, 0);
             }
         };
-        for (int kt = 0; kt < KT; kt += 2) {          // KT is even (Cin and 256 are multiples of 64)
+        // KT is even (Cin and 256 are multiples of 64); the first pair is peeled for the zero-C start
+        load_frags(t + 1, fbB);
+        __builtin_amdgcn_sched_barrier(0);            // keep the prefetch ahead of the MFMAs
+        tile(0, fbA, std::true_type{});
+        TRACE();
+        ++t;
+        load_frags(t + 1, fbA);
+        __builtin_amdgcn_sched_barrier(0);
+        tile(1, fbB, std::false_type{});
+        TRACE();
+        ++t;
+        for (int kt = 2; kt < KT; kt += 2) {
             load_frags(t + 1, fbB);
-            __builtin_amdgcn_sched_barrier(0);        // keep the prefetch ahead of the MFMAs
-            tile(kt, fbA);
+            __builtin_amdgcn_sched_barrier(0);
+            tile(kt, fbA, std::false_type{});
+            TRACE();
             ++t;
             load_frags(t + 1, fbA);
             __builtin_amdgcn_sched_barrier(0);
-            tile(kt + 1, fbB);
+            tile(kt + 1, fbB, std::false_type{});
+            TRACE();
             ++t;
         }
         // affine + LeakyReLU in registers, then overwrite the activation tile in place
         const float *sc = a.scale[layer], *sh = a.shift[layer];
         __syncthreads();                              // every wave has finished reading the old tile
+        TRACE();
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int co = wn + j * 32 + l31;
             const float s = sc[co], b = sh[co];
+            const f32x2 s2 = {s, s}, b2 = {b, b}, k2 = {M3D_LEAKY_SLOPE, M3D_LEAKY_SLOPE};
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + hrow;
-                    if (!(a.ablate & 8)) act[row * MLP_LDA + co] = leaky(acc[i][j][r] * s + b);
+                for (int r = 0; r < 16; r += 2) {     // two rows per packed op: fma, slope multiply; max per element
+                    const f32x2 v = __builtin_elementwise_fma(f32x2{acc[i][j][r], acc[i][j][r + 1]}, s2, b2);
+                    f32x2 lo;                             // spelled in asm: hipcc splits the <2 x float> multiply whose lanes are used separately
+                    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(lo) : "v"(v), "v"(k2));
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int row = i * 32 + ((r + e) & 3) + 8 * ((r + e) >> 2) + hrow;
+                        if (!(a.ablate & 8)) act[row * MLP_LDA + co] = fmaxf(v[e], lo[e]);   // == leaky(v): 0 < slope < 1
+                    }
                 }
         }
+        TRACE();
         __syncthreads();
+        TRACE();
     };
     if (HAS_L1) hidden_layer(0, kt1);
     hidden_layer(1, kt2);
@@ -180,23 +229,41 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpBatch batch)
             tile(kt + 1, fbB);
             ++t;
         }
+        TRACE();
+        // planar store out[n][co][pix]: the channel term rides in the SGPR offset of a buffer store, a lane whose pixel or
+        // channel does not exist gets the out-of-range offset
         const float *sc = a.scale[2], *sh = a.shift[2];
+        const int nimg = a.M / a.HW;
+        const __amdgpu_buffer_rsrc_t rout =
+            make_rsrc(a.out, (unsigned)(((long long)(nimg - 1) * a.out_img_stride + (long long)a.Cout * a.HW) * 4));
+        const unsigned hw4 = (unsigned)a.HW * 4u;
 #pragma unroll
         for (int i = 0; i < TMo; ++i) {
             const int m = m0 + wm + i * 32 + l31;
             const bool mok = m < a.M;
             const int mm = mok ? m : 0;
             const int n = mm / a.HW, pix = mm - n * a.HW;
-            float *ob = a.out + (long long)n * a.out_img_stride + pix;
+            const unsigned pbase = (unsigned)((long long)n * a.out_img_stride + pix + (long long)hrow * a.HW) * 4u;
 #pragma unroll
-            for (int j = 0; j < TNo; ++j)
+            for (int j = 0; j < TNo; ++j) {
+                float scv[16], shv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int co = wn + j * 32 + (r & 3) + 8 * (r >> 2) + hrow;
-                    if (mok && co < a.Cout) ob[(size_t)co * a.HW] = acc[i][j][r] * sc[co] + sh[co];
+                    const int co = min(wn + j * 32 + (r & 3) + 8 * (r >> 2) + hrow, a.Cout - 1);
+                    scv[r] = sc[co];
+                    shv[r] = sh[co];
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cu = wn + j * 32 + (r & 3) + 8 * (r >> 2);      // wave-uniform part of the channel
+                    const unsigned vo = (mok && cu + hrow < a.Cout) ? pbase : M3D_BUF_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i][j][r] * scv[r] + shv[r]), rout, vo,
+                                                          (unsigned)cu * hw4, 0);
+                }
+            }
         }
     }
+    TRACE();
 }
 
 template <bool HAS_L1, int N3>
@@ -224,7 +291,10 @@ static int fill_mlp_args(const m3d_mlp_desc *d, MlpArgs &a)
     M3D_REQUIRE(d->in_cs % 4 == 0 && d->in_cs >= d->Cin && ((uintptr_t)d->in & 15) == 0, "head_mlp: input alignment");
     M3D_REQUIRE(d->Cout >= 1 && d->Cout <= d->Cout_pad && (d->Cout_pad == 64 || d->Cout_pad == 256),
                 "head_mlp: Cout_pad must be 64 or 256 (got %d)", d->Cout_pad);
-    M3D_REQUIRE(d->M > 0 && d->M < (1ll << 30) && d->HW > 0, "head_mlp: bad M / HW");
+    M3D_REQUIRE(d->M > 0 && d->M < (1ll << 30) && d->HW > 0 && d->M % d->HW == 0, "head_mlp: bad M / HW");
+    M3D_REQUIRE(d->M * d->in_cs * 4 < (1ll << 31) &&
+                ((d->M / d->HW - 1) * d->out_img_stride + (long long)d->Cout * d->HW) * 4 < (1ll << 31),
+                "head_mlp: input / output views must be < 2 GiB");
     a.in = d->in; a.in_cs = d->in_cs; a.M = (int)d->M; a.HW = d->HW; a.Cin = d->Cin;
     a.w[0] = d->w1; a.w[1] = d->w2; a.w[2] = d->w3;
     a.scale[0] = d->s1; a.scale[1] = d->s2; a.scale[2] = d->s3;
@@ -248,6 +318,9 @@ extern "C" int m3d_head_mlp_forward_batched(const m3d_mlp_desc *d, int n, m3d_st
                     "head_mlp: heads of one launch must share M, depth and Cout_pad (head %d differs)", i);
     }
     for (int i = n; i < MLP_MAX_HEADS; ++i) b.head[i] = b.head[0];
+#ifdef HEAD_TRACE
+    b.trace = g_head_trace;
+#endif
     if (d->w1) {
         if (d->Cout_pad == 64) return launch_mlp<true, 64>(b, n, stream);
         return launch_mlp<true, 256>(b, n, stream);

@@ -587,7 +587,7 @@ static bool wino_use_wave_kernel(const m3d_conv_desc *d)
 
 extern "C" int m3d_wino_conv3x3_variant(const m3d_conv_desc *d) { return d && wino_use_wave_kernel(d) ? 1 : 0; }
 
-extern "C" int m3d_wino_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t stream_)
+extern "C" int m3d_wino_conv3x3_forward_ex(const m3d_conv_desc *d, int variant, m3d_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     M3D_REQUIRE(d && d->in && d->wgt && d->out, "wino: null pointer");
@@ -622,7 +622,9 @@ extern "C" int m3d_wino_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t str
                                     (int)smem));
         attr_set = true;
     }
-    if (wino_use_wave_kernel(d)) {
+    M3D_REQUIRE(variant >= -1 && variant <= 1, "wino: variant must be -1 (auto), 0 (LDS kernel) or 1 (wave kernel)");
+    M3D_REQUIRE(variant != 1 || d->sigmoid_from < 0, "wino: the wave kernel has no sigmoid epilogue");
+    if (variant == 1 || (variant < 0 && wino_use_wave_kernel(d))) {
         M3D_REQUIRE((long long)d->N * d->H * d->W * d->out_cs * 4 < (1ll << 31) &&
                     (long long)d->N * d->H * d->W * d->res_cs * 4 < (1ll << 31), "wino: output / residual views must be < 2 GiB");
         M3D_REQUIRE(d->Cin % 8 == 0, "wino: Cin %% 8");
@@ -634,4 +636,9 @@ extern "C" int m3d_wino_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t str
     hipLaunchKernelGGL(wino_kernel, dim3(grid), dim3(512), smem, stream, a);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
+}
+
+extern "C" int m3d_wino_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t stream)
+{
+    return m3d_wino_conv3x3_forward_ex(d, -1, stream);
 }

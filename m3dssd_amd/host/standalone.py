@@ -47,7 +47,7 @@ def _affine(co, bias, bn, dev):
 
 
 def conv_nhwc(v, weight, bias=None, bn=None, stride=1, pad=0, act=0, res=None, res_mode=0, sigmoid_from=-1, om=None,
-              cout_pad_to=32, out_cs_to=4, wino=False, splitk=True):
+              cout_pad_to=32, out_cs_to=4, wino=False, splitk=True, wino_variant=-1):
     """One m3d_conv2d_forward (or, with wino=True, m3d_wino_conv3x3_forward) launch on an NHWC view;
     returns (View, keepalive)."""
     wp, co, cop, kh, kw = _pack(weight, v.c, cout_pad_to)
@@ -79,8 +79,10 @@ def conv_nhwc(v, weight, bias=None, bn=None, stride=1, pad=0, act=0, res=None, r
         if splits.value > 1 and splitk:
             ws = torch.empty(ws_bytes.value // 4, device=v.t.device, dtype=torch.float32)
             d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws_bytes.value
-    fn = _hip.lib().m3d_wino_conv3x3_forward if wino else _hip.lib().m3d_conv2d_forward
-    _hip.check(fn(ctypes.byref(d), _stream()))
+    if wino:
+        _hip.check(_hip.lib().m3d_wino_conv3x3_forward_ex(ctypes.byref(d), wino_variant, _stream()))
+    else:
+        _hip.check(_hip.lib().m3d_conv2d_forward(ctypes.byref(d), _stream()))
     return out, (wp, scale, shift, ws)
 
 

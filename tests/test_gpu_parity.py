@@ -632,12 +632,21 @@ WINO_CASES = [
 ]
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("case", WINO_CASES)
-def test_winograd_conv3x3_matches_torch(case):
-    """m3d_wino_conv3x3_forward (F(2x2,3x3), fp32) vs F.conv2d: same tolerance as the direct igemm."""
+def test_winograd_conv3x3_matches_torch(case, variant):
+    """m3d_wino_conv3x3_forward_ex (F(2x2,3x3), fp32), LDS kernel (0) and register-resident wave kernel (1), vs F.conv2d:
+    same tolerance as the direct igemm; ragged tile groups, image borders, Cout not a multiple of 32, residual."""
+    import ctypes
+    from m3dssd_amd import _hip
     from m3dssd_amd.host import standalone as S
     dev = _dev()
     n, ci, h, w, co, bias, bn, act, res, sg = case
+    if variant == 1 and sg >= 0:                       # no sigmoid epilogue in the wave kernel: refused, never silently wrong
+        d = _hip.ConvDesc()
+        d.sigmoid_from = sg
+        assert _hip.lib().m3d_wino_conv3x3_variant(ctypes.byref(d)) == 0
+        return
     g = torch.Generator().manual_seed(sum(case) + 7)
     x = torch.randn(n, ci, h, w, generator=g)
     wt = torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5
@@ -665,10 +674,32 @@ def test_winograd_conv3x3_matches_torch(case):
         v, _ = S._to_nhwc(x.to(dev))
         rv = S._to_nhwc(r.to(dev))[0] if res else None
         out, keep = S.conv_nhwc(v, wt.to(dev), None if b is None else b.to(dev), None if bnm is None else bnm.to(dev),
-                                1, 1, act=act, res=rv, sigmoid_from=sg, wino=True)
+                                1, 1, act=act, res=rv, sigmoid_from=sg, wino=True, wino_variant=variant)
         got = S._to_nchw(out, co).cpu()
     assert got.shape == ref.shape
     assert _relerr(got, ref.detach()) < 2e-4
+
+
+def test_full_size_batch8_uses_wave_kernels_and_matches_batch1():
+    """At bs=8 / 1280x384 the plan picks the wave-granular kernels (enough waves), at bs=1 the LDS-tiled ones (oracle-checked
+    above): image i of the batch must equal the same image alone, so the two kernel families cross-check at full size."""
+    from model.M3d_inference_align import build
+    dev = _dev()
+    conf = synth.synth_conf((384, 1280), 0, batch_size=8, device="cuda:0")
+    net = build(conf, "test")
+    net.load_state_dict(synth.synth_state_dict(0))
+    net = net.to(dev)
+    x = synth.synth_frames(8, (384, 1280), 4321).to(dev)
+    with torch.no_grad():
+        full = [t.clone() for t in net(x)[:4]]
+        kinds8 = {op[1] for op in net.engine().plan_for(8, 384, 1280).ops}
+        one = [t.clone() for t in net(x[5:6])[:4]]
+        kinds1 = {op[1] for op in net.engine().plan_for(1, 384, 1280).ops}
+    assert "wino_wave<32,32>" in kinds8 and any(k.startswith("conv_wave") for k in kinds8)
+    assert "wino_wave<32,32>" not in kinds1
+    for name, u, s_, tol in zip(("cls", "prob", "bbox_2d", "bbox_3d"), full, one, (1e-3, 1e-4, 1e-3, 1e-3)):
+        err = (u[5:6] - s_).abs().max().item()
+        assert err < tol, (name, err)
 
 
 def test_pipelined_detector_matches_detect_batch():

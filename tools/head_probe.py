@@ -1,6 +1,7 @@
 """Time the fused head-MLP kernel alone (HIP events): python tools/head_probe.py [heads] [B]
 Env M3D_ABLATE_MLP selects the diagnostic ablations documented in csrc/head_mlp.hip."""
 import ctypes
+import os
 import sys
 
 import torch
@@ -15,6 +16,11 @@ dev = torch.device("cuda:0")
 HW, cin, cout, cpad = 48 * 160, 128, 36, 64
 M = B * HW
 L = _hip.lib()
+TR = os.environ.get("HEAD_TRACE")
+if TR:
+    L = ctypes.CDLL("m3dssd_amd/csrc/build/libm3dssd_hip_trace.so")
+    L.m3d_head_mlp_forward_batched.argtypes = [ctypes.POINTER(_hip.MlpDesc), ctypes.c_int, ctypes.c_void_p]
+    L.m3d_head_set_trace.argtypes = [ctypes.c_void_p]
 keep = []
 arr = (_hip.MlpDesc * heads)()
 x = torch.randn(M, cin, device=dev)
@@ -43,3 +49,20 @@ torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / n
 fl = 2.0 * M * (cin * 256 + 256 * 256 + 256 * cpad) * heads
 print("heads=%d B=%d  %.4f ms  executed %.1f TFLOP/s (%.1f%% of 157.3)" % (heads, B, ms, fl / ms / 1e9, fl / ms / 1e9 / 1.573))
+
+if TR:
+    import numpy as np
+    nblk = (M + 63) // 64 * heads
+    trace = torch.zeros(nblk * 4 * 64, dtype=torch.int64, device=dev)
+    L.m3d_head_set_trace(trace.data_ptr())
+    _hip.check(L.m3d_head_mlp_forward_batched(arr, heads, st))
+    torch.cuda.synchronize()
+    t = trace.cpu().numpy().reshape(nblk, 4, 64)
+    dur = t.max(axis=(1, 2)) - t[:, 0, 0]
+    print("block durations: min %d median %d max %d ticks" % (dur.min(), int(np.median(dur)), dur.max()))
+    for blk in (nblk // 2, nblk // 2 + 1):
+        for wv in (0,):
+            s_ = t[blk, wv]
+            s_ = s_[s_ > 0] - t[blk, 0, 0]
+            print("block %d wave %d:" % (blk, wv), " ".join("%d" % v for v in s_))
+            print("   deltas:", " ".join("%d" % v for v in np.diff(s_)))
