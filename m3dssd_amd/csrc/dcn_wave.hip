@@ -30,9 +30,22 @@ struct ConvWaveArgs {
     int M, KG, tiles_n;
     int act, res_mode;
     unsigned in_bytes, out_bytes, res_bytes, w_bytes;
+#ifdef CONV_TRACE
+    long long *trace;
+#endif
 };
 
 #define CW_NT 4
+
+#ifdef CONV_TRACE
+static long long *g_conv_trace = nullptr;
+extern "C" void m3d_conv_wave_set_trace(void *buf) { g_conv_trace = (long long *)buf; }
+#define TRACE_INIT() long long *trp = a.trace ? a.trace + (size_t)blockIdx.x * 128 : nullptr; int tri = 0
+#define TRACE() do { if (trp && lane == 0 && tri < 128) trp[tri++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TRACE_INIT()
+#define TRACE()
+#endif
 
 template <bool DEFORM>
 __global__ __launch_bounds__(64) void conv_wave_kernel(const ConvWaveArgs a)
@@ -42,6 +55,8 @@ __global__ __launch_bounds__(64) void conv_wave_kernel(const ConvWaveArgs a)
     __shared__ __attribute__((aligned(16))) float tapst[32 * 8];      // [pixel][4 corner offsets (as bits), 4 weights]
     const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
     const int gp = lane >> 3, gc = lane & 7;                         // gather map: pixel-in-group, chunk
+    TRACE_INIT();
+    TRACE();
     int blk;
     {
         const int nblk = gridDim.x, bid = blockIdx.x;
@@ -187,7 +202,9 @@ __global__ __launch_bounds__(64) void conv_wave_kernel(const ConvWaveArgs a)
     for (int j = 0; j < 4; ++j) rd_off[j] = (unsigned)(l31 * 32 + (((2 * j + h) ^ ((l31 >> 1) & 7)) * 4));
 
     int tap = 0, c32 = 0;                      // position of the step being computed
+    TRACE();
     for (int kg0 = 0; kg0 < a.KG; kg0 += 4) {
+        TRACE();
         // ---- combine (gather layout) and transpose through LDS into the A-operand layout ---------------------------
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -206,6 +223,7 @@ __global__ __launch_bounds__(64) void conv_wave_kernel(const ConvWaveArgs a)
             load_raw(tap + 1);
         }
         issue_gather(c32);                      // after the last step: a redundant in-range reload, never used
+        TRACE();
         f32x4 A[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) A[j] = *reinterpret_cast<const f32x4 *>(&tileA[rd_off[j]]);
@@ -227,6 +245,7 @@ __global__ __launch_bounds__(64) void conv_wave_kernel(const ConvWaveArgs a)
         group(3, bfB, bfA);
     }
 
+    TRACE();
     // ---- epilogue: lane = channel n0 + nt*32 + l31, rows = pixels m0 + (r&3) + 8*(r>>2) + 4h ------------------------------
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out, a.out_bytes);
     const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res ? a.res : a.out, a.res ? a.res_bytes : 0u);
@@ -258,6 +277,7 @@ __global__ __launch_bounds__(64) void conv_wave_kernel(const ConvWaveArgs a)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, oo, 0, 0);
         }
     }
+    TRACE();
 }
 
 // Waves the kernel would launch for this layer; 0 = not applicable (hard constraints) or, with enforce_min, too few waves.
@@ -305,6 +325,9 @@ extern "C" int m3d_conv_wave_forward(const m3d_conv_desc *d, m3d_stream_t stream
     a.out_bytes = (unsigned)(M * d->out_cs * 4);
     a.res_bytes = (unsigned)(M * d->res_cs * 4);
     a.w_bytes = (unsigned)((long long)128 * d->kh * d->kw * d->Cin * 4);
+#ifdef CONV_TRACE
+    a.trace = g_conv_trace;
+#endif
     if (d->dcn_offmask) hipLaunchKernelGGL(conv_wave_kernel<true>, dim3(waves), dim3(64), 0, stream, a);
     else hipLaunchKernelGGL(conv_wave_kernel<false>, dim3(waves), dim3(64), 0, stream, a);
     M3D_LAUNCH_CHECK();

@@ -203,6 +203,20 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpBatch batch)
             for (int j = 0; j < TNo; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        // per-channel affine of this lane's 16 rows per column tile, requested before the k loop (latency off the tail)
+        // (only for the narrow form: 64 more live registers would halve the occupancy of the 256-channel form)
+        float scv[TNo][16], shv[TNo][16];
+        auto load_affine = [&]() {
+#pragma unroll
+            for (int j = 0; j < TNo; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = min(wn + j * 32 + (r & 3) + 8 * (r >> 2) + hrow, a.Cout - 1);
+                    scv[j][r] = a.scale[2][co];
+                    shv[j][r] = a.shift[2][co];
+                }
+        };
+        if constexpr (N3 == 64) load_affine();
         auto tile = [&](int kt, f32x4 (&fb)[2][4]) {
             const float *Ab = act + (wm + l31) * MLP_LDA + kt * MLP_BK + lh4;
 #pragma unroll
@@ -232,7 +246,7 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpBatch batch)
         TRACE();
         // planar store out[n][co][pix]: the channel term rides in the SGPR offset of a buffer store, a lane whose pixel or
         // channel does not exist gets the out-of-range offset
-        const float *sc = a.scale[2], *sh = a.shift[2];
+        if constexpr (N3 != 64) load_affine();
         const int nimg = a.M / a.HW;
         const __amdgpu_buffer_rsrc_t rout =
             make_rsrc(a.out, (unsigned)(((long long)(nimg - 1) * a.out_img_stride + (long long)a.Cout * a.HW) * 4));
@@ -246,19 +260,12 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpBatch batch)
             const unsigned pbase = (unsigned)((long long)n * a.out_img_stride + pix + (long long)hrow * a.HW) * 4u;
 #pragma unroll
             for (int j = 0; j < TNo; ++j) {
-                float scv[16], shv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = min(wn + j * 32 + (r & 3) + 8 * (r >> 2) + hrow, a.Cout - 1);
-                    scv[r] = sc[co];
-                    shv[r] = sh[co];
-                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int cu = wn + j * 32 + (r & 3) + 8 * (r >> 2);      // wave-uniform part of the channel
                     const unsigned vo = (mok && cu + hrow < a.Cout) ? pbase : M3D_BUF_OOB;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i][j][r] * scv[r] + shv[r]), rout, vo,
-                                                          (unsigned)cu * hw4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i][j][r] * scv[j][r] + shv[j][r]), rout,
+                                                          vo, (unsigned)cu * hw4, 0);
                 }
             }
         }
