@@ -110,6 +110,10 @@ int m3d_conv2d_splitk_plan(const m3d_conv_desc *d, int *splits, long long *ws_by
  * (needs Cin % 32 == 0, in_cs % 32 == 0, 128-byte aligned input, Cout_pad % 128 == 0, NHWC output, shared weights,
  * no sigmoid channels) or when there are too few waves to fill the chip; the caller then stays on m3d_conv2d_forward. */
 int m3d_conv_wave_applicable(const m3d_conv_desc *d);
+/* Thin layers (too few 32 x 128 tiles) can still take this path split along K across waves: *splits and the scratch bytes to
+ * pass through splitk_ws / splitk_ws_bytes (partials are reduced in split order by a second launch, which applies the
+ * epilogue).  Without a workspace the layer is simply not split. */
+int m3d_conv_wave_splitk_plan(const m3d_conv_desc *d, int *splits, long long *ws_bytes);
 int m3d_conv_wave_forward(const m3d_conv_desc *d, m3d_stream_t stream);
 
 /* Winograd F(2x2,3x3) variant for 3x3 / stride 1 / pad 1 / even H,W plain convolutions (same descriptor; `wgt`

@@ -98,3 +98,12 @@ static inline int imin(int a, int b) { return a < b ? a : b; }
 // LeakyReLU as max(v, slope*v) (identical for 0 < slope < 1, signed zeros included): 2 VALU ops instead of 3
 __device__ __forceinline__ float leaky(float v) { return fmaxf(v, v * M3D_LEAKY_SLOPE); }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// ---- deterministic split-K reduction shared by the LDS-tiled and the wave-granular implicit GEMMs (igemm_conv.hip) -----------
+// ws holds `splits` raw partial sums [split][M][Cout_pad]; they are added in split order and the conv epilogue is applied.
+struct SplitkReduceArgs {
+    const float *ws, *scale, *shift, *res;
+    float *out;
+    int M, Cout, Cout_pad, splits, out_cs, res_cs, res_mode, act, sigmoid_from;
+};
+int m3d_launch_splitk_reduce(const SplitkReduceArgs &a, hipStream_t stream);

@@ -30,6 +30,11 @@ struct ConvWaveArgs {
     int M, KG, tiles_n;
     int act, res_mode;
     unsigned in_bytes, out_bytes, res_bytes, w_bytes;
+    // split-K across waves (layers with too few 32 x 128 tiles): grid = splits x tiles, split s covers steps
+    // [s*ss_per, (s+1)*ss_per) and stores raw partial sums to ws[s][M][Cout_pad]; m3d_launch_splitk_reduce finishes
+    float *ws;
+    int splits, ss_per, base_waves;
+    unsigned ws_bytes;
 #ifdef CONV_TRACE
     long long *trace;
 #endif
@@ -63,9 +68,15 @@ __global__ __launch_bounds__(64) void conv_wave_kernel(const ConvWaveArgs a)
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
         blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
+    int split = 0;
+    if (a.splits > 1) {
+        split = blk / a.base_waves;
+        blk -= split * a.base_waves;
+    }
     const int bm = blk / a.tiles_n, bn = blk - bm * a.tiles_n;
     const int m0 = bm * 32;
     const int KK = a.kh * a.kw, C32 = a.Cin / 32;
+    const int ss0 = split * a.ss_per, ss1 = min(KK * C32, ss0 + a.ss_per);        // this wave's steps
 
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wfrag + (size_t)bn * NT * a.KG * 256, a.w_bytes);
@@ -185,11 +196,12 @@ __global__ __launch_bounds__(64) void conv_wave_kernel(const ConvWaveArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
-    load_raw(0);
-    setup_tap(0);
-    load_raw(1);
-    issue_gather(0);
-    issue_b(0, bfA);
+    int tap = ss0 / C32, c32 = ss0 - tap * C32;                  // position of the step being computed
+    load_raw(tap);
+    setup_tap(tap);
+    load_raw(tap + 1);
+    issue_gather(c32);
+    issue_b(ss0 * 4, bfA);
 
     // LDS slots: pixel row r, 16-byte slot s lives at r*128 + ((s ^ ((r >> 1) & 7)) * 16) bytes
     unsigned wr_off[4], rd_off[4];
@@ -201,9 +213,8 @@ __global__ __launch_bounds__(64) void conv_wave_kernel(const ConvWaveArgs a)
 #pragma unroll
     for (int j = 0; j < 4; ++j) rd_off[j] = (unsigned)(l31 * 32 + (((2 * j + h) ^ ((l31 >> 1) & 7)) * 4));
 
-    int tap = 0, c32 = 0;                      // position of the step being computed
     TRACE();
-    for (int kg0 = 0; kg0 < a.KG; kg0 += 4) {
+    for (int kg0 = ss0 * 4; kg0 < ss1 * 4; kg0 += 4) {
         TRACE();
         // ---- combine (gather layout) and transpose through LDS into the A-operand layout ---------------------------
 #pragma unroll
@@ -251,6 +262,23 @@ __global__ __launch_bounds__(64) void conv_wave_kernel(const ConvWaveArgs a)
     const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res ? a.res : a.out, a.res ? a.res_bytes : 0u);
     const int n0 = bn * 32 * NT;
     const int mb = m0 + 4 * h;
+    if (a.splits > 1) {                        // raw partial sums; the reduce launch owns the epilogue
+        const __amdgpu_buffer_rsrc_t rws = make_rsrc(a.ws, a.ws_bytes);
+        const unsigned sbase = (unsigned)split * (unsigned)a.M;
+        const unsigned cpad = (unsigned)(a.tiles_n * 32 * NT);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const unsigned co = (unsigned)(n0 + nt * 32 + l31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                const unsigned oo = m < a.M ? ((sbase + (unsigned)m) * cpad + co) * 4u : M3D_BUF_OOB;
+                const float pv = acc[nt][r];   // (bit-casting the vector element expression directly stores element 0)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv), rws, oo, 0, 0);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = n0 + nt * 32 + l31;
@@ -280,29 +308,65 @@ __global__ __launch_bounds__(64) void conv_wave_kernel(const ConvWaveArgs a)
     TRACE();
 }
 
-// Waves the kernel would launch for this layer; 0 = not applicable (hard constraints) or, with enforce_min, too few waves.
-static int conv_wave_plan(const m3d_conv_desc *d, bool enforce_min)
+// Launch plan: *splits (split-K factor, 1 = none) and the total number of waves; 0 = not applicable (hard constraints) or,
+// with enforce_min, still too few waves.  Measured (profiles/): below one wave per SIMD the LDS-tiled kernel wins and the
+// deformable gather wants two waves per SIMD, so thin layers are split along K until ~1800 waves exist (at least 4 steps of
+// 32 channels per split).  Tuning knobs (experiments only): M3D_CONV_WAVE_MIN / M3D_DCN_WAVE_MIN / M3D_CONV_WAVE_SPLITK=0.
+static int conv_wave_plan(const m3d_conv_desc *d, bool enforce_min, int *splits, int *ss_per)
 {
+    *splits = 1;
+    *ss_per = d->kh * d->kw * (d->Cin / 32);
     if (d->out_nchw || d->wgt_img_stride || d->sigmoid_from >= 0) return 0;
     if (d->Cin % 32 != 0 || d->Cout_pad % 128 != 0) return 0;
     const long long M = (long long)d->N * d->Ho * d->Wo;
-    const long long waves = ((M + 31) / 32) * (d->Cout_pad / 128);
-    // measured (profiles/): below one wave per SIMD the LDS-tiled kernel wins; the deformable gather needs two waves per
-    // SIMD to hide its latency.  Tuning knobs (experiments only): M3D_CONV_WAVE_MIN / M3D_DCN_WAVE_MIN
-    static int wave_min = -1, dcn_min = -1;
+    const long long base = ((M + 31) / 32) * (d->Cout_pad / 128);
+    if (base >= (1ll << 28)) return 0;
+    static int wave_min = -1, dcn_min = -1, splitk = -1;
     if (wave_min < 0) { const char *e = getenv("M3D_CONV_WAVE_MIN"); wave_min = e ? atoi(e) : 900; }
     if (dcn_min < 0) { const char *e = getenv("M3D_DCN_WAVE_MIN"); dcn_min = e ? atoi(e) : 1500; }
-    if (enforce_min && waves < (d->dcn_offmask ? dcn_min : wave_min)) return 0;
-    return waves < (1ll << 30) ? (int)waves : 0;
+    if (splitk < 0) { const char *e = getenv("M3D_CONV_WAVE_SPLITK"); splitk = e ? atoi(e) : 1; }
+    const long long need = d->dcn_offmask ? dcn_min : wave_min;
+    const int nss = *ss_per;
+    if (base < need && splitk && d->splitk_ws) {
+        int s = (int)((1800 + base - 1) / base);
+        if (s > nss / 4) s = nss / 4;
+        if (s > 8) s = 8;
+        if (s >= 2) {
+            *ss_per = (nss + s - 1) / s;
+            *splits = (nss + *ss_per - 1) / *ss_per;
+        }
+    }
+    if (enforce_min && base * *splits < need) { *splits = 1; *ss_per = nss; return 0; }
+    return (int)(base * *splits);
 }
 
-extern "C" int m3d_conv_wave_applicable(const m3d_conv_desc *d) { return d ? conv_wave_plan(d, true) : 0; }
+extern "C" int m3d_conv_wave_applicable(const m3d_conv_desc *d)
+{
+    int s, p;
+    return d ? conv_wave_plan(d, true, &s, &p) : 0;
+}
+
+// Split-K plan of m3d_conv_wave_forward: the caller that wants thin layers on this path passes a scratch buffer of
+// *ws_bytes through splitk_ws (the plan is computed AS IF one were given).
+extern "C" int m3d_conv_wave_splitk_plan(const m3d_conv_desc *d, int *splits, long long *ws_bytes)
+{
+    M3D_REQUIRE(d && splits && ws_bytes, "conv_wave_splitk_plan: null pointer");
+    m3d_conv_desc t = *d;
+    static float dummy;
+    t.splitk_ws = &dummy;
+    int p;
+    const int waves = conv_wave_plan(&t, true, splits, &p);
+    if (waves == 0) *splits = 1;
+    *ws_bytes = *splits > 1 ? (long long)*splits * d->N * d->Ho * d->Wo * d->Cout_pad * 4 : 0;
+    return M3D_OK;
+}
 
 extern "C" int m3d_conv_wave_forward(const m3d_conv_desc *d, m3d_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     M3D_REQUIRE(d && d->in && d->wgt && d->out, "conv_wave: null pointer");
-    const int waves = conv_wave_plan(d, false);       // the fill heuristic is advisory here
+    int splits = 1, ss_per = 0;
+    const int waves = conv_wave_plan(d, false, &splits, &ss_per);       // the fill heuristic is advisory here
     M3D_REQUIRE(waves > 0, "conv_wave: needs Cin %% 32 == 0, Cout_pad %% 128 == 0, NHWC output, shared weights, no sigmoid");
     const int ho = (d->H + 2 * d->pad - (d->dil * (d->kh - 1) + 1)) / d->stride + 1;
     const int wo = (d->W + 2 * d->pad - (d->dil * (d->kw - 1) + 1)) / d->stride + 1;
@@ -328,8 +392,23 @@ extern "C" int m3d_conv_wave_forward(const m3d_conv_desc *d, m3d_stream_t stream
 #ifdef CONV_TRACE
     a.trace = g_conv_trace;
 #endif
+    a.ws = nullptr; a.splits = 1; a.ss_per = ss_per; a.base_waves = waves; a.ws_bytes = 0;
+    if (splits > 1) {
+        const long long need = (long long)splits * M * d->Cout_pad * 4;
+        M3D_REQUIRE(need <= d->splitk_ws_bytes && need < (1ll << 31) && ((uintptr_t)d->splitk_ws & 15) == 0,
+                    "conv_wave: split-K workspace too small (%lld bytes, see m3d_conv_wave_splitk_plan), >= 2 GiB or misaligned",
+                    d->splitk_ws_bytes);
+        a.ws = d->splitk_ws; a.splits = splits; a.base_waves = waves / splits; a.ws_bytes = (unsigned)need;
+    }
     if (d->dcn_offmask) hipLaunchKernelGGL(conv_wave_kernel<true>, dim3(waves), dim3(64), 0, stream, a);
     else hipLaunchKernelGGL(conv_wave_kernel<false>, dim3(waves), dim3(64), 0, stream, a);
     M3D_LAUNCH_CHECK();
+    if (splits > 1) {
+        SplitkReduceArgs r;
+        r.ws = a.ws; r.scale = d->scale; r.shift = d->shift; r.res = d->res; r.out = d->out;
+        r.M = (int)M; r.Cout = d->Cout; r.Cout_pad = d->Cout_pad; r.splits = splits; r.out_cs = d->out_cs; r.res_cs = d->res_cs;
+        r.res_mode = d->res_mode; r.act = d->act; r.sigmoid_from = -1;
+        return m3d_launch_splitk_reduce(r, stream);
+    }
     return M3D_OK;
 }

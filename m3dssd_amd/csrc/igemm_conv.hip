@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
 }
 
 // Sum the split-K partials in split order and apply the igemm epilogue; one thread per 4 channels of a pixel.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs a, int vec_out)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const SplitkReduceArgs a, int vec_out)
 {
     const int c4n = a.Cout_pad >> 2;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -421,6 +421,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmArgs a, i
     }
 }
 
+int m3d_launch_splitk_reduce(const SplitkReduceArgs &a, hipStream_t stream)
+{
+    const long long n4 = (long long)a.M * (a.Cout_pad >> 2);
+    const int vec_out = (a.out_cs % 4 == 0) && (((uintptr_t)a.out & 15) == 0);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, a, vec_out);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool DEFORM, bool SWAP>
 static int launch_igemm(const IgemmArgs &a, hipStream_t stream)
@@ -439,10 +448,11 @@ static int launch_igemm(const IgemmArgs &a, hipStream_t stream)
     hipLaunchKernelGGL(kern, dim3(b.tiles_m * b.tiles_n * b.splits), dim3(256), smem, stream, b);
     M3D_LAUNCH_CHECK();
     if (b.splits > 1) {
-        const long long n4 = (long long)b.M * (b.Cout_pad >> 2);
-        const int vec_out = (b.out_cs % 4 == 0) && (((uintptr_t)b.out & 15) == 0);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, b, vec_out);
-        M3D_LAUNCH_CHECK();
+        SplitkReduceArgs r;
+        r.ws = b.ws; r.scale = b.scale; r.shift = b.shift; r.res = b.res; r.out = b.out;
+        r.M = b.M; r.Cout = b.Cout; r.Cout_pad = b.Cout_pad; r.splits = b.splits; r.out_cs = b.out_cs; r.res_cs = b.res_cs;
+        r.res_mode = b.res_mode; r.act = b.act; r.sigmoid_from = b.sigmoid_from;
+        return m3d_launch_splitk_reduce(r, stream);
     }
     return M3D_OK;
 }

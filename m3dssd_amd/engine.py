@@ -330,13 +330,25 @@ class Engine:
         flops_true = 2.0 * x.n * d.Ho * d.Wo * d.Cout * kh * kw * (
             cin_true if cin_true is not None else (pc.cin if (pc is not None and wgt_ptr is None) else x.c))
         if (pc is not None and wgt_ptr is None and planar is None and (USE_DCN_WAVE if om is not None else USE_CONV_WAVE)
-                and x.cs % 32 == 0 and x.ptr % 128 == 0 and pc.cin_pad == x.c and L.m3d_conv_wave_applicable(ref) > 0):
-            # enough independent waves to fill the SIMDs: wave-granular kernel, no workgroup barriers (csrc/dcn_wave.hip)
-            frag = pc.frag()
-            d.wgt = frag.data_ptr()
-            plan.ops.append((name, "conv_wave<deform>" if om is not None else "conv_wave", flops_true,
-                             lambda st: _hip.check(L.m3d_conv_wave_forward(ref, st)), d))
-            return
+                and x.cs % 32 == 0 and x.ptr % 128 == 0 and pc.cin_pad == x.c):
+            # wave-granular kernel, no workgroup barriers (csrc/dcn_wave.hip); thin layers are split along K across waves
+            wsplits, wbytes = ctypes.c_int(), ctypes.c_longlong()
+            _hip.check(L.m3d_conv_wave_splitk_plan(ref, ctypes.byref(wsplits), ctypes.byref(wbytes)))
+            ws = None
+            if wsplits.value > 1:
+                ws = torch.empty(wbytes.value // 4, device=self.device, dtype=torch.float32)
+                d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), wbytes.value
+            if L.m3d_conv_wave_applicable(ref) > 0:
+                frag = pc.frag()
+                d.wgt = frag.data_ptr()
+                if ws is not None:
+                    plan.keep.append(ws)
+                kind = "conv_wave%s" % ("<%s>" % ",".join(
+                    (["deform"] if om is not None else []) + (["splitk%d" % wsplits.value] if wsplits.value > 1 else []))
+                    if (om is not None or wsplits.value > 1) else "")
+                plan.ops.append((name, kind, flops_true, lambda st: _hip.check(L.m3d_conv_wave_forward(ref, st)), d))
+                return
+            d.splitk_ws, d.splitk_ws_bytes = None, 0
         bm, bn, bk, grid = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         _hip.check(L.m3d_conv2d_tile(ref, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(bk), ctypes.byref(grid)))
         splits, ws_bytes = ctypes.c_int(), ctypes.c_longlong()

@@ -465,7 +465,8 @@ def test_dlaseg_standalone_matches_oracle():
 
 @pytest.mark.parametrize("shape", [(2, 32, 9, 13, 128, 3, 1, 1), (1, 64, 40, 52, 128, 3, 1, 1), (2, 128, 16, 24, 256, 1, 1, 0),
                                    (1, 48, 11, 7, 100, 3, 2, 1)])
-def test_dcn_wave_kernel_matches_block_kernel_and_oracle(shape):
+@pytest.mark.parametrize("deform", [1, 0])
+def test_dcn_wave_kernel_matches_block_kernel_and_oracle(shape, deform):
     """m3d_conv_wave_forward (register-resident, one wave per 32/64 px x 128 ch) vs the LDS-tiled igemm on the same
     descriptor, and vs the oracle im2col + GEMM: ragged M, borders, stride 2, channel padding, fused epilogue."""
     import ctypes
@@ -481,6 +482,8 @@ def test_dcn_wave_kernel_matches_block_kernel_and_oracle(shape):
     ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
     off = torch.randn(n, 2 * k * k, ho, wo, generator=g) * 1.5
     msk = torch.sigmoid(torch.randn(n, k * k, ho, wo, generator=g))
+    if not deform:                                       # plain convolution = zero offsets, unit mask in the oracle
+        off, msk = torch.zeros_like(off), torch.ones_like(msk)
     wt = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
     b = torch.randn(co, generator=g)
     ref = odcn.dcn_v2_forward(x, off, msk, wt, b, stride, pad, 1, 1)
@@ -490,7 +493,8 @@ def test_dcn_wave_kernel_matches_block_kernel_and_oracle(shape):
     v, _ = S._to_nhwc(x.to(dev), cin_pad)
     om, _ = S._to_nhwc(torch.cat([off, msk], 1).to(dev))
     rv, _ = S._to_nhwc(res.to(dev))
-    out_blk, keep = S.conv_nhwc(v, wt.to(dev), b.to(dev), None, stride, pad, act=1, res=rv, om=om, cout_pad_to=128)
+    out_blk, keep = S.conv_nhwc(v, wt.to(dev), b.to(dev), None, stride, pad, act=1, res=rv, om=om if deform else None,
+                                cout_pad_to=128)
     blk = S._to_nchw(out_blk, co).cpu()
     wp, co_, cop, kh, kw = S._pack(wt.to(dev), cin_pad, 128)
     frag = pack_frag(wp.view(cop, kh * kw * cin_pad), cop, dev)
@@ -502,11 +506,29 @@ def test_dcn_wave_kernel_matches_block_kernel_and_oracle(shape):
     d.kh, d.kw, d.stride, d.pad, d.dil, d.Ho, d.Wo = k, k, stride, pad, 1, ho, wo
     d.out, d.out_cs, d.scale, d.shift = out.data_ptr(), co, sc.data_ptr(), sh.data_ptr()
     d.res, d.res_cs, d.res_mode, d.act, d.sigmoid_from = rv.ptr, rv.cs, 0, 1, -1
-    d.dcn_offmask, d.dcn_om_cs = om.ptr, om.cs
+    if deform:
+        d.dcn_offmask, d.dcn_om_cs = om.ptr, om.cs
     _hip.check(L.m3d_conv_wave_forward(ctypes.byref(d), S._stream()))
     got = out.view(n, ho, wo, co).permute(0, 3, 1, 2).cpu()
     assert _relerr(got, want) < 2e-4
     assert (got - blk).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    # split along K across waves (what the engine does for thin layers; with a workspace present m3d_conv_wave_forward splits
+    # any layer that has fewer waves than the fill threshold): same result to fp32 reassociation, deterministic
+    ws = torch.empty(8 * n * ho * wo * cop, device=dev)
+    d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
+    outs = []
+    for _ in range(2):
+        out.zero_()
+        _hip.check(L.m3d_conv_wave_forward(ctypes.byref(d), S._stream()))
+        outs.append(out.clone())
+    assert torch.equal(outs[0], outs[1])
+    gs = outs[0].view(n, ho, wo, co).permute(0, 3, 1, 2).cpu()
+    assert _relerr(gs, want) < 2e-4
+    assert (gs - got).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    if k * k * cin_pad // 32 >= 8:                       # at least two splits of four steps: the short workspace is refused
+        d.splitk_ws_bytes = 64
+        assert L.m3d_conv_wave_forward(ctypes.byref(d), S._stream()) != 0 and b"workspace" in L.m3d_last_error()
+    d.splitk_ws, d.splitk_ws_bytes = None, 0
     d.sigmoid_from = 3                                   # not supported here: refused, the caller stays on the igemm
     assert L.m3d_conv_wave_applicable(ctypes.byref(d)) == 0 and L.m3d_conv_wave_forward(ctypes.byref(d), S._stream()) != 0
 
