@@ -43,7 +43,7 @@ struct WinoArgs {
 
 #ifdef WINO_TRACE
 #define TRACE_INIT() long long *trp = a.trace ? a.trace + ((size_t)blockIdx.x * 8 + wave) * 128 : nullptr; int tri = 0
-#define TRACE() do { if (trp && lane == 0 && tri < 128) trp[tri++] = __builtin_readcyclecounter(); } while (0)
+#define TRACE() do { if (trp && lane == 0 && tri < 126) { trp[tri++] = __builtin_readcyclecounter(); trp[tri == 1 ? 126 : 127] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define TRACE_INIT()
 #define TRACE()

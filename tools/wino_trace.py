@@ -50,6 +50,11 @@ t = trace.cpu().numpy().reshape(grid, 8, 128)
 start = t[:, :, 0][t[:, :, 0] > 0].min()
 end = t.max()
 print("grid %d blocks, launch %.4f ms, stamps span %d ticks (%.1f ticks/us)" % (grid, ms, end - start, (end - start) / (ms * 1e3)))
+rt = t[:, 0, 127] - t[:, 0, 126]
+last = np.where(t[:, 0, :126] > 0, t[:, 0, :126], 0).max(axis=1)
+clk = (last - t[:, 0, 0]) / np.maximum(rt, 1) * 0.1
+print("shader clock inside the kernel (memtime/realtime per wave 0): median %.3f GHz, min %.3f, max %.3f" % (np.median(clk), clk.min(), clk.max()))
+t = t.copy(); t[:, :, 126:] = 0
 bstart = t[:, 0, 0] - start
 order = np.argsort(bstart)
 print("block start times (ticks): first 5", bstart[order[:5]], " median", int(np.median(bstart)), " last 5", bstart[order[-5:]])
