@@ -1,6 +1,8 @@
 // HBM-bound helpers of the backbone / up-sampling path (NHWC, 16-byte vector access along C):
 // weight packing, layout changes at the op boundary, the 7x7 stem, 2x2 max-pool and the
 // depthwise transposed-conv up-sampler fused with the IDA skip add.
+#include <stdlib.h>
+
 #include "common.h"
 
 // ---------------------------------------------------------------------------------------
@@ -101,28 +103,45 @@ __global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float *__restri
     __shared__ float patch[3][PH][PW + 1];
     const int n = blockIdx.z, h0 = blockIdx.y * STEM_TH, w0 = blockIdx.x * STEM_TW;
     const float *im = img + (size_t)n * 3 * H * W;
-    for (int i = threadIdx.x; i < 3 * PH * PW; i += 256) {
-        const int c = i / (PH * PW), r = (i / PW) % PH, q = i % PW;
-        const int h = h0 + r - 3, w = w0 + q - 3;
-        patch[c][r][q] = (h >= 0 && h < H && w >= 0 && w < W) ? im[((size_t)c * H + h) * W + w] : 0.f;
+    {   // all loads of the thread in flight before the first LDS write
+        constexpr int NE = 3 * PH * PW, NIT = (NE + 255) / 256;
+        float v[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            const int c = i / (PH * PW), r = (i / PW) % PH, q = i % PW;
+            const int h = h0 + r - 3, w = w0 + q - 3;
+            v[k] = (i < NE && h >= 0 && h < H && w >= 0 && w < W) ? im[((size_t)c * H + h) * W + w] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < NE) patch[i / (PH * PW)][(i / PW) % PH][i % PW] = v[k];
+        }
     }
     __syncthreads();
     const int ty = threadIdx.x / STEM_TW, tx = threadIdx.x % STEM_TW;
-    float acc[16];
+    // packed fp32: two output channels per v_pk_fma_f32 (the pixel value is broadcast, the weight pair is an SGPR pair) --
+    // half the VALU instructions of a scalar-FMA loop, which ran at the non-packed VALU peak
+    f32x2 acc2[8];
 #pragma unroll
-    for (int o = 0; o < 16; ++o) acc[o] = 0.f;
+    for (int o = 0; o < 8; ++o) acc2[o] = f32x2{0.f, 0.f};
     for (int i = 0; i < 7; ++i) {
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float v = patch[c][ty + i][tx + j];
+                const f32x2 vv = {v, v};
                 const float *wp = wgt + ((i * 7 + j) * 3 + c) * 16;   // uniform -> s_load
 #pragma unroll
-                for (int o = 0; o < 16; ++o) acc[o] = fmaf(v, wp[o], acc[o]);
+                for (int o = 0; o < 8; ++o) acc2[o] = __builtin_elementwise_fma(vv, f32x2{wp[2 * o], wp[2 * o + 1]}, acc2[o]);
             }
         }
     }
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) { acc[2 * o] = acc2[o][0]; acc[2 * o + 1] = acc2[o][1]; }
     const int h = h0 + ty, w = w0 + tx;
     if (h < H && w < W) {
         float *op = out + ((size_t)(n * H + h) * W + w) * out_cs;
@@ -148,6 +167,7 @@ extern "C" int m3d_stem_conv7x7(const float *img_nchw, const float *wgt, const f
 
 // ---------------------------------------------------------------------------------------
 // level0: 3x3, 16 -> 16, stride 1, pad 1 at full resolution (model/pose_dla_dcn.py:341-342), NHWC in/out.
+// (VALU reference variant, M3D_L0_VALU=1; the MFMA kernel below is the default: 0.211 vs 0.219 ms at bs=8)
 // 16 output channels cannot fill a 32-wide MFMA tile (the igemm pads to 32 and wastes half the pipe) and the
 // layer moves 0.5 GB at bs=8, so it runs as a direct convolution on the VALU like the stem: one thread = one output
 // pixel x 16 channels, the (8+2)x(32+2)x16 input tile in LDS (pixel stride 20 floats: conflict-free b128 reads),
@@ -175,9 +195,9 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
     }
     __syncthreads();
     const int ty = threadIdx.x / L0_TW, tx = threadIdx.x % L0_TW;
-    float acc[16];
+    f32x2 acc2[8];                             // packed fp32, two output channels per v_pk_fma_f32 (see the stem)
 #pragma unroll
-    for (int o = 0; o < 16; ++o) acc[o] = 0.f;
+    for (int o = 0; o < 8; ++o) acc2[o] = f32x2{0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -189,12 +209,16 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float *wp = wgt + (((i * 3 + j) * 16) + q * 4 + e) * 16;   // uniform -> s_load
+                    const f32x2 vv = {x4[e], x4[e]};
 #pragma unroll
-                    for (int o = 0; o < 16; ++o) acc[o] = fmaf(x4[e], wp[o], acc[o]);
+                    for (int o = 0; o < 8; ++o) acc2[o] = __builtin_elementwise_fma(vv, f32x2{wp[2 * o], wp[2 * o + 1]}, acc2[o]);
                 }
             }
         }
     }
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) { acc[2 * o] = acc2[o][0]; acc[2 * o + 1] = acc2[o][1]; }
     const int h = h0 + ty, w = w0 + tx;
     if (h < H && w < W) {
         float *op = out + ((size_t)(n * H + h) * W + w) * out_cs;
@@ -208,13 +232,107 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
     }
 }
 
+
+// MFMA variant of level0.  The VALU kernel above runs at the non-packed VALU peak (v_pk_fma_f32 issues at half rate, so
+// packing buys ~5 %); v_mfma_f32_16x16x4_f32 has exactly the 16-wide N this layer needs (no padded half tile):
+//   M = 16 consecutive pixels of a row, N = 16 couts, K = 4 channels per MFMA, 4 MFMAs per tap.
+// Workgroup = 8 rows x 64 cols of output; the (8+2) x (64+2) x 16-channel input tile sits in LDS (64 B per pixel: the
+// A-operand read of a 16-pixel tile is one contiguous 1 KB ds_read_b128), borders are zero-filled by buffer range checks.
+// Lane (i = lane & 15, q = lane >> 4): A = channels 4q..4q+3 of pixel i (component t feeds MFMA t), B = W[tap][4q + t][cout i]
+// held in 36 registers for the whole kernel; D: lane = cout, registers = pixels 4q..4q+3.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#define L0M_TH 8
+#define L0M_TW 64
+__global__ __launch_bounds__(256) void conv3x3_c16_mfma_kernel(const float *__restrict__ in, int in_cs, unsigned in_bytes,
+                                                               const float *__restrict__ wgt, const float *__restrict__ scale,
+                                                               const float *__restrict__ shift, float *__restrict__ out,
+                                                               int out_cs, int H, int W)
+{
+    constexpr int PH = L0M_TH + 2, PW = L0M_TW + 2;
+    __shared__ __attribute__((aligned(16))) float tile[PH * PW * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int n = blockIdx.z, h0 = blockIdx.y * L0M_TH, w0 = blockIdx.x * L0M_TW;
+    // ---- B operand: 9 taps x (4 channels of this lane's k slot) for cout li --------------------------------------
+    f32x4 bw[9];
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bw[t9][t] = wgt[((t9 * 16) + 4 * lq + t) * 16 + li];
+    // ---- stage the input tile ---------------------------------------------------------------------------------------
+    {
+        // all loads of the thread are issued before the first LDS write (a rolled loop would serialise 11 memory latencies)
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(in, in_bytes);
+        constexpr int NE = PH * PW * 4, NIT = (NE + 255) / 256;
+        f32x4 v[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int e = tid + 256 * k;
+            const int q = e & 3, p = e >> 2;
+            const int r = p / PW, c = p - r * PW;
+            const int h = h0 + r - 1, w = w0 + c - 1;
+            const unsigned vo = (e < NE && h >= 0 && h < H && w >= 0 && w < W)
+                                    ? ((unsigned)((n * H + h) * W + w) * (unsigned)in_cs + (unsigned)q * 4u) * 4u : M3D_BUF_OOB;
+            v[k] = buf_load_f32x4(rin, vo, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int e = tid + 256 * k;
+            if (e < NE) *reinterpret_cast<f32x4 *>(tile + e * 4) = v[k];
+        }
+    }
+    __syncthreads();
+    // ---- 9 taps x 8 pixel tiles (2 rows x 4 column tiles per wave) x 4 MFMAs -------------------------------------------
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[rr][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 3; ++tj) {
+            const f32x4 b = bw[ti * 3 + tj];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(
+                        tile + ((2 * wave + rr + ti) * PW + ct * 16 + li + tj) * 16 + lq * 4);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[rr][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], acc[rr][ct], 0, 0, 0);
+                }
+        }
+    // ---- epilogue: lane = cout li, registers = pixels 4*lq + r of the 16-pixel tile -------------------------------------
+    const float sc = scale[li], sh = shift[li];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int h = h0 + 2 * wave + rr;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int w = w0 + ct * 16 + 4 * lq + r;
+                if (h < H && w < W) out[((size_t)(n * H + h) * W + w) * out_cs + li] = leaky(acc[rr][ct][r] * sc + sh);
+            }
+    }
+}
+
 extern "C" int m3d_conv3x3_c16(const float *in, int in_cs, const float *wgt, const float *scale, const float *shift,
                                float *out, int out_cs, int N, int H, int W, m3d_stream_t stream)
 {
     M3D_REQUIRE(in && wgt && scale && shift && out && in_cs % 4 == 0 && out_cs % 4 == 0 && in_cs >= 16 && out_cs >= 16,
                 "conv3x3_c16: bad arguments");
-    hipLaunchKernelGGL(conv3x3_c16_kernel, dim3(cdiv(W, L0_TW), cdiv(H, L0_TH), N), dim3(256), 0, (hipStream_t)stream, in,
-                       in_cs, wgt, scale, shift, out, out_cs, H, W);
+    static int valu = -1;                        // tuning knob (experiments only): M3D_L0_VALU=1 selects the VALU kernel
+    if (valu < 0) { const char *e = getenv("M3D_L0_VALU"); valu = e ? atoi(e) : 0; }
+    const long long in_bytes = (long long)N * H * W * in_cs * 4;
+    if (!valu && in_bytes < (1ll << 31))
+        hipLaunchKernelGGL(conv3x3_c16_mfma_kernel, dim3(cdiv(W, L0M_TW), cdiv(H, L0M_TH), N), dim3(256), 0, (hipStream_t)stream,
+                           in, in_cs, (unsigned)in_bytes, wgt, scale, shift, out, out_cs, H, W);
+    else
+        hipLaunchKernelGGL(conv3x3_c16_kernel, dim3(cdiv(W, L0_TW), cdiv(H, L0_TH), N), dim3(256), 0, (hipStream_t)stream, in,
+                           in_cs, wgt, scale, shift, out, out_cs, H, W);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
 }
