@@ -226,6 +226,13 @@ int m3d_anab_pool_partial(const float *kv, int kv_cs, const float *s, int s_cs, 
 int m3d_anab_pool_finish(const float *partial, const int *bin_slots, const float *bin_inv_area, int n_bins,
                          int max_slots, int Ck, int Cv, float *khat, int keys_pad, int ck_pad, float *vhatT,
                          int B, m3d_stream_t stream);
+/* Both steps in one call for psp sizes (1, 4, 8, 16) on maps with H % 16 == 0 and W % 16 == 0, where the adaptive windows of
+ * the four scales nest: the features are read once instead of once per scale.  `scratch` holds
+ * m3d_anab_pool_nested_scratch_bytes(B, Ck + Cv) bytes; `s` = the 4 gate channels (scale order), bins in scale-major order
+ * (1 + 16 + 64 + 256 = 337 keys).  Same outputs as m3d_anab_pool_partial + m3d_anab_pool_finish up to fp32 summation order. */
+long long m3d_anab_pool_nested_scratch_bytes(int B, int C);
+int m3d_anab_pool_nested(const float *kv, int kv_cs, const float *s, int s_cs, int B, int H, int W, int Ck, int Cv,
+                         float *scratch, float *khat, int keys_pad, int ck_pad, float *vhatT, m3d_stream_t stream);
 /* In-place softmax over the first `valid` columns of each row; columns [valid, cs) are zeroed. */
 int m3d_softmax_rows(float *x, int rows, int valid, int cs, m3d_stream_t stream);
 

@@ -37,12 +37,78 @@ __global__ void anchor_select_kernel(const float *__restrict__ cls, int A, int N
     sel_prob[(size_t)b * HW + p] = best;
 }
 
+// 4-class fast path: 64 pixels x 4 anchor groups per workgroup (one wave per group, pixels along lanes -> 256-byte coalesced
+// loads), the anchors of a group unrolled by 3 so that 12 loads are in flight; the groups cover ascending anchor ranges and are
+// merged in that order with a strict '>' -> the same "lowest index wins" tie rule as the sequential kernel above, and each
+// fg value is computed by the same expression (bit-identical).  The one-thread-per-pixel loop above serialised 36 x 4
+// dependent load latencies on 960 waves (60 us for 35 MB).
+__global__ __launch_bounds__(256) void anchor_select4_kernel(const float *__restrict__ cls, int A, int HW, int *__restrict__ sel_idx,
+                                                             float *__restrict__ sel_prob, float *__restrict__ fg_all)
+{
+    __shared__ float sbest[4][64];
+    __shared__ int sidx[4][64];
+    const int b = blockIdx.y, g = threadIdx.x >> 6, lp = threadIdx.x & 63;
+    const int p = blockIdx.x * 64 + lp;
+    const bool pv = p < HW;
+    const int per = (A + 3) >> 2, a0 = g * per, a1 = min(A, a0 + per);
+    const float *base = cls + (size_t)b * 4 * A * HW + (pv ? p : 0);
+    float best = -1.f;
+    int bi = 0;
+    auto fg_of = [&](const float (&l)[4]) {
+        const float mx = fmaxf(fmaxf(fmaxf(l[0], l[1]), l[2]), l[3]);
+        float sum = 0.f, e0 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float e = expf(l[c] - mx);
+            if (c == 0) e0 = e;
+            sum += e;
+        }
+        return 1.f - e0 / sum;
+    };
+    int a = a0;
+    for (; a + 3 <= a1; a += 3) {
+        float l[3][4];
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) l[u][c] = base[(size_t)(c * A + a + u) * HW];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const float fg = fg_of(l[u]);
+            if (fg_all && pv) fg_all[((size_t)b * A + a + u) * HW + p] = fg;
+            if (fg > best) { best = fg; bi = a + u; }
+        }
+    }
+    for (; a < a1; ++a) {
+        float l[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) l[c] = base[(size_t)(c * A + a) * HW];
+        const float fg = fg_of(l);
+        if (fg_all && pv) fg_all[((size_t)b * A + a) * HW + p] = fg;
+        if (fg > best) { best = fg; bi = a; }
+    }
+    sbest[g][lp] = best;
+    sidx[g][lp] = bi;
+    __syncthreads();
+    if (g == 0 && pv) {
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if (sbest[k][lp] > best) { best = sbest[k][lp]; bi = sidx[k][lp]; }
+        sel_idx[(size_t)b * HW + p] = bi;
+        sel_prob[(size_t)b * HW + p] = best;
+    }
+}
+
 extern "C" int m3d_anchor_select(const float *cls_planar, int B, int A, int num_classes, int HW, int *sel_idx,
                                  float *sel_prob, float *fg_all, m3d_stream_t stream)
 {
     M3D_REQUIRE(cls_planar && sel_idx && sel_prob && num_classes >= 2 && num_classes <= 8, "anchor_select: bad arguments");
-    hipLaunchKernelGGL(anchor_select_kernel, dim3(cdiv(HW, 256), B), dim3(256), 0, (hipStream_t)stream, cls_planar, A,
-                       num_classes, HW, sel_idx, sel_prob, fg_all);
+    if (num_classes == 4 && A >= 4)
+        hipLaunchKernelGGL(anchor_select4_kernel, dim3(cdiv(HW, 64), B), dim3(256), 0, (hipStream_t)stream, cls_planar, A, HW,
+                           sel_idx, sel_prob, fg_all);
+    else
+        hipLaunchKernelGGL(anchor_select_kernel, dim3(cdiv(HW, 256), B), dim3(256), 0, (hipStream_t)stream, cls_planar, A,
+                           num_classes, HW, sel_idx, sel_prob, fg_all);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
 }
@@ -188,6 +254,83 @@ extern "C" int m3d_anab_pool_finish(const float *partial, const int *bin_slots, 
                 "anab_pool_finish: bad arguments");
     hipLaunchKernelGGL(anab_pool_finish_kernel, dim3(n_bins, B), dim3(256), 0, (hipStream_t)stream, partial, bin_slots,
                        bin_inv_area, n_bins, max_slots, Ck, Cv, khat, keys_pad, ck_pad, vhatT);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Nested fast path of the pyramid pooling for psp sizes (1, 4, 8, 16) on maps with H % 16 == 0 and W % 16 == 0 (the 48x160
+// map of the 1280x384 input): the adaptive windows of the four scales then nest exactly, so the features are read ONCE
+// (the generic item kernel above reads them once per scale: 291 MB instead of 73 MB at bs=8).  One workgroup per finest
+// bin (H/16 x W/16 pixels), one thread per channel, four gated sums per thread (one per scale) -> fine[B][256][4][C];
+// the finish kernel adds the fine partials of each coarse bin in row-major order (deterministic) and scatters into the
+// two GEMM operand layouts like anab_pool_finish_kernel.
+__global__ void anab_pool_nested_kernel(const float *__restrict__ kv, int kv_cs, const float *__restrict__ s, int s_cs,
+                                        float *__restrict__ fine, int H, int W, int C)
+{
+    const int fb = blockIdx.x, b = blockIdx.y;
+    const int bh = H >> 4, bw = W >> 4;
+    const int h0 = (fb >> 4) * bh, w0 = (fb & 15) * bw;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int h = h0; h < h0 + bh; ++h) {
+            const size_t prow = (size_t)(b * H + h) * W + w0;
+#pragma unroll 5
+            for (int w = 0; w < bw; ++w) {
+                const float x = kv[(prow + w) * kv_cs + c];
+                const float *g = s + (prow + w) * s_cs;
+                a0 = fmaf(x, g[0], a0);
+                a1 = fmaf(x, g[1], a1);
+                a2 = fmaf(x, g[2], a2);
+                a3 = fmaf(x, g[3], a3);
+            }
+        }
+        float *o = fine + (((size_t)b * 256 + fb) * 4) * C + c;
+        o[0] = a0; o[C] = a1; o[2 * (size_t)C] = a2; o[3 * (size_t)C] = a3;
+    }
+}
+
+__global__ void anab_pool_nested_finish_kernel(const float *__restrict__ fine, int H, int W, int Ck, int Cv,
+                                               float *__restrict__ khat, int keys_pad, int ck_pad, float *__restrict__ vhatT)
+{
+    const int bin = blockIdx.x, b = blockIdx.y;       // bins in scale-major order: 1 + 16 + 64 + 256
+    const int C = Ck + Cv;
+    int si, sz, local;
+    if (bin < 1) { si = 0; sz = 1; local = bin; }
+    else if (bin < 17) { si = 1; sz = 4; local = bin - 1; }
+    else if (bin < 81) { si = 2; sz = 8; local = bin - 17; }
+    else { si = 3; sz = 16; local = bin - 81; }
+    const int bi = local / sz, bj = local - bi * sz, f = 16 / sz;      // f x f finest bins per bin of this scale
+    const float inv = 1.f / (float)((H / sz) * (W / sz));
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = 0.f;
+        for (int di = 0; di < f; ++di)
+#pragma unroll 4
+            for (int dj = 0; dj < f; ++dj) {
+                const int fb = (bi * f + di) * 16 + bj * f + dj;
+                acc += fine[(((size_t)b * 256 + fb) * 4 + si) * C + c];
+            }
+        acc *= inv;
+        if (c < Ck) khat[((size_t)b * keys_pad + bin) * ck_pad + c] = acc;
+        else vhatT[((size_t)b * Cv + (c - Ck)) * keys_pad + bin] = acc;
+    }
+}
+
+extern "C" long long m3d_anab_pool_nested_scratch_bytes(int B, int C) { return (long long)B * 256 * 4 * C * 4; }
+
+extern "C" int m3d_anab_pool_nested(const float *kv, int kv_cs, const float *s, int s_cs, int B, int H, int W, int Ck, int Cv,
+                                    float *scratch, float *khat, int keys_pad, int ck_pad, float *vhatT, m3d_stream_t stream)
+{
+    M3D_REQUIRE(kv && s && scratch && khat && vhatT, "anab_pool_nested: null pointer");
+    M3D_REQUIRE(H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0, "anab_pool_nested: H and W must be multiples of 16 (got %dx%d)", H, W);
+    M3D_REQUIRE(keys_pad >= 337 && ck_pad >= Ck && s_cs >= 4, "anab_pool_nested: bad operand layout");
+    const int C = Ck + Cv;
+    const int threads = C <= 1024 ? ((C + 63) / 64) * 64 : 256;
+    hipLaunchKernelGGL(anab_pool_nested_kernel, dim3(256, B), dim3(threads), 0, (hipStream_t)stream, kv, kv_cs, s, s_cs, scratch,
+                       H, W, C);
+    M3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(anab_pool_nested_finish_kernel, dim3(337, B), dim3(256), 0, (hipStream_t)stream, scratch, H, W, Ck, Cv,
+                       khat, keys_pad, ck_pad, vhatT);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
 }

@@ -121,6 +121,7 @@ def pack_wino(weight, cout_pad, device):
 
 
 WINO_MIN_BLOCKS = int(os.environ.get("M3D_WINO_MIN_BLOCKS", "128"))
+USE_ANAB_NESTED = os.environ.get("M3D_ANAB_NESTED", "1") != "0"
 USE_DCN_WAVE = os.environ.get("M3D_DCN_WAVE", "1") != "0"
 USE_CONV_WAVE = os.environ.get("M3D_CONV_WAVE", "1") != "0"
 USE_WINO = os.environ.get("M3D_WINO", "1") != "0"
@@ -621,12 +622,20 @@ class Engine:
         plan.keep += [d_items, d_bscale, d_bslots, d_binv, partial, khat, vhatT]
         plan.named["anab.khat"], plan.named["anab.vhatT"] = khat, vhatT
         kvv, sv = qkvs.slice(off["k"], ckv), qkvs.slice(off["s"], self.ns)
-        self._op(plan, "anab.pool_partial", "anab_pool", lambda st: _hip.check(L.m3d_anab_pool_partial(
-            kvv.ptr, kvv.cs, sv.ptr, sv.cs, d_items.data_ptr(), items.shape[0], d_bscale.data_ptr(), n_bins,
-            partial.data_ptr(), max_slots, B, fh, fw, ckv, st)))
-        self._op(plan, "anab.pool_finish", "anab_pool", lambda st: _hip.check(L.m3d_anab_pool_finish(
-            partial.data_ptr(), d_bslots.data_ptr(), d_binv.data_ptr(), n_bins, max_slots, self.ck, self.cv,
-            khat.data_ptr(), keys_pad, self.ck_pad, vhatT.data_ptr(), B, st)))
+        if fh % 16 == 0 and fw % 16 == 0 and PSP_SIZES == (1, 4, 8, 16) and USE_ANAB_NESTED:
+            # the windows of the four scales nest: one pass over the features (csrc/rpn_kernels.hip)
+            scratch = torch.empty(L.m3d_anab_pool_nested_scratch_bytes(B, ckv) // 4, device=self.device, dtype=torch.float32)
+            plan.keep.append(scratch)
+            self._op(plan, "anab.pool_nested", "anab_pool", lambda st: _hip.check(L.m3d_anab_pool_nested(
+                kvv.ptr, kvv.cs, sv.ptr, sv.cs, B, fh, fw, self.ck, self.cv, scratch.data_ptr(), khat.data_ptr(), keys_pad,
+                self.ck_pad, vhatT.data_ptr(), st)))
+        else:
+            self._op(plan, "anab.pool_partial", "anab_pool", lambda st: _hip.check(L.m3d_anab_pool_partial(
+                kvv.ptr, kvv.cs, sv.ptr, sv.cs, d_items.data_ptr(), items.shape[0], d_bscale.data_ptr(), n_bins,
+                partial.data_ptr(), max_slots, B, fh, fw, ckv, st)))
+            self._op(plan, "anab.pool_finish", "anab_pool", lambda st: _hip.check(L.m3d_anab_pool_finish(
+                partial.data_ptr(), d_bslots.data_ptr(), d_binv.data_ptr(), n_bins, max_slots, self.ck, self.cv,
+                khat.data_ptr(), keys_pad, self.ck_pad, vhatT.data_ptr(), B, st)))
         logits = self._buf(plan, B, fh, fw, keys_pad)
         qv = qkvs.slice(off["q"], self.ck_pad)
         self._conv(plan, "anab.logits", None, qv, logits, 1, 0, act=0, affine=False, wgt_ptr=khat.data_ptr(),

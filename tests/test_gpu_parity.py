@@ -533,6 +533,50 @@ def test_dcn_wave_kernel_matches_block_kernel_and_oracle(shape, deform):
     assert L.m3d_conv_wave_applicable(ctypes.byref(d)) == 0 and L.m3d_conv_wave_forward(ctypes.byref(d), S._stream()) != 0
 
 
+def test_anab_nested_pooling_matches_generic_pooling():
+    """m3d_anab_pool_nested (one pass, nested windows) vs m3d_anab_pool_partial + m3d_anab_pool_finish (one pass per scale) on a
+    32x48 map, and vs torch adaptive_avg_pool2d of the gated features (attention.py:136-147)."""
+    from m3dssd_amd import _hip
+    from m3dssd_amd.engine import Engine
+    dev = _dev()
+    L = _hip.lib()
+    B, H, W, ck, cv = 2, 32, 48, 40, 24
+    C = ck + cv
+    g = torch.Generator().manual_seed(11)
+    kv = torch.randn(B, H, W, C, generator=g).to(dev)
+    gate = torch.rand(B, H, W, 4, generator=g).to(dev)
+    items, bin_scale, bin_slots, bin_inv = Engine._anab_items(H, W)
+    n_bins, max_slots, keys_pad, ck_pad = len(bin_scale), int(bin_slots.max()), 352, 64
+    d_items, d_bs = torch.from_numpy(items).to(dev), torch.from_numpy(bin_scale).to(dev)
+    d_sl, d_inv = torch.from_numpy(bin_slots).to(dev), torch.from_numpy(bin_inv).to(dev)
+    partial = torch.empty(B * n_bins * max_slots * C, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for nested in (0, 1):
+        khat = torch.zeros(B, keys_pad, ck_pad, device=dev)
+        vhatT = torch.zeros(B, cv, keys_pad, device=dev)
+        if nested:
+            scratch = torch.empty(L.m3d_anab_pool_nested_scratch_bytes(B, C) // 4, device=dev)
+            _hip.check(L.m3d_anab_pool_nested(kv.data_ptr(), C, gate.data_ptr(), 4, B, H, W, ck, cv, scratch.data_ptr(),
+                                              khat.data_ptr(), keys_pad, ck_pad, vhatT.data_ptr(), st))
+        else:
+            _hip.check(L.m3d_anab_pool_partial(kv.data_ptr(), C, gate.data_ptr(), 4, d_items.data_ptr(), items.shape[0],
+                                               d_bs.data_ptr(), n_bins, partial.data_ptr(), max_slots, B, H, W, C, st))
+            _hip.check(L.m3d_anab_pool_finish(partial.data_ptr(), d_sl.data_ptr(), d_inv.data_ptr(), n_bins, max_slots, ck, cv,
+                                              khat.data_ptr(), keys_pad, ck_pad, vhatT.data_ptr(), B, st))
+        outs.append((khat.cpu(), vhatT.cpu()))
+    assert n_bins == 337
+    x = kv.permute(0, 3, 1, 2).cpu()
+    gt = gate.permute(0, 3, 1, 2).cpu()
+    ref = torch.cat([F.adaptive_avg_pool2d(x * gt[:, si:si + 1], sz).flatten(2) for si, sz in enumerate((1, 4, 8, 16))], 2)
+    for khat, vhatT in outs:
+        assert (khat[:, :337, :ck] - ref[:, :ck].transpose(1, 2)).abs().max().item() < 2e-6
+        assert (vhatT[:, :, :337] - ref[:, ck:]).abs().max().item() < 2e-6
+    assert (outs[0][0] - outs[1][0]).abs().max().item() < 1e-6 and (outs[0][1] - outs[1][1]).abs().max().item() < 1e-6
+    assert L.m3d_anab_pool_nested(kv.data_ptr(), C, gate.data_ptr(), 4, B, 24, 40, ck, cv, partial.data_ptr(),
+                                  outs[0][0].data_ptr(), keys_pad, ck_pad, outs[0][1].data_ptr(), st) != 0   # 24x40 does not nest
+
+
 # ------------------------------------------------------------------------------------ fused head + graph
 def _head_case(seed, cin, cout, cpad, dev, n=2, h=13, w=21):
     """One 3-/2-layer head: returns (MlpDesc, device output, torch reference, keep-alive list)."""
