@@ -107,8 +107,8 @@ int m3d_conv2d_splitk_plan(const m3d_conv_desc *d, int *splits, long long *ws_by
  * (dcn_offmask optional), except that `wgt` is the packed [Cout_pad, kh*kw*Cin] matrix in MFMA-fragment order
  * [Cout_pad/32][kh*kw*Cin/8][h=2][r=32][t=4].  Each wave owns 32 pixels x 128 channels and works alone (no workgroup
  * barrier).  m3d_conv_wave_applicable returns the number of waves the layer yields, or 0 when it does not apply
- * (needs Cin % 32 == 0, in_cs % 32 == 0, 128-byte aligned input, Cout_pad % 128 == 0, NHWC output, shared weights,
- * no sigmoid channels) or when there are too few waves to fill the chip; the caller then stays on m3d_conv2d_forward. */
+ * (needs Cin % 32 == 0, in_cs % 32 == 0, 128-byte aligned input, Cout_pad % 128 == 0, NHWC output; per-image weights
+ * -- wgt_img_stride in floats between fragment-packed sets -- need Ho*Wo % 32 == 0) or when there are too few waves to fill the chip; the caller then stays on m3d_conv2d_forward. */
 int m3d_conv_wave_applicable(const m3d_conv_desc *d);
 /* Thin layers (too few 32 x 128 tiles) can still take this path split along K across waves: *splits and the scratch bytes to
  * pass through splitk_ws / splitk_ws_bytes (partials are reduced in split order by a second launch, which applies the
@@ -225,14 +225,16 @@ int m3d_anab_pool_partial(const float *kv, int kv_cs, const float *s, int s_cs, 
  *   vhatT[B][Cv][keys_pad]      (row = channel, col = key j)   -- "weights" of the P.V GEMM   */
 int m3d_anab_pool_finish(const float *partial, const int *bin_slots, const float *bin_inv_area, int n_bins,
                          int max_slots, int Ck, int Cv, float *khat, int keys_pad, int ck_pad, float *vhatT,
-                         int B, m3d_stream_t stream);
-/* Both steps in one call for psp sizes (1, 4, 8, 16) on maps with H % 16 == 0 and W % 16 == 0, where the adaptive windows of
+                         int B, int frag, m3d_stream_t stream);
+/* (frag bit 0 / bit 1 in either finish: khat / vhatT is written in MFMA-fragment order [R/32][K/8][2][32][4], the `wgt` layout of
+ * m3d_conv_wave_forward, instead of row-major.)
+ * Both steps in one call for psp sizes (1, 4, 8, 16) on maps with H % 16 == 0 and W % 16 == 0, where the adaptive windows of
  * the four scales nest: the features are read once instead of once per scale.  `scratch` holds
  * m3d_anab_pool_nested_scratch_bytes(B, Ck + Cv) bytes; `s` = the 4 gate channels (scale order), bins in scale-major order
  * (1 + 16 + 64 + 256 = 337 keys).  Same outputs as m3d_anab_pool_partial + m3d_anab_pool_finish up to fp32 summation order. */
 long long m3d_anab_pool_nested_scratch_bytes(int B, int C);
 int m3d_anab_pool_nested(const float *kv, int kv_cs, const float *s, int s_cs, int B, int H, int W, int Ck, int Cv,
-                         float *scratch, float *khat, int keys_pad, int ck_pad, float *vhatT, m3d_stream_t stream);
+                         float *scratch, float *khat, int keys_pad, int ck_pad, float *vhatT, int frag, m3d_stream_t stream);
 /* In-place softmax over the first `valid` columns of each row; columns [valid, cs) are zeroed. */
 int m3d_softmax_rows(float *x, int rows, int valid, int cs, m3d_stream_t stream);
 

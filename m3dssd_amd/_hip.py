@@ -76,9 +76,9 @@ SIGNATURES = {
     "m3d_fg_top1": (c_int, [P, c_int, c_int, c_int, P, P, P]),
     "m3d_align_offsets": (c_int, [c_int, P, P, c_float, P, P, P, P] + [c_float] * 4 + [P] + [c_int] * 5 + [c_ll, P]),
     "m3d_anab_pool_partial": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P] + [c_int] * 5 + [P]),
-    "m3d_anab_pool_finish": (c_int, [P, P, P] + [c_int] * 4 + [P, c_int, c_int, P, c_int, P]),
+    "m3d_anab_pool_finish": (c_int, [P, P, P] + [c_int] * 4 + [P, c_int, c_int, P, c_int, c_int, P]),
     "m3d_anab_pool_nested_scratch_bytes": (c_ll, [c_int, c_int]),
-    "m3d_anab_pool_nested": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P, P]),
+    "m3d_anab_pool_nested": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P, c_int, P]),
     "m3d_softmax_rows": (c_int, [P, c_int, c_int, c_int, P]),
     "m3d_bundle_outputs": (c_int, [P] * 7 + [c_int] * 3 + [P]),
     "m3d_decode_rows": (c_int, [P] * 9 + [c_int] * 3 + [P]),

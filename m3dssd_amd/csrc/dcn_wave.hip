@@ -28,7 +28,8 @@ struct ConvWaveArgs {
     int H, W, Cin, Ho, Wo, HoWo, Cout;
     int kh, kw, stride, pad, dil;
     int M, KG, tiles_n;
-    int act, res_mode;
+    int act, res_mode, sigmoid_from;
+    long long w_img_stride;        // floats between the per-image weight sets (0: shared weights)
     unsigned in_bytes, out_bytes, res_bytes, w_bytes;
     // split-K across waves (layers with too few 32 x 128 tiles): grid = splits x tiles, split s covers steps
     // [s*ss_per, (s+1)*ss_per) and stores raw partial sums to ws[s][M][Cout_pad]; m3d_launch_splitk_reduce finishes
@@ -79,7 +80,9 @@ __global__ __launch_bounds__(64) void conv_wave_kernel(const ConvWaveArgs a)
     const int ss0 = split * a.ss_per, ss1 = min(KK * C32, ss0 + a.ss_per);        // this wave's steps
 
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wfrag + (size_t)bn * NT * a.KG * 256, a.w_bytes);
+    // per-image weights (the ANAB logits / P.V GEMMs): the 32 pixels of a wave belong to one image (HoWo % 32 == 0)
+    const __amdgpu_buffer_rsrc_t rw =
+        make_rsrc(a.wfrag + (size_t)(m0 / a.HoWo) * a.w_img_stride + (size_t)bn * NT * a.KG * 256, a.w_bytes);
     const unsigned wlane = (unsigned)lane * 16u;
     const unsigned wstride = (unsigned)a.KG * 1024u;              // bytes between column tiles
 
@@ -300,7 +303,8 @@ __global__ __launch_bounds__(64) void conv_wave_kernel(const ConvWaveArgs a)
             float v = acc[nt][r];
             if (a.res) v = a.res_mode ? (v + rv[r]) * sc + sh : v * sc + sh + rv[r];
             else v = v * sc + sh;
-            if (a.act == 1) v = fmaxf(v, v * M3D_LEAKY_SLOPE);
+            if (a.sigmoid_from >= 0 && co >= a.sigmoid_from) v = sigmoidf_(v);
+            else if (a.act == 1) v = fmaxf(v, v * M3D_LEAKY_SLOPE);
             const unsigned oo = (cok && m < a.M) ? ((unsigned)m * (unsigned)a.out_cs + (unsigned)co) * 4u : M3D_BUF_OOB;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, oo, 0, 0);
         }
@@ -316,8 +320,9 @@ static int conv_wave_plan(const m3d_conv_desc *d, bool enforce_min, int *splits,
 {
     *splits = 1;
     *ss_per = d->kh * d->kw * (d->Cin / 32);
-    if (d->out_nchw || d->wgt_img_stride || d->sigmoid_from >= 0) return 0;
+    if (d->out_nchw) return 0;
     if (d->Cin % 32 != 0 || d->Cout_pad % 128 != 0) return 0;
+    if (d->wgt_img_stride && (d->Ho * d->Wo) % 32 != 0) return 0;
     const long long M = (long long)d->N * d->Ho * d->Wo;
     const long long base = ((M + 31) / 32) * (d->Cout_pad / 128);
     if (base >= (1ll << 28)) return 0;
@@ -367,13 +372,15 @@ extern "C" int m3d_conv_wave_forward(const m3d_conv_desc *d, m3d_stream_t stream
     M3D_REQUIRE(d && d->in && d->wgt && d->out, "conv_wave: null pointer");
     int splits = 1, ss_per = 0;
     const int waves = conv_wave_plan(d, false, &splits, &ss_per);       // the fill heuristic is advisory here
-    M3D_REQUIRE(waves > 0, "conv_wave: needs Cin %% 32 == 0, Cout_pad %% 128 == 0, NHWC output, shared weights, no sigmoid");
+    M3D_REQUIRE(waves > 0, "conv_wave: needs Cin %% 32 == 0, Cout_pad %% 128 == 0, NHWC output, Ho*Wo %% 32 == 0 with per-image weights");
     const int ho = (d->H + 2 * d->pad - (d->dil * (d->kh - 1) + 1)) / d->stride + 1;
     const int wo = (d->W + 2 * d->pad - (d->dil * (d->kw - 1) + 1)) / d->stride + 1;
     M3D_REQUIRE(ho == d->Ho && wo == d->Wo, "conv_wave: Ho/Wo mismatch");
     M3D_REQUIRE(d->in_cs % 32 == 0 && d->in_cs >= d->Cin && ((uintptr_t)d->in & 127) == 0 && ((uintptr_t)d->wgt & 15) == 0,
                 "conv_wave: the input view must be 128-byte aligned with in_cs %% 32 == 0");
     const long long M = (long long)d->N * d->Ho * d->Wo;
+    M3D_REQUIRE(!d->wgt_img_stride || (d->wgt_img_stride % 4 == 0 && d->stride == 1 && d->Ho == d->H && d->Wo == d->W),
+                "conv_wave: per-image weights need an image-aligned 16-byte stride and a same-size output");
     M3D_REQUIRE((long long)d->N * d->H * d->W * d->in_cs * 4 < (1ll << 31) && M * d->out_cs * 4 < (1ll << 31) &&
                 M * d->res_cs * 4 < (1ll << 31) && (long long)d->Cout_pad * d->kh * d->kw * d->Cin * 4 < (1ll << 31),
                 "conv_wave: views must be < 2 GiB");
@@ -384,7 +391,7 @@ extern "C" int m3d_conv_wave_forward(const m3d_conv_desc *d, m3d_stream_t stream
     a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.HoWo = d->Ho * d->Wo; a.Cout = d->Cout;
     a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
     a.M = (int)M; a.KG = d->kh * d->kw * d->Cin / 8; a.tiles_n = d->Cout_pad / 128;
-    a.act = d->act; a.res_mode = d->res_mode;
+    a.act = d->act; a.res_mode = d->res_mode; a.sigmoid_from = d->sigmoid_from; a.w_img_stride = d->wgt_img_stride;
     a.in_bytes = (unsigned)((long long)d->N * d->H * d->W * d->in_cs * 4);
     a.out_bytes = (unsigned)(M * d->out_cs * 4);
     a.res_bytes = (unsigned)(M * d->res_cs * 4);
@@ -407,7 +414,7 @@ extern "C" int m3d_conv_wave_forward(const m3d_conv_desc *d, m3d_stream_t stream
         SplitkReduceArgs r;
         r.ws = a.ws; r.scale = d->scale; r.shift = d->shift; r.res = d->res; r.out = d->out;
         r.M = (int)M; r.Cout = d->Cout; r.Cout_pad = d->Cout_pad; r.splits = splits; r.out_cs = d->out_cs; r.res_cs = d->res_cs;
-        r.res_mode = d->res_mode; r.act = d->act; r.sigmoid_from = -1;
+        r.res_mode = d->res_mode; r.act = d->act; r.sigmoid_from = d->sigmoid_from;
         return m3d_launch_splitk_reduce(r, stream);
     }
     return M3D_OK;

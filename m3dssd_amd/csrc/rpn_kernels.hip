@@ -225,12 +225,20 @@ extern "C" int m3d_anab_pool_partial(const float *kv, int kv_cs, const float *s,
     return M3D_OK;
 }
 
-// Sum the slots of each bin in order, scale by 1/area, scatter into the two GEMM operand layouts.
+// Position of weight element (row, k) of an [R][K] matrix in MFMA-fragment order [R/32][K/8][h=2][r=32][t=4] (what
+// m3d_conv_wave_forward / m3d_head_mlp_forward take as `wgt`; m3dssd_amd.engine.pack_frag on the host).
+__device__ __forceinline__ size_t frag_index(int row, int k, int K)
+{
+    return ((size_t)((row >> 5) * (K >> 3) + (k >> 3)) * 64 + ((k >> 2) & 1) * 32 + (row & 31)) * 4 + (k & 3);
+}
+
+// Sum the slots of each bin in order, scale by 1/area, scatter into the two GEMM operand layouts (row-major
+// khat[keys_pad][ck_pad], vhatT[Cv][keys_pad], or -- frag != 0 -- the same two matrices in MFMA-fragment order; frag bit 0 = khat, bit 1 = vhatT).
 // channels [0, Ck) are keys, [Ck, Ck+Cv) values.
 __global__ void anab_pool_finish_kernel(const float *__restrict__ partial, const int *__restrict__ bin_slots,
                                         const float *__restrict__ bin_inv_area, int n_bins, int max_slots, int Ck,
                                         int Cv, float *__restrict__ khat, int keys_pad, int ck_pad,
-                                        float *__restrict__ vhatT)
+                                        float *__restrict__ vhatT, int frag)
 {
     const int bin = blockIdx.x, b = blockIdx.y;
     const int C = Ck + Cv;
@@ -241,19 +249,26 @@ __global__ void anab_pool_finish_kernel(const float *__restrict__ partial, const
         float acc = 0.f;
         for (int sl = 0; sl < ns; ++sl) acc += pp[(size_t)sl * C];
         acc *= inv;
-        if (c < Ck) khat[((size_t)b * keys_pad + bin) * ck_pad + c] = acc;
-        else vhatT[((size_t)b * Cv + (c - Ck)) * keys_pad + bin] = acc;
+        if (c < Ck) {
+            if (frag & 1) khat[(size_t)b * keys_pad * ck_pad + frag_index(bin, c, ck_pad)] = acc;
+            else khat[((size_t)b * keys_pad + bin) * ck_pad + c] = acc;
+        } else {
+            if (frag & 2) vhatT[(size_t)b * Cv * keys_pad + frag_index(c - Ck, bin, keys_pad)] = acc;
+            else vhatT[((size_t)b * Cv + (c - Ck)) * keys_pad + bin] = acc;
+        }
     }
 }
 
 extern "C" int m3d_anab_pool_finish(const float *partial, const int *bin_slots, const float *bin_inv_area, int n_bins,
                                     int max_slots, int Ck, int Cv, float *khat, int keys_pad, int ck_pad, float *vhatT,
-                                    int B, m3d_stream_t stream)
+                                    int B, int frag, m3d_stream_t stream)
 {
     M3D_REQUIRE(partial && bin_slots && bin_inv_area && khat && vhatT && keys_pad >= n_bins && ck_pad >= Ck,
                 "anab_pool_finish: bad arguments");
+    M3D_REQUIRE(!frag || (keys_pad % 32 == 0 && ck_pad % 8 == 0 && Cv % 32 == 0), "anab_pool_finish: fragment layout needs "
+                "keys_pad %% 32 == 0, ck_pad %% 8 == 0, Cv %% 32 == 0");
     hipLaunchKernelGGL(anab_pool_finish_kernel, dim3(n_bins, B), dim3(256), 0, (hipStream_t)stream, partial, bin_slots,
-                       bin_inv_area, n_bins, max_slots, Ck, Cv, khat, keys_pad, ck_pad, vhatT);
+                       bin_inv_area, n_bins, max_slots, Ck, Cv, khat, keys_pad, ck_pad, vhatT, frag);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
 }
@@ -291,7 +306,8 @@ __global__ void anab_pool_nested_kernel(const float *__restrict__ kv, int kv_cs,
 }
 
 __global__ void anab_pool_nested_finish_kernel(const float *__restrict__ fine, int H, int W, int Ck, int Cv,
-                                               float *__restrict__ khat, int keys_pad, int ck_pad, float *__restrict__ vhatT)
+                                               float *__restrict__ khat, int keys_pad, int ck_pad, float *__restrict__ vhatT,
+                                               int frag)
 {
     const int bin = blockIdx.x, b = blockIdx.y;       // bins in scale-major order: 1 + 16 + 64 + 256
     const int C = Ck + Cv;
@@ -311,16 +327,24 @@ __global__ void anab_pool_nested_finish_kernel(const float *__restrict__ fine, i
                 acc += fine[(((size_t)b * 256 + fb) * 4 + si) * C + c];
             }
         acc *= inv;
-        if (c < Ck) khat[((size_t)b * keys_pad + bin) * ck_pad + c] = acc;
-        else vhatT[((size_t)b * Cv + (c - Ck)) * keys_pad + bin] = acc;
+        if (c < Ck) {
+            if (frag & 1) khat[(size_t)b * keys_pad * ck_pad + frag_index(bin, c, ck_pad)] = acc;
+            else khat[((size_t)b * keys_pad + bin) * ck_pad + c] = acc;
+        } else {
+            if (frag & 2) vhatT[(size_t)b * Cv * keys_pad + frag_index(c - Ck, bin, keys_pad)] = acc;
+            else vhatT[((size_t)b * Cv + (c - Ck)) * keys_pad + bin] = acc;
+        }
     }
 }
 
 extern "C" long long m3d_anab_pool_nested_scratch_bytes(int B, int C) { return (long long)B * 256 * 4 * C * 4; }
 
 extern "C" int m3d_anab_pool_nested(const float *kv, int kv_cs, const float *s, int s_cs, int B, int H, int W, int Ck, int Cv,
-                                    float *scratch, float *khat, int keys_pad, int ck_pad, float *vhatT, m3d_stream_t stream)
+                                    float *scratch, float *khat, int keys_pad, int ck_pad, float *vhatT, int frag,
+                                    m3d_stream_t stream)
 {
+    M3D_REQUIRE(!frag || (keys_pad % 32 == 0 && ck_pad % 8 == 0 && Cv % 32 == 0), "anab_pool_nested: fragment layout needs "
+                "keys_pad %% 32 == 0, ck_pad %% 8 == 0, Cv %% 32 == 0");
     M3D_REQUIRE(kv && s && scratch && khat && vhatT, "anab_pool_nested: null pointer");
     M3D_REQUIRE(H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0, "anab_pool_nested: H and W must be multiples of 16 (got %dx%d)", H, W);
     M3D_REQUIRE(keys_pad >= 337 && ck_pad >= Ck && s_cs >= 4, "anab_pool_nested: bad operand layout");
@@ -330,7 +354,7 @@ extern "C" int m3d_anab_pool_nested(const float *kv, int kv_cs, const float *s, 
                        H, W, C);
     M3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(anab_pool_nested_finish_kernel, dim3(337, B), dim3(256), 0, (hipStream_t)stream, scratch, H, W, Ck, Cv,
-                       khat, keys_pad, ck_pad, vhatT);
+                       khat, keys_pad, ck_pad, vhatT, frag);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
 }

@@ -121,6 +121,7 @@ def pack_wino(weight, cout_pad, device):
 
 
 WINO_MIN_BLOCKS = int(os.environ.get("M3D_WINO_MIN_BLOCKS", "128"))
+USE_ANAB_WAVE = os.environ.get("M3D_ANAB_WAVE", "1") != "0"
 USE_ANAB_NESTED = os.environ.get("M3D_ANAB_NESTED", "1") != "0"
 USE_DCN_WAVE = os.environ.get("M3D_DCN_WAVE", "1") != "0"
 USE_CONV_WAVE = os.environ.get("M3D_CONV_WAVE", "1") != "0"
@@ -286,7 +287,7 @@ class Engine:
 
     def _conv(self, plan, name, pc, x, out, stride=1, pad=0, act=0, res=None, res_mode=0, sigmoid_from=-1, om=None,
               planar=None, affine=True, wgt_ptr=None, wgt_img_stride=0, cout=None, cout_pad=None, scale=None, shift=None,
-              kh=None, kw=None, cin_true=None):
+              kh=None, kw=None, cin_true=None, wgt_frag=False):
         d = ConvDesc()
         d.inp, d.in_cs, d.N, d.H, d.W, d.Cin = x.ptr, x.cs, x.n, x.h, x.w, x.c
         kh = pc.kh if kh is None else kh
@@ -330,6 +331,13 @@ class Engine:
             return
         flops_true = 2.0 * x.n * d.Ho * d.Wo * d.Cout * kh * kw * (
             cin_true if cin_true is not None else (pc.cin if (pc is not None and wgt_ptr is None) else x.c))
+        if wgt_frag:
+            # explicit fragment-ordered (per-image) weights: the caller has already decided for the wave-granular kernel
+            assert wgt_ptr is not None and planar is None and x.cs % 32 == 0 and x.ptr % 128 == 0, name
+            if L.m3d_conv_wave_applicable(ref) <= 0:
+                raise RuntimeError("%s: fragment-ordered weights but the wave kernel does not apply" % name)
+            plan.ops.append((name, "conv_wave", flops_true, lambda st: _hip.check(L.m3d_conv_wave_forward(ref, st)), d))
+            return
         if (pc is not None and wgt_ptr is None and planar is None and (USE_DCN_WAVE if om is not None else USE_CONV_WAVE)
                 and x.cs % 32 == 0 and x.ptr % 128 == 0 and pc.cin_pad == x.c):
             # wave-granular kernel, no workgroup barriers (csrc/dcn_wave.hip); thin layers are split along K across waves
@@ -606,11 +614,18 @@ class Engine:
         B, fh, fw = x.n, x.h, x.w
         HW = fh * fw
         ctot, off = self.anab_ctot, self.anab_off
-        qkvs = self._buf(plan, B, fh, fw, ctot, _rup(ctot, 4))
+        qkvs = self._buf(plan, B, fh, fw, ctot, _rup(ctot, 32))          # 128-byte pixel rows: the wave kernel's gather map
         self._conv(plan, "anab.qkvs", P["anab.qkvs"], x, qkvs, 1, 0, act=0, sigmoid_from=off["s"], affine=False)
         items, bin_scale, bin_slots, bin_inv = self._anab_items(fh, fw)
         n_bins, max_slots = len(bin_scale), int(bin_slots.max())
-        keys_pad = _rup(n_bins, 32)
+        # the two per-image GEMMs go to the wave-granular kernel when they yield enough waves; their weights (pooled keys /
+        # values) are then written in MFMA-fragment order by the pooling finish and the key count is padded to 128
+        wave_ok = USE_ANAB_WAVE and USE_CONV_WAVE and HW % 32 == 0 and self.ck_pad % 32 == 0 and self.cv % 128 == 0
+        nw = B * HW // 32
+        wave_logits = wave_ok and nw * (_rup(n_bins, 128) // 128) >= 900
+        keys_pad = _rup(n_bins, 128) if wave_logits else _rup(n_bins, 32)
+        wave_pv = wave_ok and keys_pad % 32 == 0 and nw * (self.cv // 128) >= 900
+        frag = (1 if wave_logits else 0) | (2 if wave_pv else 0)
         d_items = torch.from_numpy(items).to(self.device)
         d_bscale = torch.from_numpy(bin_scale).to(self.device)
         d_bslots = torch.from_numpy(bin_slots).to(self.device)
@@ -628,23 +643,24 @@ class Engine:
             plan.keep.append(scratch)
             self._op(plan, "anab.pool_nested", "anab_pool", lambda st: _hip.check(L.m3d_anab_pool_nested(
                 kvv.ptr, kvv.cs, sv.ptr, sv.cs, B, fh, fw, self.ck, self.cv, scratch.data_ptr(), khat.data_ptr(), keys_pad,
-                self.ck_pad, vhatT.data_ptr(), st)))
+                self.ck_pad, vhatT.data_ptr(), frag, st)))
         else:
             self._op(plan, "anab.pool_partial", "anab_pool", lambda st: _hip.check(L.m3d_anab_pool_partial(
                 kvv.ptr, kvv.cs, sv.ptr, sv.cs, d_items.data_ptr(), items.shape[0], d_bscale.data_ptr(), n_bins,
                 partial.data_ptr(), max_slots, B, fh, fw, ckv, st)))
             self._op(plan, "anab.pool_finish", "anab_pool", lambda st: _hip.check(L.m3d_anab_pool_finish(
                 partial.data_ptr(), d_bslots.data_ptr(), d_binv.data_ptr(), n_bins, max_slots, self.ck, self.cv,
-                khat.data_ptr(), keys_pad, self.ck_pad, vhatT.data_ptr(), B, st)))
+                khat.data_ptr(), keys_pad, self.ck_pad, vhatT.data_ptr(), B, frag, st)))
         logits = self._buf(plan, B, fh, fw, keys_pad)
         qv = qkvs.slice(off["q"], self.ck_pad)
         self._conv(plan, "anab.logits", None, qv, logits, 1, 0, act=0, affine=False, wgt_ptr=khat.data_ptr(),
-                   wgt_img_stride=keys_pad * self.ck_pad, cout=n_bins, cout_pad=keys_pad, kh=1, kw=1, cin_true=self.ck)
+                   wgt_img_stride=keys_pad * self.ck_pad, cout=n_bins, cout_pad=keys_pad, kh=1, kw=1, cin_true=self.ck,
+                   wgt_frag=wave_logits)
         self._op(plan, "anab.softmax", "softmax", lambda st: _hip.check(L.m3d_softmax_rows(
             logits.ptr, B * HW, n_bins, keys_pad, st)))
         self._conv(plan, "anab.pv", None, logits, out, 1, 0, act=act, res=x, res_mode=res_mode,
                    wgt_ptr=vhatT.data_ptr(), wgt_img_stride=self.cv * keys_pad, cout=self.cv,
-                   cout_pad=_rup(self.cv, 32), kh=1, kw=1, scale=scale, shift=shift, cin_true=n_bins)
+                   cout_pad=_rup(self.cv, 32), kh=1, kw=1, scale=scale, shift=shift, cin_true=n_bins, wgt_frag=wave_pv)
 
     @classmethod
     def anab_standalone(cls, mod, x):

@@ -529,8 +529,16 @@ def test_dcn_wave_kernel_matches_block_kernel_and_oracle(shape, deform):
         d.splitk_ws_bytes = 64
         assert L.m3d_conv_wave_forward(ctypes.byref(d), S._stream()) != 0 and b"workspace" in L.m3d_last_error()
     d.splitk_ws, d.splitk_ws_bytes = None, 0
-    d.sigmoid_from = 3                                   # not supported here: refused, the caller stays on the igemm
-    assert L.m3d_conv_wave_applicable(ctypes.byref(d)) == 0 and L.m3d_conv_wave_forward(ctypes.byref(d), S._stream()) != 0
+    # sigmoid on channels >= 3 instead of the activation (the fused Q|K|V|S conv of ANAB): same epilogue as the block kernel
+    d.sigmoid_from = 3
+    out.zero_()
+    _hip.check(L.m3d_conv_wave_forward(ctypes.byref(d), S._stream()))
+    out_sg, _k = S.conv_nhwc(v, wt.to(dev), b.to(dev), None, stride, pad, act=1, res=rv, om=om if deform else None,
+                             cout_pad_to=128, sigmoid_from=3)
+    sg_blk = S._to_nchw(out_sg, co).cpu()
+    sg_wave = out.view(n, ho, wo, co).permute(0, 3, 1, 2).cpu()
+    assert (sg_wave - sg_blk).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    assert (sg_wave[:, 3:] >= 0).all() and (sg_wave[:, 3:] <= 1).all()
 
 
 def test_anab_nested_pooling_matches_generic_pooling():
@@ -558,12 +566,12 @@ def test_anab_nested_pooling_matches_generic_pooling():
         if nested:
             scratch = torch.empty(L.m3d_anab_pool_nested_scratch_bytes(B, C) // 4, device=dev)
             _hip.check(L.m3d_anab_pool_nested(kv.data_ptr(), C, gate.data_ptr(), 4, B, H, W, ck, cv, scratch.data_ptr(),
-                                              khat.data_ptr(), keys_pad, ck_pad, vhatT.data_ptr(), st))
+                                              khat.data_ptr(), keys_pad, ck_pad, vhatT.data_ptr(), 0, st))
         else:
             _hip.check(L.m3d_anab_pool_partial(kv.data_ptr(), C, gate.data_ptr(), 4, d_items.data_ptr(), items.shape[0],
                                                d_bs.data_ptr(), n_bins, partial.data_ptr(), max_slots, B, H, W, C, st))
             _hip.check(L.m3d_anab_pool_finish(partial.data_ptr(), d_sl.data_ptr(), d_inv.data_ptr(), n_bins, max_slots, ck, cv,
-                                              khat.data_ptr(), keys_pad, ck_pad, vhatT.data_ptr(), B, st))
+                                              khat.data_ptr(), keys_pad, ck_pad, vhatT.data_ptr(), B, 0, st))
         outs.append((khat.cpu(), vhatT.cpu()))
     assert n_bins == 337
     x = kv.permute(0, 3, 1, 2).cpu()
@@ -573,8 +581,23 @@ def test_anab_nested_pooling_matches_generic_pooling():
         assert (khat[:, :337, :ck] - ref[:, :ck].transpose(1, 2)).abs().max().item() < 2e-6
         assert (vhatT[:, :, :337] - ref[:, ck:]).abs().max().item() < 2e-6
     assert (outs[0][0] - outs[1][0]).abs().max().item() < 1e-6 and (outs[0][1] - outs[1][1]).abs().max().item() < 1e-6
+    # fragment-ordered outputs (the wave-granular GEMMs' weight layout): unpack and compare with the row-major result
+    kp, cvp = 384, 32                                                    # keys padded to 128, Cv a multiple of 32
+    kv2 = torch.randn(B, H, W, ck + cvp, generator=g).to(dev)
+    res = []
+    for fr in (0, 3):
+        khat = torch.zeros(B, kp * ck_pad, device=dev)
+        vhatT = torch.zeros(B, cvp * kp, device=dev)
+        scratch = torch.empty(L.m3d_anab_pool_nested_scratch_bytes(B, ck + cvp) // 4, device=dev)
+        _hip.check(L.m3d_anab_pool_nested(kv2.data_ptr(), ck + cvp, gate.data_ptr(), 4, B, H, W, ck, cvp, scratch.data_ptr(),
+                                          khat.data_ptr(), kp, ck_pad, vhatT.data_ptr(), fr, st))
+        if fr:
+            khat = khat.view(B, kp // 32, ck_pad // 8, 2, 32, 4).permute(0, 1, 4, 2, 3, 5).reshape(B, kp * ck_pad)
+            vhatT = vhatT.view(B, cvp // 32, kp // 8, 2, 32, 4).permute(0, 1, 4, 2, 3, 5).reshape(B, cvp * kp)
+        res.append((khat.cpu(), vhatT.cpu()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert L.m3d_anab_pool_nested(kv.data_ptr(), C, gate.data_ptr(), 4, B, 24, 40, ck, cv, partial.data_ptr(),
-                                  outs[0][0].data_ptr(), keys_pad, ck_pad, outs[0][1].data_ptr(), st) != 0   # 24x40 does not nest
+                                  outs[0][0].data_ptr(), keys_pad, ck_pad, outs[0][1].data_ptr(), 0, st) != 0   # 24x40 does not nest
 
 
 # ------------------------------------------------------------------------------------ fused head + graph
