@@ -68,7 +68,7 @@ def kernel_symbol(label):
     if label.startswith("wino"):
         return "wino_kernel(WinoArgs)"
     if label.startswith("conv_wave"):
-        return "void conv_wave_kernel<%s>(ConvWaveArgs)" % ("true" if "deform" in label else "false")   # (+ split-K reduce)
+        return "void conv_wave_kernel<%s, 4>(ConvWaveArgs)" % ("true" if "deform" in label else "false")   # (+ split-K reduce)
     if label.startswith("head_mlp"):
         layers, n3 = re.findall(r"\d+", label)[:2]
         return "void head_mlp_kernel<%s, %s>(MlpBatch)" % ("true" if layers == "3" else "false", n3)

@@ -105,9 +105,9 @@ int m3d_conv2d_splitk_plan(const m3d_conv_desc *d, int *splits, long long *ws_by
 
 /* Wave-granular convolution / deformable convolution (csrc/dcn_wave.hip): same descriptor as m3d_conv2d_forward
  * (dcn_offmask optional), except that `wgt` is the packed [Cout_pad, kh*kw*Cin] matrix in MFMA-fragment order
- * [Cout_pad/32][kh*kw*Cin/8][h=2][r=32][t=4].  Each wave owns 32 pixels x 128 channels and works alone (no workgroup
+ * [Cout_pad/32][kh*kw*Cin/8][h=2][r=32][t=4].  Each wave owns 32 pixels x 128 channels (64 when Cout_pad is an odd multiple of 64) and works alone (no workgroup
  * barrier).  m3d_conv_wave_applicable returns the number of waves the layer yields, or 0 when it does not apply
- * (needs Cin % 32 == 0, in_cs % 32 == 0, 128-byte aligned input, Cout_pad % 128 == 0, NHWC output; per-image weights
+ * (needs Cin % 32 == 0, in_cs % 32 == 0, 128-byte aligned input, Cout_pad % 64 == 0, NHWC output; per-image weights
  * -- wgt_img_stride in floats between fragment-packed sets -- need Ho*Wo % 32 == 0) or when there are too few waves to fill the chip; the caller then stays on m3d_conv2d_forward. */
 int m3d_conv_wave_applicable(const m3d_conv_desc *d);
 /* Thin layers (too few 32 x 128 tiles) can still take this path split along K across waves: *splits and the scratch bytes to

@@ -1,4 +1,4 @@
-// Wave-granular implicit-GEMM convolution / deformable convolution for gfx950: ONE WAVE = 32 output pixels x 128 output
+// Wave-granular implicit-GEMM convolution / deformable convolution for gfx950: ONE WAVE = 32 output pixels x 128 (or 64) output
 // channels, 64-thread workgroups, no workgroup barriers; the accumulators (64 AGPRs) and operands leave room for two waves
 // per SIMD, which cover each other's load / LDS latency.
 //
@@ -41,7 +41,6 @@ struct ConvWaveArgs {
 #endif
 };
 
-#define CW_NT 4
 
 #ifdef CONV_TRACE
 static long long *g_conv_trace = nullptr;
@@ -53,10 +52,10 @@ extern "C" void m3d_conv_wave_set_trace(void *buf) { g_conv_trace = (long long *
 #define TRACE()
 #endif
 
-template <bool DEFORM>
+// NT = column tiles of 32 output channels per wave: 4 (128 channels) or, for 64-channel layers, 2
+template <bool DEFORM, int NT>
 __global__ __launch_bounds__(64) void conv_wave_kernel(const ConvWaveArgs a)
 {
-    constexpr int NT = CW_NT;
     __shared__ __attribute__((aligned(16))) float tileA[32 * 32];     // [pixel][8 slots of 4 channels], swizzled
     __shared__ __attribute__((aligned(16))) float tapst[32 * 8];      // [pixel][4 corner offsets (as bits), 4 weights]
     const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
@@ -321,10 +320,11 @@ static int conv_wave_plan(const m3d_conv_desc *d, bool enforce_min, int *splits,
     *splits = 1;
     *ss_per = d->kh * d->kw * (d->Cin / 32);
     if (d->out_nchw) return 0;
-    if (d->Cin % 32 != 0 || d->Cout_pad % 128 != 0) return 0;
+    if (d->Cin % 32 != 0 || d->Cout_pad % 64 != 0) return 0;
+    const int cw = d->Cout_pad % 128 == 0 ? 128 : 64;      // channels per wave
     if (d->wgt_img_stride && (d->Ho * d->Wo) % 32 != 0) return 0;
     const long long M = (long long)d->N * d->Ho * d->Wo;
-    const long long base = ((M + 31) / 32) * (d->Cout_pad / 128);
+    const long long base = ((M + 31) / 32) * (d->Cout_pad / cw);
     if (base >= (1ll << 28)) return 0;
     static int wave_min = -1, dcn_min = -1, splitk = -1;
     if (wave_min < 0) { const char *e = getenv("M3D_CONV_WAVE_MIN"); wave_min = e ? atoi(e) : 900; }
@@ -372,7 +372,7 @@ extern "C" int m3d_conv_wave_forward(const m3d_conv_desc *d, m3d_stream_t stream
     M3D_REQUIRE(d && d->in && d->wgt && d->out, "conv_wave: null pointer");
     int splits = 1, ss_per = 0;
     const int waves = conv_wave_plan(d, false, &splits, &ss_per);       // the fill heuristic is advisory here
-    M3D_REQUIRE(waves > 0, "conv_wave: needs Cin %% 32 == 0, Cout_pad %% 128 == 0, NHWC output, Ho*Wo %% 32 == 0 with per-image weights");
+    M3D_REQUIRE(waves > 0, "conv_wave: needs Cin %% 32 == 0, Cout_pad %% 64 == 0, NHWC output, Ho*Wo %% 32 == 0 with per-image weights");
     const int ho = (d->H + 2 * d->pad - (d->dil * (d->kh - 1) + 1)) / d->stride + 1;
     const int wo = (d->W + 2 * d->pad - (d->dil * (d->kw - 1) + 1)) / d->stride + 1;
     M3D_REQUIRE(ho == d->Ho && wo == d->Wo, "conv_wave: Ho/Wo mismatch");
@@ -390,12 +390,13 @@ extern "C" int m3d_conv_wave_forward(const m3d_conv_desc *d, m3d_stream_t stream
     a.in_cs = d->in_cs; a.out_cs = d->out_cs; a.res_cs = d->res_cs; a.om_cs = d->dcn_om_cs;
     a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.HoWo = d->Ho * d->Wo; a.Cout = d->Cout;
     a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.dil = d->dil;
-    a.M = (int)M; a.KG = d->kh * d->kw * d->Cin / 8; a.tiles_n = d->Cout_pad / 128;
+    const int cw = d->Cout_pad % 128 == 0 ? 128 : 64;
+    a.M = (int)M; a.KG = d->kh * d->kw * d->Cin / 8; a.tiles_n = d->Cout_pad / cw;
     a.act = d->act; a.res_mode = d->res_mode; a.sigmoid_from = d->sigmoid_from; a.w_img_stride = d->wgt_img_stride;
     a.in_bytes = (unsigned)((long long)d->N * d->H * d->W * d->in_cs * 4);
     a.out_bytes = (unsigned)(M * d->out_cs * 4);
     a.res_bytes = (unsigned)(M * d->res_cs * 4);
-    a.w_bytes = (unsigned)((long long)128 * d->kh * d->kw * d->Cin * 4);
+    a.w_bytes = (unsigned)((long long)cw * d->kh * d->kw * d->Cin * 4);
 #ifdef CONV_TRACE
     a.trace = g_conv_trace;
 #endif
@@ -407,8 +408,13 @@ extern "C" int m3d_conv_wave_forward(const m3d_conv_desc *d, m3d_stream_t stream
                     d->splitk_ws_bytes);
         a.ws = d->splitk_ws; a.splits = splits; a.base_waves = waves / splits; a.ws_bytes = (unsigned)need;
     }
-    if (d->dcn_offmask) hipLaunchKernelGGL(conv_wave_kernel<true>, dim3(waves), dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL(conv_wave_kernel<false>, dim3(waves), dim3(64), 0, stream, a);
+    if (cw == 128) {
+        if (d->dcn_offmask) hipLaunchKernelGGL((conv_wave_kernel<true, 4>), dim3(waves), dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL((conv_wave_kernel<false, 4>), dim3(waves), dim3(64), 0, stream, a);
+    } else {
+        if (d->dcn_offmask) hipLaunchKernelGGL((conv_wave_kernel<true, 2>), dim3(waves), dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL((conv_wave_kernel<false, 2>), dim3(waves), dim3(64), 0, stream, a);
+    }
     M3D_LAUNCH_CHECK();
     if (splits > 1) {
         SplitkReduceArgs r;

@@ -464,7 +464,7 @@ def test_dlaseg_standalone_matches_oracle():
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 9, 13, 128, 3, 1, 1), (1, 64, 40, 52, 128, 3, 1, 1), (2, 128, 16, 24, 256, 1, 1, 0),
-                                   (1, 48, 11, 7, 100, 3, 2, 1)])
+                                   (1, 48, 11, 7, 100, 3, 2, 1), (1, 32, 12, 20, 64, 3, 2, 1), (2, 64, 9, 9, 40, 1, 1, 0)])
 @pytest.mark.parametrize("deform", [1, 0])
 def test_dcn_wave_kernel_matches_block_kernel_and_oracle(shape, deform):
     """m3d_conv_wave_forward (register-resident, one wave per 32/64 px x 128 ch) vs the LDS-tiled igemm on the same
@@ -490,13 +490,14 @@ def test_dcn_wave_kernel_matches_block_kernel_and_oracle(shape, deform):
     res = torch.randn(n, co, ho, wo, generator=g)
     want = F.leaky_relu(ref + res, 0.01)
     cin_pad = (ci + 31) // 32 * 32
+    cpt = 64 if co <= 64 else 128                        # Cout_pad 64 -> the 64-channel variant of the kernel
     v, _ = S._to_nhwc(x.to(dev), cin_pad)
     om, _ = S._to_nhwc(torch.cat([off, msk], 1).to(dev))
     rv, _ = S._to_nhwc(res.to(dev))
     out_blk, keep = S.conv_nhwc(v, wt.to(dev), b.to(dev), None, stride, pad, act=1, res=rv, om=om if deform else None,
-                                cout_pad_to=128)
+                                cout_pad_to=cpt)
     blk = S._to_nchw(out_blk, co).cpu()
-    wp, co_, cop, kh, kw = S._pack(wt.to(dev), cin_pad, 128)
+    wp, co_, cop, kh, kw = S._pack(wt.to(dev), cin_pad, cpt)
     frag = pack_frag(wp.view(cop, kh * kw * cin_pad), cop, dev)
     sc, sh = S._affine(co, b.to(dev), None, dev)
     out = torch.zeros(n * ho * wo * co, device=dev)
@@ -534,7 +535,7 @@ def test_dcn_wave_kernel_matches_block_kernel_and_oracle(shape, deform):
     out.zero_()
     _hip.check(L.m3d_conv_wave_forward(ctypes.byref(d), S._stream()))
     out_sg, _k = S.conv_nhwc(v, wt.to(dev), b.to(dev), None, stride, pad, act=1, res=rv, om=om if deform else None,
-                             cout_pad_to=128, sigmoid_from=3)
+                             cout_pad_to=cpt, sigmoid_from=3)
     sg_blk = S._to_nchw(out_sg, co).cpu()
     sg_wave = out.view(n, ho, wo, co).permute(0, 3, 1, 2).cpu()
     assert (sg_wave - sg_blk).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
