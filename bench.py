@@ -243,8 +243,12 @@ def main():
     for op in plan.ops:
         if op[1] == dominant and op[4] is not None:
             d = op[4]
-            o = d.N * d.Ho * d.Wo * d.Cout * 4
-            ab += d.N * d.H * d.W * d.Cin * 4 + o + (o if d.res else 0) + d.Cout * d.kh * d.kw * d.Cin * 4
+            if hasattr(d, "Ho"):                              # m3d_conv_desc
+                o = d.N * d.Ho * d.Wo * d.Cout * 4
+                ab += d.N * d.H * d.W * d.Cin * 4 + o + (o if d.res else 0) + d.Cout * d.kh * d.kw * d.Cin * 4
+            else:                                             # m3d_mlp_desc or an array of them (batched heads)
+                for h in (d if hasattr(d, "__len__") else [d]):
+                    ab += h.M * h.Cin * 4 + h.M * h.Cout * 4 + ((h.Cin * 256 if h.w1 else 0) + 256 * 256 + 256 * h.Cout) * 4
             an += 1
     alg_bytes = int(ab / an) if an else None
 
