@@ -17,6 +17,11 @@ if mode == "mfma":
     sys.exit(0)
 dev = torch.device("cuda:0")
 L = _hip.lib()
+import os
+if os.environ.get('TRACE_LIB'):
+    L = ctypes.CDLL('m3dssd_amd/csrc/build/libm3dssd_hip_trace.so')
+    for f in ('m3d_wino_conv3x3_forward', 'm3d_conv_wave_forward'):
+        getattr(L, f).argtypes = [ctypes.POINTER(_hip.ConvDesc), ctypes.c_void_p]
 B, H, W, cin, cout = 8, 48, 160, 128, 128
 x = torch.randn(B * H * W * cin, device=dev)
 out = torch.empty(B * H * W * cout, device=dev)
@@ -40,7 +45,7 @@ st = torch.cuda.current_stream().cuda_stream
 t0 = time.time()
 n = 0
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-while time.time() - t0 < 8.0:
+while time.time() - t0 < float(os.environ.get('LOOP_S', '8')):
     e0.record()
     for _ in range(200):
         assert fn(st) == 0
