@@ -184,6 +184,17 @@ int m3d_nhwc_to_nchw(const float *in, int in_cs, float *out, int N, int C, int H
 /* 7x7, 3->16, stride 1, pad 3 on an NCHW image; fused affine (folded BN) + LeakyReLU; NHWC out. */
 int m3d_stem_conv7x7(const float *img_nchw, const float *wgt /*[7*7*3][16]*/, const float *scale,
                      const float *shift, float *out, int out_cs, int N, int H, int W, m3d_stream_t stream);
+/* Test-time input path of the reference: uint8 BGR frames [N][img_h][img_w][3] (what cv2.imread returns),
+ * zero border at the bottom / right up to H x W, /255, -mean, /stds in float32 (mean / stds: HOST pointers to 3 floats, indexed
+ * by BGR channel position exactly as lib/augmentations.py:44-57 applies them), BGR -> RGB, HWC -> CHW
+ * (augmentations.py:472-501, dataloader.py:943-950).  Bit-identical to the numpy arithmetic.  m3d_preprocess_u8 writes the
+ * [N][3][H][W] float tensor; m3d_stem_conv7x7_u8 feeds the stem directly (no float image in HBM: 1.5 MB instead of 5.9 MB
+ * per 384x1280 frame cross the boundary). */
+int m3d_preprocess_u8(const unsigned char *frames_bgr, int N, int img_h, int img_w, const float *mean3, const float *stds3,
+                      float *out_nchw, int H, int W, m3d_stream_t stream);
+int m3d_stem_conv7x7_u8(const unsigned char *frames_bgr, int img_h, int img_w, const float *mean3, const float *stds3,
+                        const float *wgt, const float *scale, const float *shift, float *out, int out_cs, int N, int H, int W,
+                        m3d_stream_t stream);
 /* 3x3, 16 -> 16, stride 1, pad 1 (DLA level0, pose_dla_dcn.py:341-342) as a direct VALU convolution: NHWC in/out,
  * wgt [(i*3+j)*16 + cin][16 cout], fused affine (folded BN) + LeakyReLU. */
 int m3d_conv3x3_c16(const float *in, int in_cs, const float *wgt, const float *scale, const float *shift, float *out,

@@ -94,15 +94,35 @@ extern "C" int m3d_nhwc_to_nchw(const float *in, int in_cs, float *out, int N, i
 // through the scalar cache (wave-uniform index) so the VALU sees them as SGPR operands.
 #define STEM_TH 8
 #define STEM_TW 32
-__global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float *__restrict__ img, const float *__restrict__ wgt,
+// Test-time input path of the reference fused into the load: uint8 BGR frames [N][img_h][img_w][3], zero
+// border at the bottom / right up to H x W, then /255, -mean, /stds in float32 with mean / stds indexed by the BGR channel
+// position, BGR -> RGB (lib/augmentations.py:36-57,138-160,472-501, lib/dataloader.py:943-950).  IEEE division, no contraction:
+// bit-identical to the numpy arithmetic.
+struct U8Norm {
+    float mean[3], stds[3];       // indexed by BGR position, as the reference applies them
+    int img_h, img_w;
+};
+__device__ __forceinline__ float u8_normalise(const unsigned char *__restrict__ frame, const U8Norm &nm, int h, int w, int c_rgb)
+{
+    const int cb = 2 - c_rgb;
+    float v = (h < nm.img_h && w < nm.img_w) ? (float)frame[((size_t)h * nm.img_w + w) * 3 + cb] : 0.f;
+    v = v / 255.0f;
+    v = v - nm.mean[cb];
+    return v / nm.stds[cb];
+}
+
+template <bool U8>
+__global__ __launch_bounds__(256) void stem_conv7x7_kernel(const void *__restrict__ img_, const float *__restrict__ wgt,
                                                            const float *__restrict__ scale,
                                                            const float *__restrict__ shift, float *__restrict__ out,
-                                                           int out_cs, int H, int W)
+                                                           int out_cs, int H, int W, U8Norm nm)
 {
+    const float *img = static_cast<const float *>(img_);
     constexpr int PH = STEM_TH + 6, PW = STEM_TW + 6;
     __shared__ float patch[3][PH][PW + 1];
     const int n = blockIdx.z, h0 = blockIdx.y * STEM_TH, w0 = blockIdx.x * STEM_TW;
     const float *im = img + (size_t)n * 3 * H * W;
+    const unsigned char *frame = static_cast<const unsigned char *>(img_) + (size_t)n * nm.img_h * nm.img_w * 3;
     {   // all loads of the thread in flight before the first LDS write
         constexpr int NE = 3 * PH * PW, NIT = (NE + 255) / 256;
         float v[NIT];
@@ -111,7 +131,9 @@ __global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float *__restri
             const int i = threadIdx.x + 256 * k;
             const int c = i / (PH * PW), r = (i / PW) % PH, q = i % PW;
             const int h = h0 + r - 3, w = w0 + q - 3;
-            v[k] = (i < NE && h >= 0 && h < H && w >= 0 && w < W) ? im[((size_t)c * H + h) * W + w] : 0.f;
+            const bool inside = i < NE && h >= 0 && h < H && w >= 0 && w < W;      // outside: the conv's own zero padding
+            if constexpr (U8) v[k] = inside ? u8_normalise(frame, nm, h, w, c) : 0.f;
+            else v[k] = inside ? im[((size_t)c * H + h) * W + w] : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
@@ -159,8 +181,65 @@ extern "C" int m3d_stem_conv7x7(const float *img_nchw, const float *wgt, const f
                                 float *out, int out_cs, int N, int H, int W, m3d_stream_t stream)
 {
     M3D_REQUIRE(img_nchw && wgt && scale && shift && out && out_cs % 4 == 0 && out_cs >= 16, "stem: bad arguments");
-    hipLaunchKernelGGL(stem_conv7x7_kernel, dim3(cdiv(W, STEM_TW), cdiv(H, STEM_TH), N), dim3(256), 0,
-                       (hipStream_t)stream, img_nchw, wgt, scale, shift, out, out_cs, H, W);
+    hipLaunchKernelGGL(stem_conv7x7_kernel<false>, dim3(cdiv(W, STEM_TW), cdiv(H, STEM_TH), N), dim3(256), 0,
+                       (hipStream_t)stream, (const void *)img_nchw, wgt, scale, shift, out, out_cs, H, W, U8Norm{});
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+static int fill_u8norm(U8Norm &nm, const float *mean3, const float *stds3, int img_h, int img_w, int H, int W)
+{
+    M3D_REQUIRE(mean3 && stds3, "preprocess: mean / stds are host pointers to 3 floats each");
+    M3D_REQUIRE(img_h >= 1 && img_w >= 1 && img_h <= H && img_w <= W,
+                "preprocess: the frame (%dx%d) must fit the padded size (%dx%d)", img_h, img_w, H, W);
+    for (int c = 0; c < 3; ++c) {
+        M3D_REQUIRE(stds3[c] != 0.f, "preprocess: zero std");
+        nm.mean[c] = mean3[c];
+        nm.stds[c] = stds3[c];
+    }
+    nm.img_h = img_h; nm.img_w = img_w;
+    return M3D_OK;
+}
+
+extern "C" int m3d_stem_conv7x7_u8(const unsigned char *frames_bgr, int img_h, int img_w, const float *mean3, const float *stds3,
+                                   const float *wgt, const float *scale, const float *shift, float *out, int out_cs, int N, int H,
+                                   int W, m3d_stream_t stream)
+{
+    M3D_REQUIRE(frames_bgr && wgt && scale && shift && out && out_cs % 4 == 0 && out_cs >= 16, "stem_u8: bad arguments");
+    U8Norm nm;
+    const int rc = fill_u8norm(nm, mean3, stds3, img_h, img_w, H, W);
+    if (rc != M3D_OK) return rc;
+    hipLaunchKernelGGL(stem_conv7x7_kernel<true>, dim3(cdiv(W, STEM_TW), cdiv(H, STEM_TH), N), dim3(256), 0,
+                       (hipStream_t)stream, (const void *)frames_bgr, wgt, scale, shift, out, out_cs, H, W, nm);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+// The same input path on its own: [N][img_h][img_w][3] uint8 BGR -> [N][3][H][W] float32 RGB planes.
+__global__ void preprocess_u8_kernel(const unsigned char *__restrict__ frames, float *__restrict__ out, int N, int H, int W,
+                                     U8Norm nm)
+{
+    const long long total = (long long)N * H * W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W);
+        const long long t = i / W;
+        const int h = (int)(t % H), n = (int)(t / H);
+        const unsigned char *frame = frames + (size_t)n * nm.img_h * nm.img_w * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[(((size_t)n * 3 + c) * H + h) * W + w] = u8_normalise(frame, nm, h, w, c);
+    }
+}
+
+extern "C" int m3d_preprocess_u8(const unsigned char *frames_bgr, int N, int img_h, int img_w, const float *mean3,
+                                 const float *stds3, float *out_nchw, int H, int W, m3d_stream_t stream)
+{
+    M3D_REQUIRE(frames_bgr && out_nchw && N >= 1, "preprocess_u8: bad arguments");
+    U8Norm nm;
+    const int rc = fill_u8norm(nm, mean3, stds3, img_h, img_w, H, W);
+    if (rc != M3D_OK) return rc;
+    const long long total = (long long)N * H * W;
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(imin(cdiv(total, 256), 16384)), dim3(256), 0, (hipStream_t)stream, frames_bgr,
+                       out_nchw, N, H, W, nm);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
 }

@@ -387,9 +387,20 @@ class Engine:
         in_ptr = [0]                      # set by forward(): the caller's NCHW tensor is read in place
         plan.named["input_ptr"] = in_ptr
         s0 = self._buf(plan, B, H, W, 16)
-        self._op(plan, "stem", "stem", lambda st: _hip.check(L.m3d_stem_conv7x7(
-            in_ptr[0], P["stem.w"].data_ptr(), P["stem.scale"].data_ptr(), P["stem.shift"].data_ptr(), s0.ptr,
-            s0.cs, B, H, W, st)))
+        in_u8 = [0, 0, 0]                 # (ptr, h, w) of uint8 BGR frames; set by forward_u8() instead of in_ptr
+        plan.named["input_u8"] = in_u8
+        mean3 = (ctypes.c_float * 3)(*[float(v) for v in self.conf.image_means])
+        stds3 = (ctypes.c_float * 3)(*[float(v) for v in self.conf.image_stds])
+
+        def stem(st):
+            if in_u8[0]:                  # test-time input path fused into the stem's loads
+                _hip.check(L.m3d_stem_conv7x7_u8(in_u8[0], in_u8[1], in_u8[2], mean3, stds3, P["stem.w"].data_ptr(),
+                                                 P["stem.scale"].data_ptr(), P["stem.shift"].data_ptr(), s0.ptr, s0.cs, B, H,
+                                                 W, st))
+            else:
+                _hip.check(L.m3d_stem_conv7x7(in_ptr[0], P["stem.w"].data_ptr(), P["stem.scale"].data_ptr(),
+                                              P["stem.shift"].data_ptr(), s0.ptr, s0.cs, B, H, W, st))
+        self._op(plan, "stem", "stem", stem)
         l0 = self._buf(plan, B, H, W, 16, name="level0")
         if P["level0.direct"] is not None and os.environ.get("M3D_LEVEL0_IGEMM", "0") != "1":
             pc0 = P["level0"]
@@ -720,7 +731,28 @@ class Engine:
         plan = self.plan_for(B, H, W)
         x = x.contiguous()
         plan.named["input_ptr"][0] = x.data_ptr()
+        plan.named["input_u8"][0] = 0
         self.run_plan(plan)
+        n = plan.named
+        return n["cls"], n["prob"], n["bbox_2d"], n["bbox_3d"]
+
+    def forward_u8(self, frames, size=None):
+        """frames: uint8 [B, h, w, 3] BGR device tensor (what cv2.imread returns, batched) -> the same outputs as
+        forward(Preprocess(frames)): padding to `size` (default conf.crop_size), /255, -mean, /stds, BGR->RGB
+        (lib/augmentations.py:472-501, lib/dataloader.py:943-950) happen inside the stem kernel's loads."""
+        if not frames.is_cuda or frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3:
+            raise NotImplementedError("forward_u8: uint8 [B, h, w, 3] ROCm device tensor expected")
+        H, W = (int(v) for v in (size if size is not None else self.conf.crop_size))
+        B, h, w, _ = frames.shape
+        if h > H or w > W:
+            raise RuntimeError("forward_u8: frame %dx%d does not fit the padded size %dx%d" % (h, w, H, W))
+        plan = self.plan_for(B, H, W)
+        frames = frames.contiguous()
+        plan.named["input_u8"][:] = [frames.data_ptr(), h, w]
+        try:
+            self.run_plan(plan)
+        finally:
+            plan.named["input_u8"][0] = 0
         n = plan.named
         return n["cls"], n["prob"], n["bbox_2d"], n["bbox_3d"]
 

@@ -83,10 +83,18 @@ class RPN(nn.Module):
     def forward(self, x):
         if self.training:
             raise NotImplementedError("m3dssd_amd accelerates inference (eval mode); call .eval() or build(conf, 'test')")
-        feat_h, feat_w = x.shape[2] // self.feat_stride, x.shape[3] // self.feat_stride
-        assert feat_h == self.feat_size[0], "x.shape is {}".format(x.shape)
+        u8 = x.dtype == torch.uint8 and x.dim() == 4 and x.shape[3] == 3      # raw BGR frames [B, h, w, 3]: the test-time
+        if u8:                                                                 # Preprocess runs inside the stem kernel
+            size = [int(v) for v in self._conf.crop_size]
+            feat_h, feat_w = size[0] // self.feat_stride, size[1] // self.feat_stride
+        else:
+            feat_h, feat_w = x.shape[2] // self.feat_stride, x.shape[3] // self.feat_stride
+            assert feat_h == self.feat_size[0], "x.shape is {}".format(x.shape)
         with torch.no_grad():
-            cls, prob, bbox_2d, bbox_3d = self.engine().forward(x.float())
+            if u8:
+                cls, prob, bbox_2d, bbox_3d = self.engine().forward_u8(x, size)
+            else:
+                cls, prob, bbox_2d, bbox_3d = self.engine().forward(x.float())
         key = (feat_h, feat_w, x.device)
         if getattr(self, "_feat_size_key", None) != key:       # cached: a fresh host->device copy per call would
             self._feat_size_t = torch.tensor([feat_h, feat_w], dtype=torch.float, device=x.device)  # break graph capture

@@ -819,3 +819,60 @@ def test_pipelined_detector_matches_detect_batch():
     assert len(got) == 3
     for (gd, gc), (rd, rc) in zip(got, ref):
         assert torch.equal(gc, rc) and torch.equal(gd, rd)
+
+
+# ------------------------------------------------------------------------------------ test-time input path (8f row 4)
+def test_preprocess_u8_bit_exact_and_fused_stem():
+    """m3d_preprocess_u8 == oracle.preprocess == the reference golden, bit for bit (IEEE division, numpy's operation order);
+    the stem fed with uint8 frames (m3d_stem_conv7x7_u8) == the stem fed with the preprocessed float image, bit for bit."""
+    import ctypes
+    from m3dssd_amd import _hip
+    from m3dssd_amd.host.preprocess import preprocess
+    from oracle.preprocess import preprocess as opre
+    dev = _dev()
+    L = _hip.lib()
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "preprocess.npz"))
+    mean, stds = g["mean"], g["stds"]
+    for n in "abc":
+        got = preprocess(torch.from_numpy(g["in_" + n]).to(dev), tuple(g["size_" + n]), mean, stds).cpu().numpy()[0]
+        assert np.array_equal(got, g["out_" + n])
+    rng = np.random.RandomState(3)
+    frames = rng.randint(0, 256, size=(3, 50, 70, 3)).astype(np.uint8)            # batch of 3, padded to 64x96
+    want = np.stack([opre(f, (64, 96), mean, stds) for f in frames])
+    xf = preprocess(torch.from_numpy(frames).to(dev), (64, 96), mean, stds)
+    assert np.array_equal(xf.cpu().numpy(), want)
+    with pytest.raises(RuntimeError):
+        preprocess(torch.from_numpy(frames).to(dev), (32, 96), mean, stds)         # frame taller than the target
+    with pytest.raises(NotImplementedError):
+        preprocess(torch.from_numpy(frames), (64, 96), mean, stds)                 # host tensor
+    # fused stem
+    w = torch.randn(7 * 7 * 3 * 16, device=dev) * 0.1
+    sc, sh = torch.rand(16, device=dev) + 0.5, torch.randn(16, device=dev) * 0.1
+    o1, o2 = torch.zeros(3 * 64 * 96 * 16, device=dev), torch.zeros(3 * 64 * 96 * 16, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    m3, s3 = (ctypes.c_float * 3)(*mean.tolist()), (ctypes.c_float * 3)(*stds.tolist())
+    fr = torch.from_numpy(frames).to(dev)
+    _hip.check(L.m3d_stem_conv7x7(xf.data_ptr(), w.data_ptr(), sc.data_ptr(), sh.data_ptr(), o1.data_ptr(), 16, 3, 64, 96, st))
+    _hip.check(L.m3d_stem_conv7x7_u8(fr.data_ptr(), 50, 70, m3, s3, w.data_ptr(), sc.data_ptr(), sh.data_ptr(), o2.data_ptr(), 16,
+                                     3, 64, 96, st))
+    assert torch.equal(o1, o2)
+
+
+def test_network_accepts_uint8_frames():
+    """net(uint8 BGR frames) == net(Preprocess(frames)) exactly: the input path runs inside the stem kernel."""
+    from m3dssd_amd.host.preprocess import preprocess
+    from model.M3d_inference_align import build
+    dev = _dev()
+    conf = synth.synth_conf((128, 320), 0, batch_size=2, device="cuda:0")
+    net = build(conf, "test")
+    net.load_state_dict(synth.synth_state_dict(0))
+    net = net.to(dev)
+    rng = np.random.RandomState(5)
+    frames = torch.from_numpy(rng.randint(0, 256, size=(2, 120, 310, 3)).astype(np.uint8)).to(dev)
+    with torch.no_grad():
+        a = [t.clone() for t in net(frames)[:4]]
+        x = preprocess(frames, conf.crop_size, conf.image_means, conf.image_stds)
+        b = [t.clone() for t in net(x)[:4]]
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    assert float(a[3].abs().max()) > 0

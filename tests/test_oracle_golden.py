@@ -211,3 +211,20 @@ def test_detect_matches_reference_im_detect_3d(golden_dir, crop, name):
     # kept anchors identical (col 13 = anchor id, col 5 = class), coordinates to fp32 roundoff
     assert np.array_equal(ab[:, 13], ref[:, 13]) and np.array_equal(ab[:, 5], ref[:, 5])
     assert np.abs(ab - ref).max() < 1e-3 * max(1.0, np.abs(ref).max())
+
+
+# ------------------------------------------------------------------------------------ test-time input path (8f row 4)
+def test_preprocess_oracle_matches_reference_golden(golden_dir):
+    """oracle.preprocess == the reference's Preprocess + BGR->RGB + CHW (tests/golden/preprocess.npz, generated by
+    tools/gen_golden_preprocess.py from lib/augmentations.py and lib/dataloader.py): bit-exact, incl. the padded border."""
+    from oracle.preprocess import preprocess
+    g = _load(golden_dir, "preprocess.npz")
+    for n in "abc":
+        out = preprocess(g["in_" + n], tuple(g["size_" + n]), g["mean"], g["stds"])
+        assert out.dtype == np.float32 and np.array_equal(out, g["out_" + n])
+    h, w, _ = g["in_a"].shape
+    border = preprocess(g["in_a"], tuple(g["size_a"]), g["mean"], g["stds"])[:, h:, :]
+    want = ((np.float32(0) / np.float32(255) - g["mean"]) / g["stds"])[::-1]          # -mean/std per RGB plane, not zero
+    assert np.array_equal(border, np.broadcast_to(want[:, None, None], border.shape))
+    with pytest.raises(ValueError):
+        preprocess(g["in_a"], (32, 32), g["mean"], g["stds"])
