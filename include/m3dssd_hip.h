@@ -274,6 +274,19 @@ void _nms(int *keep_out, int *num_out, const float *boxes_host, int boxes_num, i
           float nms_overlap_thresh, int device_id);
 
 /* ------------------------------------------------------------------------------------------
+ * Post-NMS 3-D refinement (lib/rpn_util.py:1801-1847 per-box loop of test_kitti_3d): convertAlpha2Rot,
+ * hill_climb on the yaw (step_r_init, halving down to r_lim; the depth step is 0 as in the reference call) scored by
+ * test_projection, convertRot2Alpha, camera-space centre.  One thread per row, float64.
+ *   aboxes [B][K][14] fp32 rows (x1 y1 x2 y2 score cls x3d y3d z3d w3d h3d l3d alpha anchor), counts [B],
+ *   p2 / p2_inv [B][16] row-major 4x4 doubles (device), out [B][K][16] doubles:
+ *   valid, cls, alpha, x1, y1, x2, y2, h3d, w3d, l3d, x3d, y3d (bottom centre), z3d, ry3d, score, 0
+ *   (valid = 0 and zeros for rows past counts[b] or with score < score_thresh) -- the fields of the KITTI result line
+ *   '{cls} -1 -1 {alpha} {x1} {y1} {x2} {y2} {h} {w} {l} {x} {y} {z} {ry} {score}' (lib/rpn_util.py:1848-1849).
+ * ------------------------------------------------------------------------------------------ */
+int m3d_refine_3d(const float *aboxes, const int *counts, int B, int K, const double *p2, const double *p2_inv,
+                  double score_thresh, int hill_climbing, double step_r_init, double r_lim, double *out, m3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Instrumentation: HIP-event timing of a launch sequence on a stream (used by bench.py).
  * ------------------------------------------------------------------------------------------ */
 int m3d_event_create(void **ev);

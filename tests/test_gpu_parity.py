@@ -876,3 +876,43 @@ def test_network_accepts_uint8_frames():
     for u, v in zip(a, b):
         assert torch.equal(u, v)
     assert float(a[3].abs().max()) > 0
+
+
+# ------------------------------------------------------------------------------------ post-NMS 3-D refinement (8f row 2)
+def test_refine_3d_matches_oracle_and_reference_text():
+    """m3d_refine_3d (one thread per detection, float64) vs oracle.refine and the reference golden: refined values to 1e-9,
+    identical hill-climb outcomes, and the KITTI text (6 decimals) identical to what the reference's functions produce."""
+    from m3dssd_amd.host import refine as HR
+    from oracle import refine as R
+    dev = _dev()
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "refine.npz"))
+    p2, rows = g["p2"], g["rows"]
+    lbls = ["Car", "Pedestrian", "Cyclist"]
+    # batch of 2 images: 40 + 8 rows (second image padded with garbage past its count)
+    dets = np.zeros((2, 40, 14), dtype=np.float32)
+    dets[0] = rows[:40]
+    dets[1, :8] = rows[40:]
+    dets[1, 8:] = 123.0
+    counts = torch.tensor([40, 8], dtype=torch.int32, device=dev)
+    out = HR.refine_detections(torch.from_numpy(dets).to(dev), counts, p2).cpu().numpy()
+    p2_inv = np.linalg.inv(p2)
+    for b, sl in ((0, range(0, 40)), (1, range(40, 48))):
+        for k, i in enumerate(sl):
+            o = out[b, k]
+            if rows[i][4] >= 0.75:
+                want = np.array(R.refine_row(rows[i], p2, p2_inv))
+                assert o[0] == 1.0 and o[1] == rows[i][5]
+                assert np.abs(o[2:15] - want).max() < 1e-9, (i, o[2:15], want)
+                assert np.abs(o[2:15] - g["refined"][i]).max() < 1e-9
+            else:
+                assert not o.any()
+    assert not out[1, 8:].any()
+    text = HR.kitti_text(out[0], lbls) + HR.kitti_text(out[1], lbls)
+    assert text == str(g["text"])
+    assert text == R.kitti_text(rows, p2, lbls, nms_topn_post=48)
+    # no hill climbing: only the two angle conversions and the back-projection
+    out0 = HR.refine_detections(torch.from_numpy(dets).to(dev), counts, p2, hill_climbing=False).cpu().numpy()
+    want0 = np.array(R.refine_row(rows[0], p2, p2_inv, hill_climbing=False))
+    assert (rows[0][4] < 0.75 and not out0[0, 0].any()) or np.abs(out0[0, 0, 2:15] - want0).max() < 1e-9
+    with pytest.raises(NotImplementedError):
+        HR.refine_detections(torch.from_numpy(dets), counts.cpu(), p2)

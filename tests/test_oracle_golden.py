@@ -228,3 +228,21 @@ def test_preprocess_oracle_matches_reference_golden(golden_dir):
     assert np.array_equal(border, np.broadcast_to(want[:, None, None], border.shape))
     with pytest.raises(ValueError):
         preprocess(g["in_a"], (32, 32), g["mean"], g["stds"])
+
+
+# ------------------------------------------------------------------------------------ post-NMS 3-D refinement (8f row 2)
+def test_refine_oracle_matches_reference_golden(golden_dir):
+    """oracle.refine == the reference's hill_climb / test_projection / project_3d / convertAlpha2Rot / convertRot2Alpha run on
+    48 seeded detections (tests/golden/refine.npz, tools/gen_golden_refine.py): refined rows and the KITTI text bit-identical."""
+    from oracle import refine as R
+    g = _load(golden_dir, "refine.npz")
+    p2 = g["p2"]
+    p2_inv = np.linalg.inv(p2)
+    out = np.array([R.refine_row(r, p2, p2_inv) for r in g["rows"]])
+    assert np.array_equal(out, g["refined"])
+    assert R.kitti_text(g["rows"], p2, ["Car", "Pedestrian", "Cyclist"], nms_topn_post=48) == str(g["text"])
+    ol, verts, invalid = R.test_projection(p2, p2_inv, np.array([300.0, 150.0, 80.0, 60.0]), 340.0, 180.0, 20.0, 1.6, 1.5, 3.9, 0.3)
+    assert ol == float(g["tp_ol"]) and np.array_equal(verts, g["tp_verts"]) and invalid == bool(g["tp_invalid"])
+    moved = np.abs(out[:, 11] - np.array([R.refine_row(r, p2, p2_inv, hill_climbing=False)[11] for r in g["rows"]]))
+    assert (moved > 1e-3).sum() >= 24                    # the hill climb actually moves most yaws of this fixture
+    assert np.array_equal(out[5], np.array(R.refine_row(g["rows"][5], p2, p2_inv, hill_climbing=False)))   # behind the camera
