@@ -372,16 +372,22 @@ __global__ __launch_bounds__(256) void conv3x3_c16_mfma_kernel(const float *__re
 #pragma unroll
         for (int tj = 0; tj < 3; ++tj) {
             const f32x4 b = bw[ti * 3 + tj];
+            // the 8 A fragments of the tap first, then t-major MFMAs: consecutive MFMAs hit different accumulators (a dependent
+            // v_mfma_f32_16x16x4_f32 waits 40 cycles, an independent one issues every 32 -- MI355X_MICROARCH.md)
+            f32x4 a[2][4];
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                    const f32x4 a = *reinterpret_cast<const f32x4 *>(
+                for (int ct = 0; ct < 4; ++ct)
+                    a[rr][ct] = *reinterpret_cast<const f32x4 *>(
                         tile + ((2 * wave + rr + ti) * PW + ct * 16 + li + tj) * 16 + lq * 4);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        acc[rr][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], acc[rr][ct], 0, 0, 0);
-                }
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+                        acc[rr][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rr][ct][t], b[t], acc[rr][ct], 0, 0, 0);
         }
     // ---- epilogue: lane = cout li, registers = pixels 4*lq + r of the 16-pixel tile -------------------------------------
     const float sc = scale[li], sh = shift[li];
