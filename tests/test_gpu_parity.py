@@ -792,6 +792,33 @@ def test_full_size_batch8_uses_wave_kernels_and_matches_batch1():
         assert err < tol, (name, err)
 
 
+def test_config4_shard_size_batch32_properties():
+    """BASELINE.json config 4 shards 32 images per GPU: at that size (1280x384) image i of the batch equals the same image alone,
+    two runs are bit-identical, and the detections of the batch equal those of its two halves (size-independent properties)."""
+    from lib.rpn_util import detect_batch
+    from model.M3d_inference_align import build
+    dev = _dev()
+    conf = synth.synth_conf((384, 1280), 0, batch_size=32, device="cuda:0")
+    net = build(conf, "test")
+    net.load_state_dict(synth.synth_state_dict(0))
+    net = net.to(dev)
+    x = synth.synth_frames(32, (384, 1280), 99).to(dev)
+    with torch.no_grad():
+        a = [t.clone() for t in net(x)[:4]]
+        b = [t.clone() for t in net(x)[:4]]
+        one = [t.clone() for t in net(x[17:18])[:4]]
+        dets, counts = (t.clone() for t in detect_batch(net, x, conf))
+        d0, c0 = (t.clone() for t in detect_batch(net, x[:16], conf))
+        d1, c1 = (t.clone() for t in detect_batch(net, x[16:], conf))
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    for name, u, s_, tol in zip(("cls", "prob", "bbox_2d", "bbox_3d"), a, one, (1e-3, 1e-4, 1e-3, 1e-3)):
+        assert (u[17:18] - s_).abs().max().item() < tol, name
+    assert torch.equal(counts, torch.cat([c0, c1]))
+    assert (dets - torch.cat([d0, d1])).abs().max().item() < 1e-2      # decoded pixels / metres of the same kept anchors
+    assert torch.equal(dets[:, :, 13], torch.cat([d0, d1])[:, :, 13])  # identical anchor ids row by row
+
+
 def test_pipelined_detector_matches_detect_batch():
     """forward(k) overlapped with detect(k-1) in one hipGraph: same detections as the sequential path."""
     from lib.rpn_util import detect_batch
