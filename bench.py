@@ -64,7 +64,7 @@ def kernel_symbol(label):
     """engine label -> demangled kernel name as rocprofv3 prints it."""
     import re
     if label.startswith("wino_wave"):
-        return "wino_wave_kernel(WinoArgs)"
+        return "void wino_wave_kernel<%s>(WinoArgs)" % ("true" if "splitk" in label else "false")
     if label.startswith("wino"):
         return "wino_kernel(WinoArgs)"
     if label.startswith("conv_wave"):

@@ -124,6 +124,10 @@ int m3d_wino_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t stream);
  * channels x 16 transform positions in 512 registers, no LDS), 0 = LDS kernel (64 tiles x 32 channels per 512-thread
  * workgroup) -- chosen when the layer yields too few waves for the 1024 SIMDs or needs the sigmoid epilogue. */
 int m3d_wino_conv3x3_variant(const m3d_conv_desc *d);
+/* Thin layers can still use the wave kernel split along K across waves (and only the split form has the sigmoid epilogue):
+ * *splits and the scratch bytes to pass through splitk_ws / splitk_ws_bytes; partials are reduced in split order by a second
+ * launch.  m3d_wino_conv3x3_variant answers for the descriptor as given (with or without a workspace). */
+int m3d_wino_conv3x3_splitk_plan(const m3d_conv_desc *d, int *splits, long long *ws_bytes);
 /* Same with the kernel chosen by the caller: variant -1 = automatic, 0 = LDS kernel, 1 = wave kernel (tests, tuning). */
 int m3d_wino_conv3x3_forward_ex(const m3d_conv_desc *d, int variant, m3d_stream_t stream);
 

@@ -36,6 +36,12 @@ struct WinoArgs {
     int tiles_n;             // Cout_pad / 32
     int act, sigmoid_from, res_mode;
     int ablate;   // diagnostics (M3D_ABLATE): 1 = loader skips steady-state loads, 2 = no MFMA, 4 = loader skips transform+store, 8 = no U loads
+    // split-K across waves (wave kernel only; layers with too few 32 x 32 tiles): grid = splits x tiles, split s covers k-steps
+    // [s*ks_per, (s+1)*ks_per) and stores its share of the UNTRANSFORMED-BACK outputs A^T M A (linear in M) to
+    // ws[s][N*H*W][Cout_pad]; m3d_launch_splitk_reduce adds them in split order and applies the epilogue
+    float *ws;
+    int splits, ks_per, base_waves;
+    unsigned ws_bytes;
 #ifdef WINO_TRACE
     long long *trace;   // [block][wave][64] s_memtime stamps (diagnostic build only, tools/wino_trace.py)
 #endif
@@ -392,6 +398,8 @@ __device__ __forceinline__ void wait_vm4(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d)
     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
+// PART = split-K form: the wave covers k-steps [ks0, ks1) and stores raw partial outputs to the workspace
+template <bool PART>
 __global__ __launch_bounds__(64) void wino_wave_kernel(const WinoArgs a)
 {
     __shared__ __attribute__((aligned(16))) int pixb[32];   // first output pixel of each tile (-1: no such tile)
@@ -407,9 +415,15 @@ __global__ __launch_bounds__(64) void wino_wave_kernel(const WinoArgs a)
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
         blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
+    int split = 0;
+    if constexpr (PART) {
+        split = blk / a.base_waves;
+        blk -= split * a.base_waves;
+    }
     const int bm = blk / a.tiles_n, bn = blk - bm * a.tiles_n;
     const int t0 = bm * 32, n0 = bn * 32;
     const int KS = a.Cin / 8;
+    const int ks0 = PART ? split * a.ks_per : 0, ks1 = PART ? min(KS, ks0 + a.ks_per) : KS;   // this wave's k-steps
 
     unsigned poff[16];
     {
@@ -436,9 +450,9 @@ __global__ __launch_bounds__(64) void wino_wave_kernel(const WinoArgs a)
 
     f32x4 d[16], V[16], Uf[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) buf_load_async(d[i], rin, poff[i], 0);
+    for (int i = 0; i < 16; ++i) buf_load_async(d[i], rin, poff[i], (unsigned)ks0 * 32u);
 #pragma unroll
-    for (int x = 0; x < 16; ++x) buf_load_async(Uf[x], ru, ulane, x * xstride);
+    for (int x = 0; x < 16; ++x) buf_load_async(Uf[x], ru, ulane, x * xstride + (unsigned)ks0 * 1024u);
     __builtin_amdgcn_sched_barrier(0);        // the accumulators are cleared while the first loads are in flight
     f32x16 acc[16];
 #pragma unroll
@@ -501,8 +515,8 @@ __global__ __launch_bounds__(64) void wino_wave_kernel(const WinoArgs a)
         group(std::integral_constant<int, 2>{});
         group(std::integral_constant<int, 3>{});
     };
-    for (int s = 0; s + 1 < KS; ++s) step(s, std::false_type{});
-    step(KS - 1, std::true_type{});
+    for (int s = ks0; s + 1 < ks1; ++s) step(s, std::false_type{});
+    step(ks1 - 1, std::true_type{});
     TRACE();
 
     // ---- A^T M A + epilogue in registers: lane = cout n0 + l31, tiles t0 + 4h + {0..3, 8..11, 16..19, 24..27} -------------
@@ -515,6 +529,12 @@ __global__ __launch_bounds__(64) void wino_wave_kernel(const WinoArgs a)
     const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res ? a.res : a.out, a.res ? a.res_bytes : 0u);
     // byte offsets of the four output pixels of a tile relative to its first one ride in the SGPR offset of the store
     const unsigned ocs4 = (unsigned)a.out_cs * 4u, rcs4 = (unsigned)a.res_cs * 4u;
+    // split-K form: the same stores go to the partial-sum workspace [split][pixel][Cout_pad] instead (every padded channel is
+    // written, the reduce launch skips co >= Cout); one offset array serves both so that the register budget is unchanged
+    constexpr bool part = PART;
+    const __amdgpu_buffer_rsrc_t rdst = part ? make_rsrc(a.ws, a.ws_bytes) : rout;
+    const unsigned dcs = part ? (unsigned)a.Cout_pad : (unsigned)a.out_cs;
+    const unsigned dcs4 = dcs * 4u, sbase = part ? (unsigned)split * (unsigned)(a.N * a.H * a.W) : 0u;
     unsigned obase[16];
     float rv[16][4];
 #pragma unroll
@@ -524,8 +544,8 @@ __global__ __launch_bounds__(64) void wino_wave_kernel(const WinoArgs a)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const bool ok = cok && pbv[k] >= 0;
-            obase[4 * q + k] = ok ? ((unsigned)pbv[k] * (unsigned)a.out_cs + (unsigned)co) * 4u : M3D_BUF_OOB;
-            if (a.res) {                       // all residual loads are in flight before the arithmetic starts
+            obase[4 * q + k] = ((part || cok) && pbv[k] >= 0) ? ((sbase + (unsigned)pbv[k]) * dcs + (unsigned)co) * 4u : M3D_BUF_OOB;
+            if (!PART && a.res) {              // all residual loads are in flight before the arithmetic starts
                 const unsigned rb = ok ? ((unsigned)pbv[k] * (unsigned)a.res_cs + (unsigned)co) * 4u : M3D_BUF_OOB;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -552,6 +572,17 @@ __global__ __launch_bounds__(64) void wino_wave_kernel(const WinoArgs a)
         y[1] = pk_sub2(pk_sub2(s0[1], s0[2]), s0[3]);
         y[2] = s1[0] + s1[1] + s1[2];
         y[3] = pk_sub2(pk_sub2(s1[1], s1[2]), s1[3]);
+        if constexpr (PART) {                  // raw partial outputs; the reduce launch owns residual / affine / activation
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float pv = y[k][e];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv), rdst, obase[r + e],
+                                                          (unsigned)((k >> 1) * a.W + (k & 1)) * dcs4, 0);
+                }
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             f32x2 v = y[k];
@@ -574,18 +605,54 @@ __global__ __launch_bounds__(64) void wino_wave_kernel(const WinoArgs a)
     TRACE();
 }
 
-// 1: register-resident wave kernel, 0: LDS kernel.  The wave kernel needs enough waves for the 1024 SIMDs and has no sigmoid
-// epilogue.  Tuning knobs (experiments only): M3D_WINO_VARIANT=0 forces the LDS kernel, M3D_WINO_WAVE_MIN the wave threshold.
-static bool wino_use_wave_kernel(const m3d_conv_desc *d)
+// Kernel choice and split-K plan.  Returns 1 for the register-resident wave kernel (with *splits >= 1), 0 for the LDS kernel.
+// The wave kernel needs enough waves for the 1024 SIMDs: thin layers (the 12x40 maps, the 27-channel offset/mask convs) are
+// split along K across waves when the caller provides a workspace; the sigmoid epilogue only exists in the split path (the
+// reduce launch applies it).  Tuning knobs (experiments only): M3D_WINO_VARIANT=0 forces the LDS kernel, M3D_WINO_WAVE_MIN the
+// wave threshold, M3D_WINO_SPLITK=1 recommends the split form (off: it measured slower than the LDS kernel).
+static int wino_plan(const m3d_conv_desc *d, bool have_ws, int *splits, int *ks_per)
 {
-    static int wave_min = -1, variant = -1;
+    static int wave_min = -1, variant = -1, splitk = -1;
     if (wave_min < 0) { const char *e = getenv("M3D_WINO_WAVE_MIN"); wave_min = e ? atoi(e) : 800; }
     if (variant < 0) { const char *e = getenv("M3D_WINO_VARIANT"); variant = e ? atoi(e) : 1; }
+    if (splitk < 0) { const char *e = getenv("M3D_WINO_SPLITK"); splitk = e ? atoi(e) : 0; }
+    const int KS = d->Cin / 8;
+    *splits = 1;
+    *ks_per = KS;
+    if (variant != 1) return 0;
     const long long nt = (long long)d->N * (d->H / 2) * (d->W / 2);
-    return variant == 1 && d->sigmoid_from < 0 && ((nt + 31) / 32) * (d->Cout_pad / 32) >= wave_min;
+    const long long base = ((nt + 31) / 32) * (d->Cout_pad / 32);
+    if (base < wave_min && have_ws) {
+        int s = (int)((1600 + base - 1) / base);
+        if (s > KS / 8) s = KS / 8;             // at least 8 k-steps (64 channels) per split
+        if (s > 4) s = 4;
+        if (s >= 2) {
+            *ks_per = (KS + s - 1) / s;
+            *splits = (KS + *ks_per - 1) / *ks_per;
+        }
+    }
+    // (splits / ks_per stay as computed: a caller that forces the wave kernel uses them even below the fill threshold)
+    // measured (bs=8): the split form loses to the LDS kernel on the layers it would apply to (level5 0.108 vs 0.096 ms, the
+    // 27-channel offset/mask convs 0.045 vs 0.035 ms), so it is only recommended when M3D_WINO_SPLITK=1
+    if (*splits > 1 && !splitk) return 0;
+    return !(base * *splits < wave_min || (d->sigmoid_from >= 0 && *splits <= 1));
 }
 
-extern "C" int m3d_wino_conv3x3_variant(const m3d_conv_desc *d) { return d && wino_use_wave_kernel(d) ? 1 : 0; }
+extern "C" int m3d_wino_conv3x3_variant(const m3d_conv_desc *d)
+{
+    int s, k;
+    return d ? wino_plan(d, d->splitk_ws != nullptr, &s, &k) : 0;
+}
+
+// Split-K plan of the wave kernel computed AS IF a workspace were given: *splits and the bytes to pass through splitk_ws.
+extern "C" int m3d_wino_conv3x3_splitk_plan(const m3d_conv_desc *d, int *splits, long long *ws_bytes)
+{
+    M3D_REQUIRE(d && splits && ws_bytes, "wino_splitk_plan: null pointer");
+    int k;
+    if (!wino_plan(d, true, splits, &k)) *splits = 1;            // not recommended: no split, the LDS kernel runs
+    *ws_bytes = *splits > 1 ? (long long)*splits * d->N * d->H * d->W * d->Cout_pad * 4 : 0;
+    return M3D_OK;
+}
 
 extern "C" int m3d_wino_conv3x3_forward_ex(const m3d_conv_desc *d, int variant, m3d_stream_t stream_)
 {
@@ -623,13 +690,33 @@ extern "C" int m3d_wino_conv3x3_forward_ex(const m3d_conv_desc *d, int variant, 
         attr_set = true;
     }
     M3D_REQUIRE(variant >= -1 && variant <= 1, "wino: variant must be -1 (auto), 0 (LDS kernel) or 1 (wave kernel)");
-    M3D_REQUIRE(variant != 1 || d->sigmoid_from < 0, "wino: the wave kernel has no sigmoid epilogue");
-    if (variant == 1 || (variant < 0 && wino_use_wave_kernel(d))) {
+    int splits = 1, ks_per = d->Cin / 8;
+    const int planned = wino_plan(d, d->splitk_ws != nullptr, &splits, &ks_per);
+    if (variant == 0 || (variant < 0 && !planned)) { splits = 1; ks_per = d->Cin / 8; }
+    M3D_REQUIRE(variant != 1 || d->sigmoid_from < 0 || splits > 1,
+                "wino: the wave kernel applies the sigmoid epilogue only in its split-K form (needs a workspace)");
+    a.ws = nullptr; a.splits = 1; a.ks_per = ks_per; a.base_waves = cdiv(a.NT, 32) * a.tiles_n; a.ws_bytes = 0;
+    if (variant == 1 || (variant < 0 && planned)) {
+        if (splits > 1) {
+            const long long need = (long long)splits * d->N * d->H * d->W * d->Cout_pad * 4;
+            M3D_REQUIRE(need <= d->splitk_ws_bytes && need < (1ll << 31) && ((uintptr_t)d->splitk_ws & 15) == 0,
+                        "wino: split-K workspace too small (%lld bytes, see m3d_wino_conv3x3_splitk_plan), >= 2 GiB or misaligned",
+                        d->splitk_ws_bytes);
+            a.ws = d->splitk_ws; a.splits = splits; a.ws_bytes = (unsigned)need;
+        }
         M3D_REQUIRE((long long)d->N * d->H * d->W * d->out_cs * 4 < (1ll << 31) &&
                     (long long)d->N * d->H * d->W * d->res_cs * 4 < (1ll << 31), "wino: output / residual views must be < 2 GiB");
         M3D_REQUIRE(d->Cin % 8 == 0, "wino: Cin %% 8");
-        hipLaunchKernelGGL(wino_wave_kernel, dim3(cdiv(a.NT, 32) * a.tiles_n), dim3(64), 0, stream, a);
+        if (a.splits > 1) hipLaunchKernelGGL(wino_wave_kernel<true>, dim3(a.base_waves * a.splits), dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL(wino_wave_kernel<false>, dim3(a.base_waves), dim3(64), 0, stream, a);
         M3D_LAUNCH_CHECK();
+        if (a.splits > 1) {
+            SplitkReduceArgs r;
+            r.ws = a.ws; r.scale = d->scale; r.shift = d->shift; r.res = d->res; r.out = d->out;
+            r.M = d->N * d->H * d->W; r.Cout = d->Cout; r.Cout_pad = d->Cout_pad; r.splits = a.splits; r.out_cs = d->out_cs;
+            r.res_cs = d->res_cs; r.res_mode = d->res_mode; r.act = d->act; r.sigmoid_from = d->sigmoid_from;
+            return m3d_launch_splitk_reduce(r, stream);
+        }
         return M3D_OK;
     }
     const int grid = cdiv(a.NT, WINO_T) * a.tiles_n;

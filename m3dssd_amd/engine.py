@@ -326,7 +326,16 @@ class Engine:
             # Winograd F(2x2,3x3): 2.25x fewer MFMA FLOPs for the plain 3x3 stride-1 layers
             d.wgt = pc.wino.data_ptr()
             flops = 2.0 * x.n * d.Ho * d.Wo * d.Cout * 9 * pc.cin
-            kind = "wino_wave<32,32>" if L.m3d_wino_conv3x3_variant(ref) == 1 else "wino_lds<64,32,16>"
+            ssplits, sbytes = ctypes.c_int(), ctypes.c_longlong()          # thin layers: wave kernel split along K across waves
+            _hip.check(L.m3d_wino_conv3x3_splitk_plan(ref, ctypes.byref(ssplits), ctypes.byref(sbytes)))
+            if ssplits.value > 1:
+                ws = torch.empty(sbytes.value // 4, device=self.device, dtype=torch.float32)
+                plan.keep.append(ws)
+                d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), sbytes.value
+            if L.m3d_wino_conv3x3_variant(ref) == 1:
+                kind = "wino_wave<32,32%s>" % (",splitk%d" % ssplits.value if ssplits.value > 1 else "")
+            else:
+                kind = "wino_lds<64,32,16>"
             plan.ops.append((name, kind, flops, lambda st: _hip.check(L.m3d_wino_conv3x3_forward(ref, st)), d))
             return
         flops_true = 2.0 * x.n * d.Ho * d.Wo * d.Cout * kh * kw * (

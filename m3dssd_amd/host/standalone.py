@@ -47,7 +47,7 @@ def _affine(co, bias, bn, dev):
 
 
 def conv_nhwc(v, weight, bias=None, bn=None, stride=1, pad=0, act=0, res=None, res_mode=0, sigmoid_from=-1, om=None,
-              cout_pad_to=32, out_cs_to=4, wino=False, splitk=True, wino_variant=-1):
+              cout_pad_to=32, out_cs_to=4, wino=False, splitk=True, wino_variant=-1, wino_splitk=False):
     """One m3d_conv2d_forward (or, with wino=True, m3d_wino_conv3x3_forward) launch on an NHWC view;
     returns (View, keepalive)."""
     wp, co, cop, kh, kw = _pack(weight, v.c, cout_pad_to)
@@ -80,6 +80,9 @@ def conv_nhwc(v, weight, bias=None, bn=None, stride=1, pad=0, act=0, res=None, r
             ws = torch.empty(ws_bytes.value // 4, device=v.t.device, dtype=torch.float32)
             d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws_bytes.value
     if wino:
+        if wino_splitk:                        # workspace for the wave kernel's split-K form (4 splits at most)
+            ws = torch.empty(4 * v.n * ho * wo * cop, device=v.t.device, dtype=torch.float32)
+            d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
         _hip.check(_hip.lib().m3d_wino_conv3x3_forward_ex(ctypes.byref(d), wino_variant, _stream()))
     else:
         _hip.check(_hip.lib().m3d_conv2d_forward(ctypes.byref(d), _stream()))

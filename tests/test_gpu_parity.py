@@ -722,7 +722,7 @@ WINO_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("case", WINO_CASES)
 def test_winograd_conv3x3_matches_torch(case, variant):
     """m3d_wino_conv3x3_forward_ex (F(2x2,3x3), fp32), LDS kernel (0) and register-resident wave kernel (1), vs F.conv2d:
@@ -732,9 +732,12 @@ def test_winograd_conv3x3_matches_torch(case, variant):
     from m3dssd_amd.host import standalone as S
     dev = _dev()
     n, ci, h, w, co, bias, bn, act, res, sg = case
-    if variant == 1 and sg >= 0:                       # no sigmoid epilogue in the wave kernel: refused, never silently wrong
+    split = variant == 2                               # 2 = wave kernel in its split-K form (workspace given)
+    variant = min(variant, 1)
+    if variant == 1 and sg >= 0 and not split:         # the wave kernel has the sigmoid epilogue only when split: refused
         d = _hip.ConvDesc()
         d.sigmoid_from = sg
+        d.Cin, d.Cout_pad, d.N, d.H, d.W = ci, 32, n, h, w
         assert _hip.lib().m3d_wino_conv3x3_variant(ctypes.byref(d)) == 0
         return
     g = torch.Generator().manual_seed(sum(case) + 7)
@@ -764,7 +767,7 @@ def test_winograd_conv3x3_matches_torch(case, variant):
         v, _ = S._to_nhwc(x.to(dev))
         rv = S._to_nhwc(r.to(dev))[0] if res else None
         out, keep = S.conv_nhwc(v, wt.to(dev), None if b is None else b.to(dev), None if bnm is None else bnm.to(dev),
-                                1, 1, act=act, res=rv, sigmoid_from=sg, wino=True, wino_variant=variant)
+                                1, 1, act=act, res=rv, sigmoid_from=sg, wino=True, wino_variant=variant, wino_splitk=split)
         got = S._to_nchw(out, co).cpu()
     assert got.shape == ref.shape
     assert _relerr(got, ref.detach()) < 2e-4
