@@ -379,9 +379,56 @@ __global__ void softmax_rows_kernel(float *__restrict__ x, int rows, int valid, 
     for (int j = lane; j < cs; j += 64) r[j] = j < valid ? expf(r[j] - mx) * inv : 0.f;
 }
 
+// Single-pass variant for rows of up to 64*NV*4 floats with cs % 4 == 0: the row is read once into registers (16-byte loads),
+// same arithmetic as the kernel above (max, then sum of expf(x - max), then the quotient; the per-lane grouping of the sum
+// differs, i.e. fp32 reassociation only); the three-pass kernel re-reads the row from L2 twice.
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(float *__restrict__ x, int rows, int valid, int cs)
+{
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float *r = x + (size_t)row * cs;
+    f32x4 v[NV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int j = (k * 64 + lane) * 4;
+        v[k] = j < cs ? *reinterpret_cast<const f32x4 *>(r + j) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (j + e < valid) mx = fmaxf(mx, v[k][e]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = (k * 64 + lane) * 4 + e;
+            v[k][e] = j < valid ? expf(v[k][e] - mx) : 0.f;
+            sum += v[k][e];
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int j = (k * 64 + lane) * 4;
+        if (j < cs) *reinterpret_cast<f32x4 *>(r + j) = v[k] * inv;
+    }
+}
+
 extern "C" int m3d_softmax_rows(float *x, int rows, int valid, int cs, m3d_stream_t stream)
 {
     M3D_REQUIRE(x && rows > 0 && valid > 0 && cs >= valid, "softmax_rows: bad arguments");
+    if (cs % 4 == 0 && cs <= 512 && ((uintptr_t)x & 15) == 0) {
+        if (cs <= 256) hipLaunchKernelGGL(softmax_rows_reg_kernel<1>, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, rows, valid, cs);
+        else hipLaunchKernelGGL(softmax_rows_reg_kernel<2>, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, rows, valid, cs);
+        M3D_LAUNCH_CHECK();
+        return M3D_OK;
+    }
     hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, rows, valid, cs);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
