@@ -319,13 +319,22 @@ __global__ void anab_pool_nested_finish_kernel(const float *__restrict__ fine, i
     const int bi = local / sz, bj = local - bi * sz, f = 16 / sz;      // f x f finest bins per bin of this scale
     const float inv = 1.f / (float)((H / sz) * (W / sz));
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float acc = 0.f;
-        for (int di = 0; di < f; ++di)
-#pragma unroll 4
-            for (int dj = 0; dj < f; ++dj) {
-                const int fb = (bi * f + di) * 16 + bj * f + dj;
-                acc += fine[(((size_t)b * 256 + fb) * 4 + si) * C + c];
-            }
+        // f*f terms (256 for the whole-map bin): 8 independent partial sums keep 8 loads in flight instead of one dependent
+        // chain, then a fixed-order combine (deterministic)
+        float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float *fp = fine + (((size_t)b * 256) * 4 + si) * C + c;
+        if (f >= 8) {                           // f = 8 or 16: rows of the fine grid in chunks of 8 independent loads
+            for (int di = 0; di < f; ++di)
+                for (int dj = 0; dj < f; dj += 8) {
+                    const float *q = fp + (size_t)((bi * f + di) * 16 + bj * f + dj) * 4 * C;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) part[u] += q[(size_t)u * 4 * C];
+                }
+        } else {                                // f = 1, 2 or 4: at most 16 terms
+            for (int di = 0; di < f; ++di)
+                for (int dj = 0; dj < f; ++dj) part[dj] += fp[(size_t)((bi * f + di) * 16 + bj * f + dj) * 4 * C];
+        }
+        float acc = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
         acc *= inv;
         if (c < Ck) {
             if (frag & 1) khat[(size_t)b * keys_pad * ck_pad + frag_index(bin, c, ck_pad)] = acc;
