@@ -215,6 +215,58 @@ def test_dcn_matches_oracle(shape):
     assert _relerr(got, ref) < 2e-4
 
 
+def test_dcn_properties_closed_forms():
+    """Closed forms of the modulated deformable convolution through the drop-in op (dcn_v2_im2col_cuda.cu:18-47,129-178):
+    integer offsets == a shifted plain convolution of the zero-padded input; the output is linear in the mask; samples
+    pushed entirely outside the map contribute exactly nothing (only the bias remains)."""
+    from m3dssd_amd.host import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    n, c, h, w, co, k, pad = 2, 32, 12, 14, 16, 3, 1
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(co, c, k, k, generator=g) / 17.0
+    b = torch.randn(co, generator=g)
+    ones = torch.ones(n, k * k, h, w)
+    # integer offsets (dy, dx) = (2, -1) on every tap == conv of x shifted by (-2, +1) with zero fill
+    off = torch.zeros(n, 2 * k * k, h, w)
+    off[:, 0::2] = 2.0
+    off[:, 1::2] = -1.0
+    got = ops.dcn_v2_forward(x.to(dev), off.to(dev), ones.to(dev), wt.to(dev), b.to(dev), 1, pad, 1, 1).cpu()
+    # tap (i, j) of output (ho, wo) reads x[ho - 1 + i + 2][wo - 1 + j - 1] (zero outside the map): crop one row at the top,
+    # pad three at the bottom and two columns on the left, then a plain unpadded convolution
+    ref = F.conv2d(F.pad(x, (2, 0, -1, 3)), wt, b)
+    assert _relerr(got, ref) < 2e-4
+    # linearity in the mask: f(a*m1 + b*m2) - bias == a*(f(m1) - bias) + b*(f(m2) - bias)
+    offr = torch.randn(n, 2 * k * k, h, w, generator=g) * 2.0
+    m1, m2 = torch.rand(n, k * k, h, w, generator=g), torch.rand(n, k * k, h, w, generator=g)
+    f = lambda m: ops.dcn_v2_forward(x.to(dev), offr.to(dev), m.to(dev), wt.to(dev), b.to(dev), 1, pad, 1, 1).cpu() - b.view(1, -1, 1, 1)
+    lhs, rhs = f(0.3 * m1 + 0.7 * m2), 0.3 * f(m1) + 0.7 * f(m2)
+    assert (lhs - rhs).abs().max().item() < 1e-4 * max(1.0, rhs.abs().max().item())
+    # every sample outside the map: only the bias is left, exactly
+    far = torch.full((n, 2 * k * k, h, w), 100.0)
+    out = ops.dcn_v2_forward(x.to(dev), far.to(dev), ones.to(dev), wt.to(dev), b.to(dev), 1, pad, 1, 1).cpu()
+    assert torch.equal(out, b.view(1, -1, 1, 1).expand_as(out).contiguous())
+
+
+def test_nms_collisions_and_disjoint_sets():
+    """Domain edge cases of lib/nms (nms_kernel.cu:24-144): identical boxes -> only the first in score order survives;
+    pairwise disjoint boxes -> all survive; IoU exactly at the threshold is kept (suppression is strict '>')."""
+    from m3dssd_amd.host import ops
+    dev = _dev()
+    same = np.tile(np.array([[10.0, 20.0, 60.0, 90.0, 0.0]], dtype=np.float32), (130, 1))
+    same[:, 4] = np.linspace(0.9, 0.1, 130, dtype=np.float32)
+    keep, num = ops.nms_sorted(torch.from_numpy(same).to(dev), 0.4)
+    assert int(num[0]) == 1 and int(keep[0, 0]) == 0
+    grid = np.array([[100.0 * i, 50.0 * j, 100.0 * i + 40, 50.0 * j + 30, 1.0 - 0.001 * (i * 20 + j)]
+                     for i in range(12) for j in range(20)], dtype=np.float32)
+    keep, num = ops.nms_sorted(torch.from_numpy(grid).to(dev), 0.4)
+    assert int(num[0]) == len(grid) and np.array_equal(keep[0, :len(grid)].cpu().numpy(), np.arange(len(grid)))
+    # two boxes with IoU exactly 1/3 (areas 100 px each incl. the +1 convention, overlap 50): kept at thresh 1/3
+    pair = np.array([[0, 0, 9, 9, 0.9], [5, 0, 14, 9, 0.8]], dtype=np.float32)
+    assert int(ops.nms_sorted(torch.from_numpy(pair).to(dev), 50.0 / 150.0)[1][0]) == 2
+    assert int(ops.nms_sorted(torch.from_numpy(pair).to(dev), 0.33)[1][0]) == 1
+
+
 def test_dcn_module_errors_like_reference():
     from model.DCNv2.dcn_v2 import DCNv2
     dev = _dev()
