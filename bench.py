@@ -110,14 +110,28 @@ def main():
 
     from m3dssd_amd import dist as mdist
     from m3dssd_amd import synth
-    from lib.rpn_util import detect_batch
+    from m3dssd_amd.host.detect import detect_device, select_block
     from model.M3d_inference_align import build
 
-    rank, world, local = mdist.init_from_env()
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one process per GPU under torch.distributed.run
+        # (RCCL rendezvous on 127.0.0.1; rank 0 prints the JSON line on the inherited stdout)
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("OMP_NUM_THREADS", "8")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    rank, world, local = mdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     B = args.batch
@@ -131,10 +145,10 @@ def main():
     eng = net.engine()
 
     def step():
-        dets, counts = detect_batch(net, x, conf)
+        block, counts = select_block(*detect_device(net, x, conf), conf)
         if world > 1:
-            dets, counts = mdist.gather_detections(dets, counts)
-        return dets, counts
+            return mdist.gather_block(block)
+        return block[:, :-1], counts
 
     # ---- warm-up: first step builds the plan; one fully instrumented step finds the dominant kernel ----
     for _ in range(max(1, args.warmup - 1)):
@@ -184,15 +198,15 @@ def main():
         pipe.input.copy_(x)
 
         def timed_step():
-            r = pipe.step()
+            r = pipe.step(as_block=True)
             if world > 1 and r is not None:
-                return mdist.gather_detections(*r)
+                return mdist.gather_block(r[0])
             return r
 
         def flush():
-            r = pipe.flush()
+            r = pipe.flush(as_block=True)
             if world > 1 and r is not None:
-                return mdist.gather_detections(*r)
+                return mdist.gather_block(r[0])
             return r
         timed_step()
         flush()
@@ -201,17 +215,17 @@ def main():
         cap_stream = torch.cuda.Stream()
         cap_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cap_stream):
-            detect_batch(net, x, conf)                       # warm the side stream (allocator pools)
+            select_block(*detect_device(net, x, conf), conf)  # warm the side stream (allocator pools)
             torch.cuda.synchronize()
             with torch.cuda.graph(graph, stream=cap_stream):
-                g_dets, g_counts = detect_batch(net, x, conf)
+                g_block, g_counts = select_block(*detect_device(net, x, conf), conf)
         torch.cuda.current_stream().wait_stream(cap_stream)
 
         def timed_step():
             graph.replay()
             if world > 1:
-                return mdist.gather_detections(g_dets, g_counts)
-            return g_dets, g_counts
+                return mdist.gather_block(g_block)
+            return g_block[:, :-1], g_counts
         timed_step()
     else:
         timed_step = step

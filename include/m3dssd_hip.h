@@ -257,10 +257,21 @@ int m3d_softmax_rows(float *x, int rows, int valid, int cs, m3d_stream_t stream)
  * Outputs, decode, NMS.
  * ------------------------------------------------------------------------------------------ */
 /* planar staging (cls [B][4A][HW], box [B][11][A][HW] in the order x,y,w,h,x3d,y3d,z3d,w3d,h3d,l3d,rY3d)
- * -> cls/prob [B][A*HW][4], bbox_2d [B][A*HW][4], bbox_3d [B][A*HW][7], and (optional) a sortable
- * 64-bit key per row: (monotone bits of max fg class prob) << 32 | (0xFFFFFFFF - row). */
+ * -> cls/prob [B][A*HW][4], bbox_2d [B][A*HW][4], bbox_3d [B][A*HW][7], and (optional) score_bits [B][A*HW]: the
+ * max fg class probability of the row as monotone unsigned bits (a > b as floats <=> bits(a) > bits(b)), the sort
+ * key of m3d_topk_decode. */
 int m3d_bundle_outputs(const float *cls_planar, const float *box_planar, float *cls, float *prob, float *bbox_2d,
-                       float *bbox_3d, long long *score_key, int B, int A, int HW, m3d_stream_t stream);
+                       float *bbox_3d, unsigned int *score_bits, int B, int A, int HW, m3d_stream_t stream);
+/* The reference's `argsort()[::-1][:nms_topN_pre]` + decode (lib/rpn_util.py:1442-1544) in one launch, one workgroup
+ * per image: radix select of the k rows with the largest (score, -row) -- descending score, ascending row among equal
+ * scores: a total order, unlike the reference's unstable argsort -- bitonic sort of those k, decode of exactly those rows
+ * -> aboxes [B][k][14] (x1,y1,x2,y2,score,cls,x3d,y3d,z3d,w3d,h3d,l3d,ry3d,anchor), score-descending; rows_out [B][k]
+ * (optional) gets the selected row ids.  1 <= k <= min(R, 4096), R < 2^22; workspace: m3d_topk_decode_workspace_bytes. */
+long long m3d_topk_decode_workspace_bytes(int B, int R);
+int m3d_topk_decode(const unsigned int *score_bits, const float *prob, const float *bbox_2d, const float *bbox_3d,
+                    const float *rois /*[R][5]*/, const float *anchors /*[A][9]*/, const float *means /*[11]*/,
+                    const float *stds /*[11]*/, float *aboxes, int *rows_out, void *workspace, long long workspace_bytes,
+                    int B, int R, int k, m3d_stream_t stream);
 /* Decode `n_rows` selected rows per image -> aboxes [B][n_rows][14]
  * (x1,y1,x2,y2,score,cls,x3d,y3d,z3d,w3d,h3d,l3d,ry3d,anchor). */
 int m3d_decode_rows(const long long *rows /*[B][n_rows] row ids*/, const float *prob, const float *bbox_2d,
@@ -273,6 +284,11 @@ int m3d_decode_rows(const long long *rows /*[B][n_rows] row ids*/, const float *
 long long m3d_nms_workspace_bytes(int B, int n);
 int m3d_nms_sorted_dev(const float *boxes_dev, int B, int n, int box_stride, float thresh, void *mask_ws,
                        int *keep_dev, int *num_keep_dev, m3d_stream_t stream);
+/* Kept rows of the NMS -> fixed-size blocks (lib/rpn_util.py:1547-1555 `aboxes[keep][:nms_topN_post]`): block
+ * [B][post + 1][14], rows [0, min(num_keep, post)) = aboxes[keep[j]], the rest zero, row `post` = (count, 0, ...) -- the
+ * message of the multi-GPU all-gather; counts [B] (optional) gets min(num_keep, post). */
+int m3d_select_post(const float *aboxes /*[B][n][14]*/, const int *keep /*[B][n]*/, const int *num_keep /*[B]*/, int B, int n,
+                    int post, float *block, int *counts, m3d_stream_t stream);
 /* Exact twin of the reference's _nms (lib/nms/gpu_nms.hpp): host pointers, synchronous. */
 void _nms(int *keep_out, int *num_out, const float *boxes_host, int boxes_num, int boxes_dim,
           float nms_overlap_thresh, int device_id);

@@ -14,7 +14,7 @@ void m3d_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *m3d_last_error(void) { return g_err; }
-extern "C" int m3d_abi_version(void) { return 1; }
+extern "C" int m3d_abi_version(void) { return 2; }
 
 // ------------------------------------------------------------------------------------------
 extern "C" int m3d_event_create(void **ev)

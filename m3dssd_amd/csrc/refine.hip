@@ -6,6 +6,10 @@
 // -- which the reference does in Python / numpy on the host (<= 40 boxes x ~14 projections per image).  Contraction is off and
 // every dot product is accumulated left to right; against numpy the results agree to ~1e-12 (BLAS may fuse / reorder), far
 // inside the 6 decimals of the KITTI result format.
+// numpy scalar semantics of the reference's environment (requirements.txt:50 pins numpy==1.18.1: value-based promotion) are
+// mirrored: `box = aboxes[i]` holds np.float32 scalars, so x3d*z3d, y3d*z3d (rpn_util.py:1825,1836 and test_projection :2025,
+// where cx, cy, z arrive as np.float32), the box width / height (:1813-1814) and x + w - 1 (:2022-2023) are ROUNDED TO FLOAT32
+// before they widen into the float64 arithmetic; np.float32 + Python float (the angle conversions, ry3d +- step) is float64.
 #include "common.h"
 
 #pragma clang fp contract(off)
@@ -30,11 +34,16 @@ __device__ __forceinline__ double wrap_pi(double a)
 }
 
 // test_projection: returns ol, sets *invalid
-__device__ double test_projection_dev(const double *p2, const double *pi, double bx, double by, double bw, double bh, double cx,
-                                      double cy, double z, double w3d, double h3d, double l3d, double rot, bool *invalid)
+// bx, by, bw, bh, cx, cy are float32 values (the row's np.float32 scalars); z_f32: z is still the row's float32 depth (always,
+// for the depth step of 0 the reference passes) -> the products round to float32 like np.float32 * np.float32
+__device__ double test_projection_dev(const double *p2, const double *pi, float bxf, float byf, float bwf, float bhf, float cxf,
+                                      float cyf, double z, bool z_f32, double w3d, double h3d, double l3d, double rot,
+                                      bool *invalid)
 {
-    const double x2 = bx + bw - 1, y2 = by + bh - 1;
-    const double v0 = cx * z, v1 = cy * z;
+    const double bx = bxf, by = byf;
+    const double x2 = (double)((bxf + bwf) - 1.0f), y2 = (double)((byf + bhf) - 1.0f);
+    const double v0 = z_f32 ? (double)(cxf * (float)z) : (double)cxf * z;
+    const double v1 = z_f32 ? (double)(cyf * (float)z) : (double)cyf * z;
     const double X = pi[0] * v0 + pi[1] * v1 + pi[2] * z + pi[3] * 1.0;
     const double Y = pi[4] * v0 + pi[5] * v1 + pi[6] * z + pi[7] * 1.0;
     const double Z = pi[8] * v0 + pi[9] * v1 + pi[10] * z + pi[11] * 1.0;
@@ -76,38 +85,40 @@ __global__ void refine3d_kernel(const RefineArgs a)
         return;
     }
     const double *p2 = a.p2 + (size_t)b * 16, *pi = a.p2_inv + (size_t)b * 16;
-    const double x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
-    const double x3d = r[6], y3d = r[7];
+    const float x1f = r[0], y1f = r[1], x2f = r[2], y2f = r[3], x3f = r[6], y3f = r[7];
+    const double x1 = x1f, y1 = y1f, x2 = x2f, y2 = y2f;
     double z3d = r[8];
+    bool z_f32 = true;                                                         // z3d is still the row's np.float32
     const double w3d = r[9], h3d = r[10], l3d = r[11];
     double ry = r[12];
     {
-        const double v0 = x3d * z3d, v1 = y3d * z3d;
+        const double v0 = (double)(x3f * r[8]), v1 = (double)(y3f * r[8]);     // np.float32 products (rpn_util.py:1825)
         const double X = pi[0] * v0 + pi[1] * v1 + pi[2] * z3d + pi[3] * 1.0;
         const double Z = pi[8] * v0 + pi[9] * v1 + pi[10] * z3d + pi[11] * 1.0;
         ry = wrap_pi(ry + atan2(-Z, X) + 0.5 * REF_PI);                       // convertAlpha2Rot
     }
     if (a.hill_climbing) {
-        const double bw = x2 - x1 + 1, bh = y2 - y1 + 1;
+        const float bw = (x2f - x1f) + 1.0f, bh = (y2f - y1f) + 1.0f;        // np.float32 (rpn_util.py:1813-1814)
+        const float x1 = x1f, y1 = y1f, x3d = x3f, y3d = y3f;
         double step_z = a.step_z_init, step_r = a.step_r_init;
         bool invalid;
-        double ol_best = test_projection_dev(p2, pi, x1, y1, bw, bh, x3d, y3d, z3d, w3d, h3d, l3d, ry, &invalid);
+        double ol_best = test_projection_dev(p2, pi, x1, y1, bw, bh, x3d, y3d, z3d, z_f32, w3d, h3d, l3d, ry, &invalid);
         if (!invalid) {
             int guard = 0;
             while ((step_z > a.z_lim || step_r > a.r_lim) && ++guard < 100000) {
                 if (step_z > a.z_lim) {
                     bool in_neg, in_pos;
-                    const double ol_neg = test_projection_dev(p2, pi, x1, y1, bw, bh, x3d, y3d, z3d - step_z, w3d, h3d, l3d, ry, &in_neg);
-                    const double ol_pos = test_projection_dev(p2, pi, x1, y1, bw, bh, x3d, y3d, z3d + step_z, w3d, h3d, l3d, ry, &in_pos);
+                    const double ol_neg = test_projection_dev(p2, pi, x1, y1, bw, bh, x3d, y3d, z3d - step_z, false, w3d, h3d, l3d, ry, &in_neg);
+                    const double ol_pos = test_projection_dev(p2, pi, x1, y1, bw, bh, x3d, y3d, z3d + step_z, false, w3d, h3d, l3d, ry, &in_pos);
                     if (((ol_pos - ol_best) <= a.min_ol_dif) && ((ol_neg - ol_best) <= a.min_ol_dif)) step_z = step_z * 0.5;
-                    else if ((ol_pos - ol_best) > a.min_ol_dif && ol_pos > ol_neg && !in_pos) { z3d += step_z; ol_best = ol_pos; }
-                    else if ((ol_neg - ol_best) > a.min_ol_dif && !in_neg) { z3d -= step_z; ol_best = ol_neg; }
+                    else if ((ol_pos - ol_best) > a.min_ol_dif && ol_pos > ol_neg && !in_pos) { z3d += step_z; z_f32 = false; ol_best = ol_pos; }
+                    else if ((ol_neg - ol_best) > a.min_ol_dif && !in_neg) { z3d -= step_z; z_f32 = false; ol_best = ol_neg; }
                     else step_z = step_z * 0.5;
                 }
                 if (step_r > a.r_lim) {
                     bool in_neg, in_pos;
-                    const double ol_neg = test_projection_dev(p2, pi, x1, y1, bw, bh, x3d, y3d, z3d, w3d, h3d, l3d, ry - step_r, &in_neg);
-                    const double ol_pos = test_projection_dev(p2, pi, x1, y1, bw, bh, x3d, y3d, z3d, w3d, h3d, l3d, ry + step_r, &in_pos);
+                    const double ol_neg = test_projection_dev(p2, pi, x1, y1, bw, bh, x3d, y3d, z3d, z_f32, w3d, h3d, l3d, ry - step_r, &in_neg);
+                    const double ol_pos = test_projection_dev(p2, pi, x1, y1, bw, bh, x3d, y3d, z3d, z_f32, w3d, h3d, l3d, ry + step_r, &in_pos);
                     if (((ol_pos - ol_best) <= a.min_ol_dif) && ((ol_neg - ol_best) <= a.min_ol_dif)) step_r = step_r * 0.5;
                     else if ((ol_pos - ol_best) > a.min_ol_dif && ol_pos > ol_neg && !in_pos) { ry += step_r; ol_best = ol_pos; }
                     else if ((ol_neg - ol_best) > a.min_ol_dif && !in_neg) { ry -= step_r; ol_best = ol_neg; }
@@ -117,7 +128,8 @@ __global__ void refine3d_kernel(const RefineArgs a)
             ry = wrap_pi(ry);
         }
     }
-    const double v0 = x3d * z3d, v1 = y3d * z3d;
+    const double v0 = z_f32 ? (double)(x3f * (float)z3d) : (double)x3f * z3d;   // rpn_util.py:1836
+    const double v1 = z_f32 ? (double)(y3f * (float)z3d) : (double)y3f * z3d;
     const double X = pi[0] * v0 + pi[1] * v1 + pi[2] * z3d + pi[3] * 1.0;
     const double Y = pi[4] * v0 + pi[5] * v1 + pi[6] * z3d + pi[7] * 1.0;
     const double Z = pi[8] * v0 + pi[9] * v1 + pi[10] * z3d + pi[11] * 1.0;

@@ -454,7 +454,7 @@ __device__ __forceinline__ unsigned int f32_sortable(float f)
 
 __global__ void bundle_outputs_kernel(const float *__restrict__ cls_pl, const float *__restrict__ box_pl,
                                       float *__restrict__ cls, float *__restrict__ prob, float *__restrict__ b2,
-                                      float *__restrict__ b3, long long *__restrict__ key, int A, int HW)
+                                      float *__restrict__ b3, unsigned int *__restrict__ key, int A, int HW)
 {
     const int b = blockIdx.y;
     const int R = A * HW;
@@ -485,80 +485,18 @@ __global__ void bundle_outputs_kernel(const float *__restrict__ cls_pl, const fl
     for (int k = 0; k < 7; ++k) b3[o * 7 + k] = bb[(size_t)(4 + k) * R];
     if (key) {
         const float sc = fmaxf(fmaxf(pr[1], pr[2]), pr[3]);
-        key[o] = (long long)(((unsigned long long)f32_sortable(sc) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)row));
+        key[o] = f32_sortable(sc);
     }
 }
 
 extern "C" int m3d_bundle_outputs(const float *cls_planar, const float *box_planar, float *cls, float *prob,
-                                  float *bbox_2d, float *bbox_3d, long long *score_key, int B, int A, int HW,
+                                  float *bbox_2d, float *bbox_3d, unsigned int *score_bits, int B, int A, int HW,
                                   m3d_stream_t stream)
 {
     M3D_REQUIRE(cls_planar && box_planar && cls && prob && bbox_2d && bbox_3d, "bundle_outputs: null pointer");
     hipLaunchKernelGGL(bundle_outputs_kernel, dim3(cdiv((long long)A * HW, 256), B), dim3(256), 0, (hipStream_t)stream,
-                       cls_planar, box_planar, cls, prob, bbox_2d, bbox_3d, score_key, A, HW);
+                       cls_planar, box_planar, cls, prob, bbox_2d, bbox_3d, score_bits, A, HW);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
 }
 
-// ---------------------------------------------------------------------------------------
-// Decode (lib/rpn_util.py:1442-1521 + bbox_transform_inv :1137-1186), scale_factor = 1.
-// Row layout out: x1,y1,x2,y2,score,cls,x3d,y3d,z3d,w3d,h3d,l3d,ry3d,anchor  (rpn_util.py:1550)
-__global__ void decode_rows_kernel(const long long *__restrict__ rows, const float *__restrict__ prob,
-                                   const float *__restrict__ b2, const float *__restrict__ b3,
-                                   const float *__restrict__ rois, const float *__restrict__ anchors,
-                                   const float *__restrict__ means, const float *__restrict__ stds,
-                                   float *__restrict__ out, int R, int n_rows)
-{
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rows) return;
-    const int row = (int)rows[(size_t)b * n_rows + i];
-    const size_t o = (size_t)b * R + row;
-    const float *ro = rois + (size_t)row * 5;
-    const float x1 = ro[0], y1 = ro[1], x2 = ro[2], y2 = ro[3];
-    const int tr = (int)ro[4];
-    const float *an = anchors + tr * 9;
-    const float widths = x2 - x1 + 1.0f, heights = y2 - y1 + 1.0f;
-    const float ctr_x = x1 + 0.5f * widths, ctr_y = y1 + 0.5f * heights;
-    float d3[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) d3[k] = b3[o * 7 + k] * stds[4 + k] + means[4 + k];
-    float *q = out + ((size_t)b * n_rows + i) * 14;
-    const float dx = b2[o * 4 + 0] * stds[0] + means[0];
-    const float dy = b2[o * 4 + 1] * stds[1] + means[1];
-    const float dw = b2[o * 4 + 2] * stds[2] + means[2];
-    const float dh = b2[o * 4 + 3] * stds[3] + means[3];
-    const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
-    const float pw = expf(dw) * widths, ph = expf(dh) * heights;
-    q[0] = pcx - 0.5f * pw;
-    q[1] = pcy - 0.5f * ph;
-    q[2] = pcx + 0.5f * pw;
-    q[3] = pcy + 0.5f * ph;
-    const float p1 = prob[o * 4 + 1], p2 = prob[o * 4 + 2], p3 = prob[o * 4 + 3];
-    float sc = p1;
-    int cl = 1;
-    if (p2 > sc) { sc = p2; cl = 2; }
-    if (p3 > sc) { sc = p3; cl = 3; }
-    q[4] = sc;
-    q[5] = (float)cl;
-    q[6] = d3[0] * widths + ctr_x;
-    q[7] = d3[1] * heights + ctr_y;
-    q[8] = an[4] + d3[2];
-    q[9] = expf(d3[3]) * an[5];
-    q[10] = expf(d3[4]) * an[6];
-    q[11] = expf(d3[5]) * an[7];
-    q[12] = an[8] + d3[6];
-    q[13] = (float)tr;
-}
-
-extern "C" int m3d_decode_rows(const long long *rows, const float *prob, const float *bbox_2d, const float *bbox_3d,
-                               const float *rois, const float *anchors, const float *means, const float *stds,
-                               float *aboxes, int B, int R, int n_rows, m3d_stream_t stream)
-{
-    M3D_REQUIRE(rows && prob && bbox_2d && bbox_3d && rois && anchors && means && stds && aboxes && n_rows > 0,
-                "decode_rows: bad arguments");
-    hipLaunchKernelGGL(decode_rows_kernel, dim3(cdiv(n_rows, 256), B), dim3(256), 0, (hipStream_t)stream, rows, prob,
-                       bbox_2d, bbox_3d, rois, anchors, means, stds, aboxes, R, n_rows);
-    M3D_LAUNCH_CHECK();
-    return M3D_OK;
-}

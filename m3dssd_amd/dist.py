@@ -28,7 +28,7 @@ def init_from_env(backend=None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -46,20 +46,39 @@ def shard_batch(batch, rank, world):
     return batch[lo:hi]
 
 
+_GATHER_OUT = {}
+
+
+def gather_block(block, group=None):
+    """block [b, P + 1, 14] float32 as written by ``m3d_select_post`` (row P = (count, 0, ...)), this rank's shard ->
+    (all_dets [world*b, P, 14], all_counts [world*b] int32) identical on every rank, in global image order.
+    ONE collective, no staging copy; the receive buffer is cached per shape (the returned tensors are views of it and
+    are overwritten by the next call with the same shape)."""
+    if block.dim() != 3 or block.shape[2] != ROW or not block.is_contiguous():
+        raise ValueError("gather_block: block must be contiguous [b, P + 1, 14]")
+    b, p1, _ = block.shape
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return block[:, :p1 - 1], block[:, p1 - 1, 0].to(torch.int32)
+    world = dist.get_world_size(group)
+    key = (block.device, b, p1, world, id(group))
+    out = _GATHER_OUT.get(key)
+    if out is None:
+        out = _GATHER_OUT[key] = torch.empty(world * b, p1, ROW, device=block.device, dtype=torch.float32)
+    dist.all_gather_into_tensor(out, block, group=group)
+    return out[:, :p1 - 1], out[:, p1 - 1, 0].to(torch.int32)
+
+
 def gather_detections(dets, counts, group=None):
     """dets [b, P, 14] float32, counts [b] int32 (this rank's shard) ->
-    (all_dets [world*b, P, 14], all_counts [world*b]) identical on every rank, in global image order."""
+    (all_dets [world*b, P, 14], all_counts [world*b]) identical on every rank, in global image order.
+    (Callers that already hold the [b, P + 1, 14] block of ``select_block`` use ``gather_block`` and skip the staging copy.)"""
     if dets.dim() != 3 or dets.shape[2] != ROW or counts.shape[0] != dets.shape[0]:
         raise ValueError("gather_detections: dets must be [b, P, 14] and counts [b]")
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return dets, counts
-    world = dist.get_world_size(group)
     b, p, _ = dets.shape
     # counts travel in the same message as the boxes (one collective, one latency): last row of the block
-    block = torch.empty(b, p + 1, ROW, device=dets.device, dtype=torch.float32)
+    block = torch.zeros(b, p + 1, ROW, device=dets.device, dtype=torch.float32)
     block[:, :p] = dets
-    block[:, p] = 0
     block[:, p, 0] = counts.to(torch.float32)
-    out = torch.empty(world * b, p + 1, ROW, device=dets.device, dtype=torch.float32)
-    dist.all_gather_into_tensor(out, block.contiguous(), group=group)
-    return out[:, :p].contiguous(), out[:, p, 0].to(torch.int32)
+    return gather_block(block, group)

@@ -53,8 +53,8 @@ class View:
 
 class _Stream:
     @staticmethod
-    def current():
-        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    def current(device=None):
+        return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 class PackedConv:
@@ -144,6 +144,8 @@ class Engine:
         self.device = torch.device(device if device is not None else conf.device)
         if self.device.type != "cuda":
             raise NotImplementedError("the M3DSSD HIP engine runs on a ROCm device only (got %s)" % self.device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.conf = conf
         sd = {k[7:] if k.startswith("module.") else k: v for k, v in state_dict.items()}
         self.sd = sd
@@ -617,8 +619,8 @@ class Engine:
         prob = torch.empty(B, R, NC, device=self.device, dtype=torch.float32)
         b2 = torch.empty(B, R, 4, device=self.device, dtype=torch.float32)
         b3 = torch.empty(B, R, 7, device=self.device, dtype=torch.float32)
-        key = torch.empty(B, R, device=self.device, dtype=torch.int64)
-        plan.named.update(cls=cls, prob=prob, bbox_2d=b2, bbox_3d=b3, score_key=key)
+        key = torch.empty(B, R, device=self.device, dtype=torch.int32)   # monotone score bits (u32)
+        plan.named.update(cls=cls, prob=prob, bbox_2d=b2, bbox_3d=b3, score_bits=key)
         assert NC == 4, "bundle kernel is written for 4 classes (bg + 3)"
         self._op(plan, "bundle_outputs", "bundle", lambda st: _hip.check(L.m3d_bundle_outputs(
             cls_pl.data_ptr(), box_pl.data_ptr(), cls.data_ptr(), prob.data_ptr(), b2.data_ptr(), b3.data_ptr(),
@@ -736,6 +738,8 @@ class Engine:
         (views of plan-owned buffers, overwritten by the next call with the same shape)."""
         if not x.is_cuda:
             raise NotImplementedError("M3DSSD HIP engine: input must be a ROCm device tensor")
+        if x.device != self.device:
+            raise RuntimeError("M3DSSD HIP engine on %s got an input on %s" % (self.device, x.device))
         B, _, H, W = x.shape
         plan = self.plan_for(B, H, W)
         x = x.contiguous()
@@ -753,6 +757,8 @@ class Engine:
             raise NotImplementedError("forward_u8: uint8 [B, h, w, 3] ROCm device tensor expected")
         H, W = (int(v) for v in (size if size is not None else self.conf.crop_size))
         B, h, w, _ = frames.shape
+        if frames.device != self.device:
+            raise RuntimeError("M3DSSD HIP engine on %s got frames on %s" % (self.device, frames.device))
         if h > H or w > W:
             raise RuntimeError("forward_u8: frame %dx%d does not fit the padded size %dx%d" % (h, w, H, W))
         plan = self.plan_for(B, H, W)
@@ -775,8 +781,13 @@ class Engine:
         return plan.named["feats0"]
 
     def run_plan(self, plan, start=0, end=None):
-        """Issue plan.ops[start:end] on the current stream (the whole forward by default)."""
-        st = _Stream.current()
+        """Issue plan.ops[start:end] on the ENGINE device's current stream (the whole forward by default); the engine's
+        device is made current for the launches, whatever the caller's current device is."""
+        with torch.cuda.device(self.device):
+            self._run_plan(plan, start, end)
+
+    def _run_plan(self, plan, start, end):
+        st = _Stream.current(self.device)
         ops = plan.ops[start:end]
         if self.profile is None:
             for op in ops:

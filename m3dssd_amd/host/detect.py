@@ -6,8 +6,9 @@ x1,y1,x2,y2,score,cls,x3d,y3d,z3d,w3d,h3d,l3d,ry3d,anchor in descending-score or
 ``detect_batch`` is the batched form the reference lacks (it indexes batch 0, :1484-1503): it
 returns fixed-size blocks [B, nms_topN_post, 14] + counts, the wire format of the multi-GPU gather.
 
-The score sort uses the 64-bit keys written by ``m3d_bundle_outputs`` (score bits, inverted row id) so
-the order is total: descending score, ascending row among equals."""
+The descending score sort + top-N-pre cut + decode is ONE launch (``m3d_topk_decode``: radix select over the total
+order "descending score, ascending row among equals" on the score bits written by ``m3d_bundle_outputs``), NMS is two
+(``m3d_nms_sorted_dev``), the post-NMS row selection one (``m3d_select_post``): four launches, no ATen kernels."""
 import ctypes
 
 import numpy as np
@@ -15,32 +16,44 @@ import torch
 
 from .. import _hip
 
+NMS_MAX_PRE = 4096        # m3d_nms_sorted_dev / m3d_topk_decode: one 64-bit "removed" word per lane, k keys in LDS
 
-def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def check_conf(conf):
+    """Limits of the device detection stage, checked where the module is built (clear message instead of a C-ABI error)."""
+    if int(conf.nms_topN_pre) > NMS_MAX_PRE:
+        raise ValueError("nms_topN_pre = %d: the device NMS / top-k handle at most %d pre-NMS boxes per image "
+                         "(the reference default is 3000)" % (int(conf.nms_topN_pre), NMS_MAX_PRE))
+    if len(conf.lbls) + 1 != 4:
+        raise ValueError("the output bundling / decode kernels are written for 4 classes (background + 3), got %d"
+                         % (len(conf.lbls) + 1))
 
 
 def detect_from_outputs(eng, plan, prob, bbox_2d, bbox_3d, rois, conf):
-    """decode -> top-N-pre -> NMS on the engine's output buffers (current stream).
+    """top-N-pre select + decode -> NMS on the engine's output buffers (current stream of their device).
     -> (aboxes [B, n_pre, 14] score-sorted, keep [B, n_pre] int32 positions, num_keep [B] int32)."""
     L = _hip.lib()
     dev = prob.device
     B, R = prob.shape[0], prob.shape[1]
-    keys = plan.named["score_key"]
+    bits = plan.named["score_bits"]
     n_pre = min(int(conf.nms_topN_pre), R)
-    top = torch.topk(keys, n_pre, dim=1, largest=True, sorted=True)[0]
-    rows = (0xFFFFFFFF - (top & 0xFFFFFFFF)).contiguous()              # int64 row ids, score-descending
-    aboxes = torch.empty(B, n_pre, 14, device=dev, dtype=torch.float32)
     P = eng.P
     with torch.cuda.device(dev):
-        _hip.check(L.m3d_decode_rows(rows.data_ptr(), prob.data_ptr(), bbox_2d.data_ptr(), bbox_3d.data_ptr(),
-                                     rois.data_ptr(), P["anchors"].data_ptr(), P["means"].data_ptr(),
-                                     P["stds"].data_ptr(), aboxes.data_ptr(), B, R, n_pre, _stream()))
+        st = _stream(dev)
+        aboxes = torch.empty(B, n_pre, 14, device=dev, dtype=torch.float32)
         keep = torch.empty(B, n_pre, device=dev, dtype=torch.int32)
-        num = torch.zeros(B, device=dev, dtype=torch.int32)
-        ws = torch.empty(L.m3d_nms_workspace_bytes(B, n_pre), device=dev, dtype=torch.uint8)
+        num = torch.empty(B, device=dev, dtype=torch.int32)
+        tk_bytes = L.m3d_topk_decode_workspace_bytes(B, R)
+        ws = torch.empty(max(tk_bytes, L.m3d_nms_workspace_bytes(B, n_pre)), device=dev, dtype=torch.uint8)
+        _hip.check(L.m3d_topk_decode(bits.data_ptr(), prob.data_ptr(), bbox_2d.data_ptr(), bbox_3d.data_ptr(),
+                                     rois.data_ptr(), P["anchors"].data_ptr(), P["means"].data_ptr(),
+                                     P["stds"].data_ptr(), aboxes.data_ptr(), None, ws.data_ptr(), tk_bytes, B, R, n_pre, st))
         _hip.check(L.m3d_nms_sorted_dev(aboxes.data_ptr(), B, n_pre, 14, float(conf.nms_thres), ws.data_ptr(),
-                                        keep.data_ptr(), num.data_ptr(), _stream()))
+                                        keep.data_ptr(), num.data_ptr(), st))
     return aboxes, keep, num
 
 
@@ -76,20 +89,28 @@ def im_detect_3d(im, net, rpn_conf, obj=None, gpu=0, synced=False):
     return out
 
 
+def select_block(aboxes, keep, num, conf):
+    """Kept rows -> (block [B, nms_topN_post + 1, 14], counts [B] int32): rows [0, count) of image b are its detections,
+    the rest zero, row nms_topN_post carries the count -- the all-gather message of m3dssd_amd.dist."""
+    L = _hip.lib()
+    dev = aboxes.device
+    B, n = aboxes.shape[0], aboxes.shape[1]
+    post = int(conf.nms_topN_post)
+    with torch.cuda.device(dev):
+        block = torch.empty(B, post + 1, 14, device=dev, dtype=torch.float32)
+        counts = torch.empty(B, device=dev, dtype=torch.int32)
+        _hip.check(L.m3d_select_post(aboxes.data_ptr(), keep.data_ptr(), num.data_ptr(), B, n, post, block.data_ptr(),
+                                     counts.data_ptr(), _stream(dev)))
+    return block, counts
+
+
 def select_post(aboxes, keep, num, conf):
     """Kept rows -> fixed-size blocks (dets [B, nms_topN_post, 14] zero-padded, counts [B] int32)."""
-    B = aboxes.shape[0]
-    post = int(conf.nms_topN_post)
-    idx = keep[:, :post].long().clamp_(min=0, max=aboxes.shape[1] - 1)
-    counts = torch.clamp(num, max=post)
-    dets = torch.gather(aboxes, 1, idx[:, :, None].expand(B, idx.shape[1], 14))
-    valid = torch.arange(idx.shape[1], device=dets.device)[None, :] < counts[:, None]
-    dets = dets * valid[:, :, None].to(dets.dtype)
-    if dets.shape[1] < post:
-        dets = torch.cat([dets, dets.new_zeros(B, post - dets.shape[1], 14)], 1)
-    return dets.contiguous(), counts.to(torch.int32)
+    block, counts = select_block(aboxes, keep, num, conf)
+    return block[:, :-1], counts
 
 
 def detect_batch(net, im, conf):
-    """-> (dets [B, nms_topN_post, 14] zero-padded, counts [B] int32) device tensors."""
+    """-> (dets [B, nms_topN_post, 14] zero-padded, counts [B] int32) device tensors (dets is a view of the
+    [B, nms_topN_post + 1, 14] gather block, see select_block)."""
     return select_post(*detect_device(net, im, conf), conf)

@@ -41,6 +41,8 @@ class RPN(nn.Module):
         self.feat_size = rpn_util.calc_output_size(np.array(conf.crop_size), self.feat_stride)
         self.rois = rpn_util.locate_anchors(conf.anchors, self.feat_size, conf.feat_stride, convert_tensor=True)
         self.rois = self.rois.float().to(self.device)
+        from .detect import check_conf
+        check_conf(conf)
         if not (conf.center_align and conf.shape_align and self.attention == "ANAB"):
             raise NotImplementedError("this build implements the anab_fullalign configuration "
                                       "(center_align, shape_align, attention='ANAB')")

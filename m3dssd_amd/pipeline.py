@@ -13,7 +13,7 @@ drains the last one.  Results are identical to ``lib.rpn_util.detect_batch`` (te
 """
 import torch
 
-from .host.detect import detect_from_outputs, select_post
+from .host.detect import detect_from_outputs, select_block
 
 
 class PipelinedDetector:
@@ -36,7 +36,7 @@ class PipelinedDetector:
 
     def _detect(self):
         prob, b2, b3 = self._outs
-        return select_post(*detect_from_outputs(self.eng, self.plan, prob, b2, b3, self._rois, self.conf), self.conf)
+        return select_block(*detect_from_outputs(self.eng, self.plan, prob, b2, b3, self._rois, self.conf), self.conf)
 
     def _forward(self, start, end):
         self.plan.named["input_ptr"][0] = self.input.data_ptr()
@@ -53,30 +53,33 @@ class PipelinedDetector:
             with torch.cuda.graph(self.graph, stream=cap):
                 side.wait_stream(cap)                    # fork
                 with torch.cuda.stream(side):
-                    self._dets, self._counts = self._detect()       # batch k-1
+                    self._block, self._counts = self._detect()      # batch k-1
                 self._forward(0, self.n_fwd)             # batch k, everything but the bundling
                 cap.wait_stream(side)                    # join: outputs may now be overwritten
                 self._forward(self.n_fwd, None)
             # tail graph for flush(): detect only
             self.tail = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.tail, stream=cap):
-                self._tdets, self._tcounts = self._detect()
+                self._tblock, self._tcounts = self._detect()
         torch.cuda.current_stream(self.dev).wait_stream(cap)
 
-    def step(self, x=None):
+    def step(self, x=None, as_block=False):
         """Submit batch k (copied into ``self.input`` unless x is None = already written there); returns
-        (dets, counts) of batch k-1, or None for the first call.  Returned tensors are overwritten by the next step."""
+        (dets, counts) of batch k-1, or None for the first call.  Returned tensors are overwritten by the next step.
+        as_block: return the [B, nms_topN_post + 1, 14] gather block (m3dssd_amd.dist.gather_block) instead of dets."""
         if x is not None:
             self.input.copy_(x)
         had = self._pending
         self.graph.replay()
         self._pending = True
-        return (self._dets, self._counts) if had else None
+        if not had:
+            return None
+        return (self._block if as_block else self._block[:, :-1], self._counts)
 
-    def flush(self):
+    def flush(self, as_block=False):
         """Detections of the last submitted batch."""
         if not self._pending:
             return None
         self.tail.replay()
         self._pending = False
-        return self._tdets, self._tcounts
+        return (self._tblock if as_block else self._tblock[:, :-1], self._tcounts)

@@ -1,6 +1,9 @@
 """TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's post-NMS 3-D refinement and KITTI result formatting
-(SURVEY section 8f row 2).  float64 throughout (the reference mixes numpy scalars and Python floats; rows enter as float32
-and are promoted here once).
+(SURVEY section 8f row 2).  The reference mixes np.float32 scalars (`box = aboxes[i]`) and Python floats; its environment pins
+numpy==1.18.1 (requirements.txt:50, value-based promotion), under which np.float32 * np.float32 (x3d*z3d, y3d*z3d, the box
+width / height, x + w - 1 inside test_projection) ROUNDS TO FLOAT32 while np.float32 + Python float is float64.  That is what
+is restated here with explicit np.float32 arithmetic, so the result does not depend on the numpy installed (numpy >= 2 would
+also round the angle sums to float32, which the reference's authors never ran).
 
     lib/util.py:516-535          convertAlpha2Rot / convertRot2Alpha
     lib/rpn_util.py:921-970      project_3d
@@ -48,9 +51,16 @@ def project_3d(p2, x3d, y3d, z3d, w3d, h3d, l3d, ry3d):
 
 def test_projection(p2, p2_inv, box_2d, cx, cy, z, w3d, h3d, l3d, rot_y):
     """-> (ol, verts, invalid)."""
-    x, y = box_2d[0], box_2d[1]
-    x2, y2 = x + box_2d[2] - 1, y + box_2d[3] - 1
-    c3 = np.asarray(p2_inv, dtype=np.float64).dot(np.array([cx * z, cy * z, z, 1], dtype=np.float64))
+    f32 = np.float32
+    bx, by, bw, bh = (f32(v) for v in box_2d)                  # float32 array in the reference (np.array of np.float32 scalars)
+    x, y = float(bx), float(by)
+    x2, y2 = float(f32(f32(bx + bw) - f32(1))), float(f32(f32(by + bh) - f32(1)))      # np.float32 + np.float32 - 1
+    if isinstance(z, np.float32):                              # cx, cy, z still the row's np.float32 scalars: float32 products
+        v0, v1 = float(f32(f32(cx) * z)), float(f32(f32(cy) * z))
+    else:                                                      # a stepped depth (np.float32 -+ Python float) is float64
+        v0, v1 = float(cx) * float(z), float(cy) * float(z)
+    c3 = np.asarray(p2_inv, dtype=np.float64).dot(np.array([v0, v1, float(z), 1], dtype=np.float64))
+    w3d, h3d, l3d, rot_y = float(w3d), float(h3d), float(l3d), float(rot_y)
     verts, corners = project_3d(p2, c3[0], c3[1], c3[2], w3d, h3d, l3d, rot_y)
     invalid = bool(np.any(corners[2, :] <= 0))
     xn, yn, x2n, y2n = verts[:, 0].min(), verts[:, 1].min(), verts[:, 0].max(), verts[:, 1].max()
@@ -67,14 +77,14 @@ def hill_climb(p2, p2_inv, box_2d, x2d, y2d, z2d, w3d, h3d, l3d, ry3d, step_z_in
         return z2d, ry3d, verts_best
     while step_z > z_lim or step_r > r_lim:
         if step_z > z_lim:
-            ol_neg, v_neg, inv_neg = test_projection(p2, p2_inv, box_2d, x2d, y2d, z2d - step_z, w3d, h3d, l3d, ry3d)
-            ol_pos, v_pos, inv_pos = test_projection(p2, p2_inv, box_2d, x2d, y2d, z2d + step_z, w3d, h3d, l3d, ry3d)
+            ol_neg, v_neg, inv_neg = test_projection(p2, p2_inv, box_2d, x2d, y2d, float(z2d) - step_z, w3d, h3d, l3d, ry3d)
+            ol_pos, v_pos, inv_pos = test_projection(p2, p2_inv, box_2d, x2d, y2d, float(z2d) + step_z, w3d, h3d, l3d, ry3d)
             if ((ol_pos - ol_best) <= min_ol_dif) and ((ol_neg - ol_best) <= min_ol_dif):
                 step_z = step_z * 0.5
             elif (ol_pos - ol_best) > min_ol_dif and ol_pos > ol_neg and not inv_pos:
-                z2d, ol_best, verts_best = z2d + step_z, ol_pos, v_pos
+                z2d, ol_best, verts_best = float(z2d) + step_z, ol_pos, v_pos
             elif (ol_neg - ol_best) > min_ol_dif and not inv_neg:
-                z2d, ol_best, verts_best = z2d - step_z, ol_neg, v_neg
+                z2d, ol_best, verts_best = float(z2d) - step_z, ol_neg, v_neg
             else:
                 step_z = step_z * 0.5
         if step_r > r_lim:
@@ -94,18 +104,28 @@ def hill_climb(p2, p2_inv, box_2d, x2d, y2d, z2d, w3d, h3d, l3d, ry3d, step_z_in
 def refine_row(row, p2, p2_inv, hill_climbing=True):
     """One aboxes row [x1, y1, x2, y2, score, cls, x3d, y3d, z3d, w3d, h3d, l3d, alpha, anchor] (rpn_util.py:1550) ->
     [alpha, x1, y1, x2, y2, h3d, w3d, l3d, x3d, y3d, z3d, ry3d, score] as written to the KITTI file (rpn_util.py:1813-1849)."""
-    b = [float(v) for v in row]
+    f32 = np.float32
+    b = [f32(v) for v in row]                                      # np.float32 scalars, as `box = aboxes[boxind, :]` yields
     x1, y1, x2, y2, score = b[0], b[1], b[2], b[3], b[4]
-    x3d, y3d, z3d, w3d, h3d, l3d, ry3d = b[6], b[7], b[8], b[9], b[10], b[11], b[12]
+    x3d, y3d, z3d, w3d, h3d, l3d = b[6], b[7], b[8], b[9], b[10], b[11]
     p2_inv = np.asarray(p2_inv, dtype=np.float64)
-    c3 = p2_inv.dot(np.array([x3d * z3d, y3d * z3d, 1 * z3d, 1], dtype=np.float64))
-    ry3d = convert_alpha2rot(ry3d, c3[2], c3[0])
+
+    def back_project(z):
+        if isinstance(z, np.float32):                              # np.float32 * np.float32 -> float32, then widened
+            v0, v1 = float(f32(x3d * z)), float(f32(y3d * z))
+        else:
+            v0, v1 = float(x3d) * float(z), float(y3d) * float(z)
+        return p2_inv.dot(np.array([v0, v1, float(z), 1], dtype=np.float64))
+
+    c3 = back_project(z3d)
+    ry3d = convert_alpha2rot(float(b[12]), c3[2], c3[0])           # np.float32 + Python float -> float64 (numpy 1.18)
     if hill_climbing:
-        z3d, ry3d, _ = hill_climb(p2, p2_inv, np.array([x1, y1, x2 - x1 + 1, y2 - y1 + 1]), x3d, y3d, z3d, w3d, h3d, l3d, ry3d,
-                                  step_r_init=0.3 * math.pi, r_lim=0.01)
-    c3 = p2_inv.dot(np.array([x3d * z3d, y3d * z3d, 1 * z3d, 1], dtype=np.float64))
+        box_2d = np.array([x1, y1, f32(f32(x2 - x1) + f32(1)), f32(f32(y2 - y1) + f32(1))], dtype=np.float32)
+        z3d, ry3d, _ = hill_climb(p2, p2_inv, box_2d, x3d, y3d, z3d, w3d, h3d, l3d, ry3d, step_r_init=0.3 * math.pi, r_lim=0.01)
+    c3 = back_project(z3d)
     alpha = convert_rot2alpha(ry3d, c3[2], c3[0])
-    return [alpha, x1, y1, x2, y2, h3d, w3d, l3d, c3[0], c3[1] + h3d / 2, c3[2], ry3d, score]
+    return [alpha, float(x1), float(y1), float(x2), float(y2), float(h3d), float(w3d), float(l3d), c3[0],
+            c3[1] + float(h3d) / 2, c3[2], ry3d, float(score)]
 
 
 def kitti_text(aboxes, p2, lbls, nms_topn_post=40, score_thresh=0.75, hill_climbing=True):

@@ -37,7 +37,7 @@ def _relerr(a, b):
 def test_library_loads_and_reports_errors():
     from m3dssd_amd import _hip
     L = _hip.lib()
-    assert L.m3d_abi_version() == 1
+    assert L.m3d_abi_version() == 2
     d = _hip.ConvDesc()
     assert L.m3d_conv2d_forward(d, None) != 0          # null pointers -> M3D_E_ARG, no crash
     assert b"null" in L.m3d_last_error()
@@ -369,6 +369,28 @@ def _check_decisions(taps_free, ind, prob_sel):
     return int(diff.sum()), int(flip.sum())
 
 
+def _clean_rows(taps_free, ind, prob_sel, A, radius=4):
+    """Row mask [B, A*fh*fw]: rows whose pixel lies at least `radius` pixels away from every pixel where the engine and the
+    free-running oracle took a different discrete decision (top-1 anchor / hard mask at an exact near-tie).  A differing
+    decision changes that pixel's alignment offsets; center_align then resamples the aligned map around each pixel, so the
+    neighbourhood is excluded too.  (z3d also passes through ANAB's global pooling: bounded separately by the callers.)"""
+    fg = taps_free["fg_prob"]
+    o_mask, o_ind = fg.max(dim=1, keepdim=True)
+    bad = ((o_ind != ind) | ((o_mask > 0.5) != (prob_sel > 0.5))).float()
+    if bad.any():
+        bad = F.max_pool2d(bad, 2 * radius + 1, stride=1, padding=radius)
+    ok = (bad == 0).view(bad.shape[0], 1, -1).expand(-1, A, -1).reshape(bad.shape[0], -1)
+    return ok
+
+
+def _parity_log(name, payload):
+    import json
+    d = os.path.join(os.path.dirname(GOLDEN.rstrip("/")), "..", "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "parity_r02.jsonl"), "a") as f:
+            f.write(json.dumps({"test": name, **payload}) + "\n")
+
+
 @pytest.mark.parametrize("crop,B,pad", [((128, 320), 2, False), ((384, 1280), 1, True)])
 def test_forward_matches_oracle(crop, B, pad):
     net, plan, out, free, inj, taps_free, taps_inj, ind, prob_sel = _run_both(crop, B, pad)
@@ -396,8 +418,21 @@ def test_forward_matches_oracle(crop, B, pad):
     assert (b2 - o_b2).abs().max().item() < 1e-3
     assert (b3 - o_b3).abs().max().item() < 1e-3               # BASELINE.json: 3D box params within 1e-3 abs
     assert torch.equal(rois, o_rois) and torch.equal(fs, o_fs)
-    if n_idx == 0 and n_flip == 0:                              # no legit flips: free-running oracle must agree too
-        assert (b3 - free[3]).abs().max().item() < 1e-3
+    # free-running oracle (its own decisions): every row away from a differing decision must agree too -- unconditional;
+    # the z3d column sits behind ANAB's global pooling, so a differing pixel can move it everywhere, slightly
+    assert n_idx + n_flip <= 8, (n_idx, n_flip)
+    ok = _clean_rows(taps_free, ind, prob_sel, b3.shape[1] // (ind.shape[2] * ind.shape[3]))
+    assert ok.float().mean().item() > 0.9
+    e_free = (b3 - free[3]).abs()
+    cols = [0, 1, 3, 4, 5, 6]
+    e_clean = e_free[:, :, cols][ok].max().item()
+    e_z = e_free[:, :, 2][ok].max().item()
+    feats_gl_err = _relerr(plan.named["feats_gl"].torch_nchw().cpu(), taps_inj["feats_gl"])
+    _parity_log("forward_matches_oracle", dict(crop=list(crop), B=B, n_idx=n_idx, n_flip=n_flip, clean_frac=ok.float().mean().item(),
+                                               bbox3d_free_clean=e_clean, z3d_free_clean=e_z,
+                                               bbox3d_inj=(b3 - o_b3).abs().max().item(), feats_gl_rel=feats_gl_err))
+    assert e_clean < 1e-3
+    assert e_z < (1e-3 if n_idx + n_flip == 0 else 5e-3)
 
 
 def test_forward_matches_reference_golden_samples():
@@ -409,9 +444,18 @@ def test_forward_matches_reference_golden_samples():
     assert cls.shape == (1, 276480, 4)
     assert np.abs(cls[:, ::st].numpy() - g["cls"]).max() < 1e-3
     n_idx, n_flip = _check_decisions(taps_free, ind, prob_sel)
-    if n_idx == 0 and n_flip == 0:
-        assert np.abs(out[3].cpu()[:, ::st].numpy() - g["bbox_3d"]).max() < 1e-3
-        assert np.abs(out[1].cpu()[:, ::st].numpy() - g["prob"]).max() < 1e-4
+    # unconditional: the sampled rows away from any differing discrete decision must match the REFERENCE's own numbers
+    # (prob is upstream of the decisions: every sampled row); the counts are bounded and logged
+    assert n_idx + n_flip <= 8, (n_idx, n_flip)
+    ok = _clean_rows(taps_free, ind, prob_sel, 36)[:, ::st].numpy()
+    assert ok.mean() > 0.9
+    e3 = np.abs(out[3].cpu()[:, ::st].numpy() - g["bbox_3d"])
+    e2 = np.abs(out[2].cpu()[:, ::st].numpy() - g["bbox_2d"])
+    _parity_log("forward_matches_reference_golden", dict(n_idx=n_idx, n_flip=n_flip, rows=int(ok.sum()), rows_total=int(ok.size),
+                                                         bbox3d=float(e3[ok].max()), bbox2d=float(e2[ok].max())))
+    assert np.abs(out[1].cpu()[:, ::st].numpy() - g["prob"]).max() < 1e-4
+    assert e3[:, :, [0, 1, 3, 4, 5, 6]][ok].max() < 1e-3 and e2[ok].max() < 1e-3
+    assert e3[:, :, 2][ok].max() < (1e-3 if n_idx + n_flip == 0 else 5e-3)
 
 
 def test_batch_invariance_and_determinism():
@@ -453,12 +497,13 @@ def test_detect_matches_oracle_given_same_network_outputs():
     ref, keep, top = odet.detect_image(prob[0], b2[0], b3[0], rois, conf)
     assert ab.shape == ref.shape
     assert np.array_equal(ab[:, 13], ref[:, 13]) and np.array_equal(ab[:, 5], ref[:, 5])
-    assert np.abs(ab - ref).max() < 1e-3 * max(1.0, np.abs(ref).max())
+    # pure fp32 decode arithmetic on IDENTICAL network outputs: per column, to fp32 roundoff (expf differs by an ulp or two)
+    assert (np.abs(ab - ref) <= 1e-4 * (1.0 + np.abs(ref))).all(), np.abs((ab - ref) / (1.0 + np.abs(ref))).max(0)
     dets, counts = detect_batch(net, x.to(dev), conf)
     assert dets.shape == (B, conf.nms_topN_post, 14) and counts.shape == (B,)
     k = int(counts[0])
     assert k == min(len(ref), conf.nms_topN_post)
-    assert np.abs(dets[0, :k].cpu().numpy() - ref[:k]).max() < 1e-3 * max(1.0, np.abs(ref).max())
+    assert (np.abs(dets[0, :k].cpu().numpy() - ref[:k]) <= 1e-4 * (1.0 + np.abs(ref[:k]))).all()
     assert dets[0, k:].abs().max().item() == 0 if k < conf.nms_topN_post else True
 
 
@@ -870,7 +915,8 @@ def test_config4_shard_size_batch32_properties():
     for name, u, s_, tol in zip(("cls", "prob", "bbox_2d", "bbox_3d"), a, one, (1e-3, 1e-4, 1e-3, 1e-3)):
         assert (u[17:18] - s_).abs().max().item() < tol, name
     assert torch.equal(counts, torch.cat([c0, c1]))
-    assert (dets - torch.cat([d0, d1])).abs().max().item() < 1e-2      # decoded pixels / metres of the same kept anchors
+    dref = torch.cat([d0, d1])                                         # decoded pixels / metres of the same kept anchors:
+    assert ((dets - dref).abs() <= 2e-4 * (1.0 + dref.abs())).all()    # the batch-32 and batch-16 plans run the same kernels
     assert torch.equal(dets[:, :, 13], torch.cat([d0, d1])[:, :, 13])  # identical anchor ids row by row
 
 

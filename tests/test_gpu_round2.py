@@ -1,0 +1,424 @@
+"""GPU parity tests added in round 2 (all through the C ABI of libm3dssd_hip.so):
+
+  * the device top-N-pre select + decode (m3d_topk_decode) and post-NMS selection (m3d_select_post) against the
+    reference's semantics (lib/rpn_util.py:1510-1555) restated with a stable sort, including heavy score ties;
+  * the benched configuration itself -- bs=8, 1280x384, wave-granular kernel plan -- against the CPU oracle directly;
+  * decode -> top-k -> NMS at full size against the reference golden (tests/golden/detect_384x1280.npz);
+  * independent pins of the DCNv2 inner op: numpy float64-accumulating twin at stride 2 / dilation 2 / pad 0 / 1x1;
+  * the module on a device that is not the current one; the N > 1 path with 2 ranks on the leased GPU.
+"""
+import ctypes
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from m3dssd_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _log(name, payload):
+    """Measured margins of the parity tests, merged back from the GPU box (gpurun_out/parity_r02.jsonl)."""
+    d = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "parity_r02.jsonl"), "a") as f:
+            f.write(json.dumps({"test": name, **payload}) + "\n")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ------------------------------------------------------------------------------------ top-k select + decode
+def _topk_inputs(R, A, seed, scores):
+    g = torch.Generator().manual_seed(seed)
+    prob = torch.rand(1, R, 4, generator=g) * 0.2
+    prob[0, :, 1] = scores                     # class 1 carries the row score; the others stay below it
+    prob[0, :, 2:] = prob[0, :, 2:] * 0.0 + (scores[:, None] * 0.5)
+    b2 = torch.randn(1, R, 4, generator=g) * 0.3
+    b3 = torch.randn(1, R, 7, generator=g) * 0.3
+    x1 = torch.rand(R, generator=g) * 1000
+    y1 = torch.rand(R, generator=g) * 300
+    rois = torch.stack([x1, y1, x1 + 20 + torch.rand(R, generator=g) * 80, y1 + 20 + torch.rand(R, generator=g) * 60,
+                        torch.randint(0, A, (R,), generator=g).float()], 1)
+    anchors = torch.rand(A, 9, generator=g) * 10 + 1
+    means, stds = torch.randn(11, generator=g) * 0.1, torch.rand(11, generator=g) + 0.5
+    return prob, b2, b3, rois, anchors, means, stds
+
+
+def _sortable_bits(score):
+    u = score.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    bits = torch.where(u >= 0x80000000, (~u) & 0xFFFFFFFF, u | 0x80000000)
+    return bits
+
+
+TOPK_CASES = [
+    ("random", 276480, 3000), ("ragged_R", 10007, 3000), ("k_equals_R", 1500, 1500), ("k1", 4097, 1), ("k_max", 50000, 4096),
+    ("all_equal", 20000, 3000), ("16_levels", 276480, 3000), ("ties_at_cut", 30000, 3000), ("negative_and_zero", 9000, 2000),
+]
+
+
+@pytest.mark.parametrize("name,R,k", TOPK_CASES)
+def test_topk_decode_matches_stable_sort(name, R, k):
+    """rows = the first k of `descending score, ascending row among equals` (oracle/nms.py:order_desc_stable, the total order
+    the reference's unstable argsort()[::-1] is one instance of); aboxes = m3d_decode_rows of those rows, bit for bit."""
+    from m3dssd_amd import _hip
+    from oracle import nms as onms
+    L = _hip.lib()
+    dev = _dev()
+    g = torch.Generator().manual_seed(len(name) * 1000 + R)
+    if name == "all_equal":
+        scores = torch.full((R,), 0.731)
+    elif name == "16_levels":
+        scores = torch.randint(0, 16, (R,), generator=g).float() / 16.0
+    elif name == "ties_at_cut":
+        scores = torch.rand(R, generator=g)
+        scores[torch.randperm(R, generator=g)[:8000]] = 0.95       # the cut at k = 3000 falls inside a block of equal scores
+    elif name == "negative_and_zero":
+        scores = torch.randn(R, generator=g)
+        scores[::7] = 0.0
+        scores[3::11] = -0.0
+    else:
+        scores = torch.rand(R, generator=g) ** 6                   # most rows near 0 like real fg probabilities
+    A = 36
+    prob, b2, b3, rois, anchors, means, stds = _topk_inputs(R, A, R + k, scores)
+    bits32 = _sortable_bits(scores)
+    bits_dev = torch.from_numpy(bits32.numpy().astype(np.uint32).view(np.int32)).to(dev)
+    d = [t.to(dev).contiguous() for t in (prob, b2, b3, rois, anchors, means, stds)]
+    ab = torch.empty(1, k, 14, device=dev)
+    rows = torch.empty(1, k, device=dev, dtype=torch.int32)
+    nb = L.m3d_topk_decode_workspace_bytes(1, R)
+    ws = torch.empty(nb, device=dev, dtype=torch.uint8)
+    _hip.check(L.m3d_topk_decode(bits_dev.data_ptr(), *[t.data_ptr() for t in d], ab.data_ptr(), rows.data_ptr(),
+                                 ws.data_ptr(), nb, 1, R, k, _stream()))
+    torch.cuda.synchronize()
+    # -0.0 sorts below +0.0 in the bit order; the stable-sort reference uses the same monotone key
+    key = bits32.numpy().astype(np.int64)
+    order = np.lexsort((np.arange(R), -key))[:k]
+    assert np.array_equal(rows[0].cpu().numpy().astype(np.int64), order), name
+    if name not in ("negative_and_zero",):
+        assert np.array_equal(order, onms.order_desc_stable(scores.numpy())[:k])
+    ref = torch.empty(1, k, 14, device=dev)
+    rows64 = torch.from_numpy(order[None].astype(np.int64)).to(dev)
+    _hip.check(L.m3d_decode_rows(rows64.data_ptr(), *[t.data_ptr() for t in d], ref.data_ptr(), 1, R, k, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(ab, ref)
+    # second run: bit-identical (integer atomics only)
+    ab2 = torch.empty_like(ab)
+    _hip.check(L.m3d_topk_decode(bits_dev.data_ptr(), *[t.data_ptr() for t in d], ab2.data_ptr(), None,
+                                 ws.data_ptr(), nb, 1, R, k, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(ab, ab2)
+
+
+def test_topk_decode_batched_and_argument_checks():
+    from m3dssd_amd import _hip
+    L = _hip.lib()
+    dev = _dev()
+    R, k, B = 5000, 700, 3
+    g = torch.Generator().manual_seed(5)
+    scores = torch.rand(B, R, generator=g)
+    bits = torch.from_numpy(_sortable_bits(scores).numpy().astype(np.uint32).view(np.int32)).to(dev)
+    prob = torch.zeros(B, R, 4)
+    prob[:, :, 1] = scores
+    b2, b3 = torch.randn(B, R, 4, generator=g), torch.randn(B, R, 7, generator=g)
+    _, _, _, rois, anchors, means, stds = _topk_inputs(R, 36, 1, scores[0])
+    d = [t.to(dev).contiguous() for t in (prob, b2, b3, rois, anchors, means, stds)]
+    ab = torch.empty(B, k, 14, device=dev)
+    rows = torch.empty(B, k, device=dev, dtype=torch.int32)
+    nb = L.m3d_topk_decode_workspace_bytes(B, R)
+    ws = torch.empty(nb, device=dev, dtype=torch.uint8)
+    _hip.check(L.m3d_topk_decode(bits.data_ptr(), *[t.data_ptr() for t in d], ab.data_ptr(), rows.data_ptr(), ws.data_ptr(),
+                                 nb, B, R, k, _stream()))
+    torch.cuda.synchronize()
+    for b in range(B):
+        order = np.lexsort((np.arange(R), -scores[b].numpy().astype(np.float64)))[:k]
+        assert np.array_equal(rows[b].cpu().numpy(), order)
+        assert torch.equal(ab[b, :, 4].cpu(), scores[b][order])
+    args = [bits.data_ptr(), *[t.data_ptr() for t in d], ab.data_ptr(), None, ws.data_ptr()]
+    assert L.m3d_topk_decode(*args, nb, B, R, 4097, _stream()) == -1          # k > 4096
+    assert L.m3d_topk_decode(*args, nb, B, R, R + 1, _stream()) == -1         # k > R  (R = 5000 > 4096 anyway)
+    assert L.m3d_topk_decode(*args, nb - 8, B, R, k, _stream()) == -3         # workspace too small
+    assert b"workspace" in L.m3d_last_error()
+
+
+def test_select_post_blocks():
+    from m3dssd_amd import _hip
+    L = _hip.lib()
+    dev = _dev()
+    B, n, post = 4, 300, 40
+    g = torch.Generator().manual_seed(9)
+    ab = torch.randn(B, n, 14, generator=g)
+    num = torch.tensor([0, 7, 40, 123], dtype=torch.int32)
+    keep = torch.stack([torch.randperm(n, generator=g).sort()[0] for _ in range(B)]).to(torch.int32)
+    block = torch.full((B, post + 1, 14), float("nan"), device=dev)
+    counts = torch.empty(B, dtype=torch.int32, device=dev)
+    _hip.check(L.m3d_select_post(ab.to(dev).data_ptr(), keep.to(dev).data_ptr(), num.to(dev).data_ptr(), B, n, post,
+                                 block.data_ptr(), counts.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    block = block.cpu()
+    assert counts.cpu().tolist() == [0, 7, 40, 40]
+    for b in range(B):
+        c = min(int(num[b]), post)
+        assert torch.equal(block[b, :c], ab[b][keep[b, :c].long()])
+        assert block[b, c:post].abs().max().item() == 0 if c < post else True
+        assert block[b, post, 0].item() == c and block[b, post, 1:].abs().max().item() == 0
+
+
+def test_conf_limits_are_checked_at_build_time():
+    from model.M3d_inference_align import build
+    conf = synth.synth_conf((128, 320), 0, batch_size=1, device="cuda:0")
+    conf.nms_topN_pre = 5000
+    with pytest.raises(ValueError, match="nms_topN_pre"):
+        build(conf, "test")
+
+
+# ------------------------------------------------------------------------------------ the benched configuration vs the oracle
+def test_bench_config_batch8_wave_plan_matches_oracle_directly():
+    """BASELINE.json configs[1] as benched: bs = 8, 1280x384 -> the plan with the wave-granular kernels (Winograd wave, conv /
+    deformable wave, batched heads) against the CPU oracle on the same 8 frames (no HIP-vs-HIP hop): cls upstream of the
+    decisions, everything downstream with the engine's decisions injected; 3-D box parameters within 1e-3 abs."""
+    from model.M3d_inference_align import build
+    from oracle import model_cpu
+    dev = _dev()
+    B, crop = 8, (384, 1280)
+    conf = synth.synth_conf(crop, 0, batch_size=B, device="cuda:0")
+    sd = synth.synth_state_dict(0)
+    x = synth.synth_frames(B, crop, 1234)
+    x[4:, :, :, (2 * crop[1]) // 3:] = 0.0                      # half of the frames with the test-time zero border
+    net = build(conf, "test")
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev)
+    with torch.no_grad():
+        cls, prob, b2, b3 = (t.cpu() for t in net(x.to(dev))[:4])
+    plan = net.engine().plan_for(B, *crop)
+    kinds = {op[1] for op in plan.ops}
+    assert "wino_wave<32,32>" in kinds and any(k.startswith("conv_wave<deform") for k in kinds), kinds
+    fh, fw = crop[0] // 8, crop[1] // 8
+    ind = plan.named["sel_idx"].view(B, 1, fh, fw).long().cpu()
+    prob_sel = plan.named["sel_prob"].view(B, 1, fh, fw).cpu()
+    cconf = synth.synth_conf(crop, 0, batch_size=B, device="cpu")
+    taps = {}
+    with torch.no_grad():
+        free = model_cpu.rpn_forward(sd, cconf, x, taps)
+        inj = model_cpu.rpn_forward(sd, cconf, x, inject={"sel": {"ind": ind, "hard": (prob_sel > 0.5).float()}})
+    e_cls = (cls - free[0]).abs().max().item() / (1.0 + free[0].abs().max().item())
+    fg = taps["fg_prob"]
+    o_mask, o_ind = fg.max(dim=1, keepdim=True)
+    diff, flip = (o_ind != ind), ((o_mask > 0.5) != (prob_sel > 0.5))
+    if diff.any():
+        assert ((o_mask - torch.gather(fg, 1, ind))[diff].abs() < 1e-4).all()
+    if flip.any():
+        assert ((o_mask - 0.5)[flip].abs() < 1e-4).all()
+    e_prob = (prob - inj[1]).abs().max().item()
+    e_b2 = (b2 - inj[2]).abs().max().item()
+    e_b3 = (b3 - inj[3]).abs().max().item()
+    _log("bench_config_batch8", dict(cls_rel=e_cls, prob=e_prob, bbox_2d=e_b2, bbox_3d=e_b3, n_idx=int(diff.sum()),
+                                     n_flip=int(flip.sum()), pixels=int(diff.numel())))
+    assert e_cls < 1e-3 and e_prob < 1e-4 and e_b2 < 1e-3
+    assert e_b3 < 1e-3                                           # BASELINE.json: 3-D box params within 1e-3 abs (fp32)
+    assert int(diff.sum()) + int(flip.sum()) <= 16               # near-ties only, and only a handful of them
+
+
+def test_detect_full_size_matches_reference_golden():
+    """decode -> top-3000 -> NMS on the HIP path at 1280x384 against the rows the REFERENCE's im_detect_3d produced
+    (tests/golden/detect_384x1280.npz, tools/gen_golden.py): kept anchors / classes identical, every column within
+    2e-3 * (1 + |ref|) (the network outputs feeding the decode carry the forward's own fp32 roundoff)."""
+    from lib.rpn_util import im_detect_3d
+    from model.M3d_inference_align import build
+    dev = _dev()
+    crop = (384, 1280)
+    conf = synth.synth_conf(crop, 0, batch_size=1, device="cuda:0")
+    net = build(conf, "test")
+    net.load_state_dict(synth.synth_state_dict(0))
+    net = net.to(dev)
+    x = synth.synth_frames(1, crop, 1234, pad_right_third=True)
+    ab = im_detect_3d(x[0], net, conf)
+    ref = np.load(os.path.join(GOLDEN, "detect_384x1280.npz"))["aboxes"]
+    assert ab.shape == ref.shape
+    assert np.array_equal(ab[:, 13], ref[:, 13]) and np.array_equal(ab[:, 5], ref[:, 5])
+    err = np.abs(ab - ref) / (1.0 + np.abs(ref))
+    _log("detect_full_size_golden", dict(max_rel=float(err.max()), per_col=[float(v) for v in err.max(0)]))
+    assert err.max() < 2e-3
+
+
+# ------------------------------------------------------------------------------------ DCNv2: independent pins
+@pytest.mark.parametrize("case", [
+    # n, c, h, w, co, k, stride, pad, dil
+    (1, 8, 9, 11, 6, 3, 2, 1, 1), (2, 4, 10, 9, 5, 3, 1, 2, 2), (1, 12, 7, 8, 4, 3, 1, 0, 1), (2, 16, 6, 7, 8, 1, 1, 0, 1),
+    (1, 5, 11, 13, 3, 3, 2, 0, 1), (1, 6, 12, 10, 7, 3, 2, 2, 2), (1, 3, 5, 5, 2, 1, 2, 0, 1),
+])
+def test_dcn_matches_numpy_float64_twin(case):
+    """The HIP op against oracle.dcn.dcn_v2_forward_numpy -- per-output-pixel loops written from
+    dcn_v2_im2col_cuda.cu:18-47,129-178 independently of the C restatement, float64 accumulation -- on the geometries the
+    C-oracle tests do not reach (stride 2, dilation 2, pad 0, 1x1, odd sizes), offsets up to +-3 px and exact -1 gates."""
+    from m3dssd_amd.host import ops
+    from oracle import dcn as odcn
+    dev = _dev()
+    n, c, h, w, co, k, stride, pad, dil = case
+    g = torch.Generator().manual_seed(sum(case) * 7 + 1)
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(co, c, k, k, generator=g) / (c * k * k) ** 0.5
+    b = torch.randn(co, generator=g)
+    ho, wo = odcn.out_size(h, w, k, k, stride, pad, dil)
+    off = torch.randn(n, 2 * k * k, ho, wo, generator=g) * 3.0
+    off[0, 0, 0, 0] = -1.0 + pad                                   # tap 0 of pixel (0, 0): h_im exactly -1 (strict gate)
+    off[0, 1, 0, 0] = float(w) + pad                               # w_im exactly W for the same tap: outside
+    m = torch.rand(n, k * k, ho, wo, generator=g)
+    ref = torch.from_numpy(odcn.dcn_v2_forward_numpy(x.numpy(), off.numpy(), m.numpy(), wt.numpy(), b.numpy(), stride, pad, dil))
+    got = ops.dcn_v2_forward(x.to(dev), off.to(dev), m.to(dev), wt.to(dev), b.to(dev), stride, pad, dil, 1).cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < 2e-5 * (1.0 + ref.abs().max().item())
+    # and the C restatement agrees with the numpy twin on the same geometry (the oracle's two forms pin each other)
+    c_ref = odcn.dcn_v2_forward(x, off, m, wt, b, stride, pad, dil, 1)
+    assert (c_ref - ref).abs().max().item() < 2e-5 * (1.0 + ref.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------ device handling
+def test_module_on_a_device_that_is_not_current():
+    """Engine launches go to the stream of the ENGINE's device whatever the caller's current device is (a second device
+    when the box has one; with one device the same path runs under an explicit non-default current stream)."""
+    from lib.rpn_util import detect_batch
+    from model.M3d_inference_align import build
+    n_dev = torch.cuda.device_count()
+    tgt = torch.device("cuda", n_dev - 1)
+    conf = synth.synth_conf((128, 320), 0, batch_size=2, device=str(tgt))
+    net = build(conf, "test")
+    net.load_state_dict(synth.synth_state_dict(0))
+    net = net.to(tgt)
+    x = synth.synth_frames(2, (128, 320), 5).to(tgt)
+    with torch.cuda.device(tgt):
+        ref = [t.clone() for t in net(x)[:4]]
+        rd, rc = (t.clone() for t in detect_batch(net, x, conf))
+    torch.cuda.synchronize(tgt)
+    side = torch.cuda.Stream(tgt)
+    with torch.cuda.device(0), torch.cuda.stream(side):
+        got = [t.clone() for t in net(x)[:4]]
+        gd, gc = (t.clone() for t in detect_batch(net, x, conf))
+    side.synchronize()
+    for u, v in zip(ref, got):
+        assert torch.equal(u, v)
+    assert torch.equal(rd, gd) and torch.equal(rc, gc)
+    with pytest.raises(RuntimeError):
+        net.engine().forward(x.cpu().to("cuda:0") if n_dev > 1 else x[:, :, :100])   # wrong device / bad size
+
+
+# ------------------------------------------------------------------------------------ N > 1 on the leased GPU
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+_RANK_SCRIPT = r"""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, %(root)r)
+from m3dssd_amd import dist as mdist, synth
+from m3dssd_amd.host.detect import detect_device, select_block
+from model.M3d_inference_align import build
+rank, world, local = mdist.init_from_env(backend=%(backend)r)
+local = local %% torch.cuda.device_count()
+torch.cuda.set_device(local)
+dev = torch.device("cuda", local)
+B = 4
+conf = synth.synth_conf((128, 320), 0, batch_size=B // world, device=str(dev))
+net = build(conf, "test")
+net.load_state_dict(synth.synth_state_dict(0))
+net = net.to(dev)
+x = synth.synth_frames(B, (128, 320), 31)
+mine = mdist.shard_batch(x, rank, world).to(dev)
+block, counts = select_block(*detect_device(net, mine, conf), conf)
+dets, cnt = mdist.gather_block(block)
+torch.cuda.synchronize()
+np.savez(os.path.join(%(out)r, "rank%%d.npz" %% rank), dets=dets.cpu().numpy(), counts=cnt.cpu().numpy())
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()
+"""
+
+
+def _run_ranks(tmp_path, backend, world=2):
+    import signal
+    import subprocess
+    import sys
+    import types
+    script = tmp_path / ("rank_%s.py" % backend)
+    script.write_text(_RANK_SCRIPT % dict(root=ROOT, backend=backend, out=str(tmp_path)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    # own session: on a hang the whole process group (launcher + ranks) is killed, nothing is left holding the GPU
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+    try:
+        out, _ = p.communicate(timeout=240)
+        return types.SimpleNamespace(returncode=p.returncode, stdout=out, timed_out=False)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        out, _ = p.communicate()
+        return types.SimpleNamespace(returncode=-9, stdout=out or "", timed_out=True)
+
+
+def _single_process_reference():
+    from lib.rpn_util import detect_batch
+    from model.M3d_inference_align import build
+    dev = _dev()
+    conf = synth.synth_conf((128, 320), 0, batch_size=4, device="cuda:0")
+    net = build(conf, "test")
+    net.load_state_dict(synth.synth_state_dict(0))
+    net = net.to(dev)
+    d, c = detect_batch(net, synth.synth_frames(4, (128, 320), 31).to(dev), conf)
+    return d.cpu().numpy(), c.cpu().numpy()
+
+
+@pytest.mark.parametrize("backend", ["nccl", "gloo"])
+def test_two_ranks_detect_and_gather_equal_single_process(tmp_path, backend):
+    """The N > 1 path end to end with 2 processes: shard the batch, forward + decode + top-k + NMS per rank on the HIP path,
+    ONE all-gather of the [b, 41, 14] blocks, every rank ends with the detections of the whole batch -- identical to the
+    single-process result.  backend nccl = RCCL (the production backend; both ranks share the one leased GPU, which RCCL
+    may refuse as a duplicate device -- then the RCCL leg is reported as skipped and the gloo leg still covers the path)."""
+    res = _run_ranks(tmp_path, backend)
+    if res.returncode != 0 and backend == "nccl" and (res.timed_out or "uplicate GPU" in res.stdout
+                                                      or "invalid usage" in res.stdout or "ncclInvalidUsage" in res.stdout):
+        _log("two_ranks_nccl", dict(status="refused by RCCL: two ranks on one device", tail=res.stdout[-600:]))
+        pytest.skip("RCCL refuses two ranks on the same device (single leased GPU)")
+    assert res.returncode == 0, res.stdout[-3000:]
+    rd, rc = _single_process_reference()
+    for r in range(2):
+        g = np.load(str(tmp_path / ("rank%d.npz" % r)))
+        assert np.array_equal(g["counts"], rc), (r, g["counts"], rc)
+        assert np.array_equal(g["dets"], rd)
+    _log("two_ranks_" + backend, dict(status="ok"))
+
+
+def test_rccl_single_rank_collective_runs():
+    """RCCL itself on the leased GPU: a 1-rank nccl process group runs the same all_gather_into_tensor the N > 1 path issues."""
+    import subprocess
+    import sys
+    code = ("import os, torch, torch.distributed as dist\n"
+            "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='%d', RANK='0', WORLD_SIZE='1')\n"
+            "torch.cuda.set_device(0)\n"
+            "dist.init_process_group('nccl', rank=0, world_size=1)\n"
+            "b = torch.arange(2 * 41 * 14, device='cuda', dtype=torch.float32).view(2, 41, 14)\n"
+            "o = torch.empty_like(b)\n"
+            "dist.all_gather_into_tensor(o, b)\n"
+            "torch.cuda.synchronize()\n"
+            "assert torch.equal(o, b)\n"
+            "dist.destroy_process_group()\n"
+            "print('RCCL_OK')\n" % _free_port())
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert res.returncode == 0 and "RCCL_OK" in res.stdout, res.stdout[-2000:]

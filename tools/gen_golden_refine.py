@@ -2,8 +2,12 @@
 """Golden vectors for the post-NMS 3-D refinement: the reference's own ``hill_climb``,
 ``test_projection``, ``project_3d`` (lib/rpn_util.py:652-708,2015-2050,921-970) and ``convertAlpha2Rot`` / ``convertRot2Alpha``
 (lib/util.py:516-535) run here on seeded detections with a KITTI-like projection matrix.  The per-box loop of test_kitti_3d
-(lib/rpn_util.py:1801-1852) is inline code in the reference, not a function: it is re-run below with the reference's functions
-doing all the arithmetic, on Python floats (float64).  Writes tests/golden/refine.npz (data only)."""
+(lib/rpn_util.py:1801-1852) is inline code in the reference, not a function: it is re-run below statement by statement on the
+np.float32 scalars `box = aboxes[boxind, :]` yields, with the reference's functions doing all the arithmetic.  The reference
+pins numpy==1.18.1 (requirements.txt:50); this image has numpy 2.2, whose NEP-50 promotion would additionally round
+`np.float32 + Python float` (convertAlpha2Rot's angle sum) to float32, which the reference's environment computes in float64:
+that one argument is widened with float() before the call, everything else (np.float32 * np.float32 products, the float32
+box_2d array) promotes identically under both numpy versions.  Writes tests/golden/refine.npz (data only)."""
 import math
 import os
 import sys
@@ -42,18 +46,25 @@ def main():
             z3d = -2.0                                                            # behind the camera: hill_climb bails out
         row = np.array([x1, y1, x2, y2, score, cls, x3d, y3d, z3d, w3d, h3d, l3d, alpha_in, i], dtype=np.float32)
         rows.append(row)
-        b = [float(v) for v in row]                                               # what the loop sees, promoted once
-        x1, y1, x2, y2, score = b[0:5]
-        x3d, y3d, z3d, w3d, h3d, l3d, ry3d = b[6:13]
+        box = row                                                                 # np.float32 scalars, as in the reference loop
+        x1, y1, x2, y2, score = box[0], box[1], box[2], box[3], box[4]
+        width, height = (x2 - x1 + 1), (y2 - y1 + 1)
+        x3d, y3d, z3d, w3d, h3d, l3d, ry3d = box[6], box[7], box[8], box[9], box[10], box[11], box[12]
+        assert all(isinstance(v, np.float32) for v in (width, height, x3d * z3d, 1 * z3d))
         # ---- lib/rpn_util.py:1813-1847, reference functions, same statement order ----
         coord3d = np.linalg.inv(p2).dot(np.array([x3d * z3d, y3d * z3d, 1 * z3d, 1]))
-        ry3d = convertAlpha2Rot(ry3d, coord3d[2], coord3d[0])
-        box_2d = np.array([x1, y1, x2 - x1 + 1, y2 - y1 + 1])
+        ry3d = convertAlpha2Rot(float(ry3d), coord3d[2], coord3d[0])              # numpy 1.18: np.float32 + float -> float64
+        box_2d = np.array([x1, y1, width, height])
+        assert box_2d.dtype == np.float32
         z3d, ry3d, verts_best = R.hill_climb(p2, p2_inv, box_2d, x3d, y3d, z3d, w3d, h3d, l3d, ry3d,
                                              step_r_init=0.3 * math.pi, r_lim=0.01)
+        assert isinstance(z3d, np.float32) and not isinstance(ry3d, np.float32)
         coord3d = np.linalg.inv(p2).dot(np.array([x3d * z3d, y3d * z3d, 1 * z3d, 1]))
         alpha = convertRot2Alpha(ry3d, coord3d[2], coord3d[0])
-        vals = [alpha, x1, y1, x2, y2, h3d, w3d, l3d, coord3d[0], coord3d[1] + h3d / 2, coord3d[2], ry3d, score]
+        x3d, y3d, z3d = coord3d[0], coord3d[1], coord3d[2]
+        y3d += h3d / 2
+        vals = [float(v) for v in (alpha, x1, y1, x2, y2, h3d, w3d, l3d, x3d, y3d, z3d, ry3d, score)]
+        cls = int(box[5])
         outs.append(vals)
         if score >= 0.75:
             texts.append(('{} -1 -1 {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} '
