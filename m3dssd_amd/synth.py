@@ -11,7 +11,8 @@ tensor keyed by crc32 of its state_dict name, so values do not depend on order):
 * conv_offset_mask is re-randomised (the reference zero-inits it,
   model/DCNv2/dcn_v2.py:60-62, which would make every DCN degenerate), BN running
   stats are randomised, and the background logit bias is raised so that both
-  branches of the ``fg > 0.5`` hard mask (feturealign_mgpu.py:62,164) occur.
+  branches of the ``fg > 0.5`` hard mask (feturealign_mgpu.py:62,164) occur; the ANAB query / key projections are scaled
+  so that the 337-key softmax is not saturated (see ANAB_QK_GAIN below).
 """
 import math
 import zlib
@@ -28,6 +29,7 @@ HEADS_TAIL = ["bbox_z3d"]
 HEADS_TAIL2 = ["bbox_w3d", "bbox_h3d", "bbox_l3d", "bbox_rY3d"]
 BG_BIAS = 4.2
 BOX_OUT_GAIN = 0.15
+ANAB_QK_GAIN = 0.1
 
 
 def _bn(spec, p, c):
@@ -181,6 +183,13 @@ def synth_state_dict(seed=0, num_anchors=36, num_classes=4):
                 v = g.uniform(-stdv, stdv, shape)
             elif name.startswith("bbox_z3d_gl.0"):
                 v = g.normal(0.0, 1.0 / math.sqrt(fan_in), shape)
+                if name.endswith(("query_conv.weight", "key_conv.weight")):
+                    # unit-gain random query / key projections of O(10) features give attention logits of +-2800 over the 337
+                    # keys: a saturated (one-hot) softmax whose output flips on fp32 roundoff -- the float64 run of the
+                    # oracle graph then differs from its own float32 run by 6e-4 in z3d (tools/truth_probe.py), and the
+                    # P.V product is hardly exercised.  0.1 on each side puts the logits at std ~2, max ~25 (mean top weight
+                    # 0.3 at 1280x384): a working attention block, conditioned like a trained one.
+                    v = v * ANAB_QK_GAIN
             else:
                 v = g.normal(0.0, 0.8 * math.sqrt(2.0 / fan_in), shape)
                 if name.startswith("bbox_") and name.endswith(".6.weight"):

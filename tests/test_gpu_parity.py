@@ -408,11 +408,10 @@ def test_forward_matches_oracle(crop, B, pad):
     # downstream of the decisions: compare with the oracle run that takes the SAME decisions
     for name in ("feats", "feats_align2d", "feats_align3d", "feats_gl"):
         got = plan.named[name].torch_nchw().cpu()
-        # intermediates amplify fp32 roundoff (bilinear gathers at learned offsets, a peaky 337-key softmax):
-        # a 2e-7 relative weight perturbation of the ORACLE moves feats_gl by 1e-3 -> relative bound here,
-        # the hard 1e-3 absolute bound is applied to the outputs below
-        # feats_gl sits behind the 337-key softmax of ANAB, the strongest roundoff amplifier of the graph
-        assert _relerr(got, taps_inj[name]) < (1e-2 if name == "feats_gl" else 2e-3), name
+        # intermediates amplify fp32 roundoff (bilinear gathers at learned offsets): relative bound here, the hard 1e-3
+        # absolute bound is applied to the outputs below.  feats_gl (behind ANAB's 337-key softmax) has the same bound as the
+        # others since the synthetic query / key projections no longer saturate the softmax (synth.ANAB_QK_GAIN)
+        assert _relerr(got, taps_inj[name]) < 2e-3, name
     o_cls, o_prob, o_b2, o_b3, o_fs, o_rois = inj
     assert (prob - o_prob).abs().max().item() < 1e-4
     assert (b2 - o_b2).abs().max().item() < 1e-3

@@ -376,11 +376,14 @@ def _single_process_reference():
     from lib.rpn_util import detect_batch
     from model.M3d_inference_align import build
     dev = _dev()
-    conf = synth.synth_conf((128, 320), 0, batch_size=4, device="cuda:0")
+    conf = synth.synth_conf((128, 320), 0, batch_size=2, device="cuda:0")
     net = build(conf, "test")
     net.load_state_dict(synth.synth_state_dict(0))
     net = net.to(dev)
-    d, c = detect_batch(net, synth.synth_frames(4, (128, 320), 31).to(dev), conf)
+    x = synth.synth_frames(4, (128, 320), 31).to(dev)
+    # the same shard-sized batches the two ranks run (a batch-4 plan may split K differently: equal only to fp32 roundoff)
+    parts = [tuple(t.clone() for t in detect_batch(net, x[lo:lo + 2], conf)) for lo in (0, 2)]
+    d, c = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
     return d.cpu().numpy(), c.cpu().numpy()
 
 
