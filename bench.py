@@ -14,7 +14,8 @@ Reported alongside `value`:
                   FLOPs of its launches / their HIP-event duration measured on the launch stream inside the
                   timed region, vs the 157.3 TFLOP/s dense fp32 MFMA peak of MI355X (MI355X_MICROARCH.md).
   cpu_baseline -- the CPU restatement of the reference (oracle/, kind "port": the reference has no CPU DCNv2)
-                  timed on this host on a bounded sample (bs = 1 frames for ~15 s), rank 0 at N = 1 only.
+                  timed on this host on bounded samples (~10 s each at bs = 8 and bs = 1), rank 0 at N = 1 only; the
+                  CPU model string, the host's core count and the threads used are reported.
 """
 import argparse
 import json
@@ -33,31 +34,50 @@ CROP = (384, 1280)
 PER_GPU_BATCH = 8
 
 
-def cpu_baseline(sd, conf_cpu, budget_s=15.0):
-    """Oracle forward + decode + NMS, bs = 1, on the host cores (bounded sample)."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sd, budget_s=10.0):
+    """Oracle forward + decode + NMS on the host cores at bs = 1 and at the benched bs = 8 (bounded samples)."""
     from m3dssd_amd import synth
     from oracle import detect as odet
     from oracle import model_cpu
-    threads = min(32, os.cpu_count() or 1)
+    host = os.cpu_count() or 1
+    threads = min(32, host)                  # torch-CPU conv on these maps stops scaling (and then degrades) past ~32 threads
     torch.set_num_threads(threads)
-    x = synth.synth_frames(1, CROP, 99)
     sd_cpu = {k: v.cpu() for k, v in sd.items()}
+    res = {}
+    for bs in (1, PER_GPU_BATCH):
+        conf_cpu = synth.synth_conf(CROP, 0, batch_size=bs, device="cpu")
+        x = synth.synth_frames(bs, CROP, 99)
 
-    def one():
-        with torch.no_grad():
-            cls, prob, b2, b3, fs, rois = model_cpu.rpn_forward(sd_cpu, conf_cpu, x)
-            odet.detect_image(prob[0], b2[0], b3[0], rois, conf_cpu)
-    one()                                   # warm-up (also builds liboracle.so if needed)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        one()
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s or n >= 50:
-            break
-    return {"value": round(n / dt, 3), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "%d frames of 1280x384 at bs=1 (%.1f s), oracle forward+decode+NMS, torch-CPU %d threads"
-                      % (n, dt, threads)}
+        def one():
+            with torch.no_grad():
+                cls, prob, b2, b3, fs, rois = model_cpu.rpn_forward(sd_cpu, conf_cpu, x)
+                for i in range(bs):
+                    odet.detect_image(prob[i], b2[i], b3[i], rois, conf_cpu)
+        one()                               # warm-up (also builds liboracle.so if needed)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            one()
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget_s or n >= 50:
+                break
+        res[bs] = (bs * n / dt, n, dt)
+    v8, n8, t8 = res[PER_GPU_BATCH]
+    v1, n1, t1 = res[1]
+    return {"value": round(v8, 3), "unit": "images/sec", "cores": threads, "host_cores": host, "cpu_model": _cpu_model(),
+            "kind": "port", "value_bs1": round(v1, 3),
+            "sample": "oracle forward+decode+NMS, torch-CPU %d threads of %d host cores: %d batches of bs=%d (%.1f s) -> value; "
+                      "%d frames at bs=1 (%.1f s) -> value_bs1; 1280x384" % (threads, host, n8, PER_GPU_BATCH, t8, n1, t1)}
 
 
 def kernel_symbol(label):
@@ -80,9 +100,10 @@ def kernel_symbol(label):
 
 
 def pmc_traffic(kernel_label):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_hbm_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 wide-read correction applied); None if the
-    kernel was not profiled.  PMC counters cannot be collected inside the timed run itself."""
+    """(HBM bytes per launch, source file) of a kernel from the committed PMC passes (profiles/*_hbm_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 wide-read correction applied); (None, None) if the
+    kernel was not profiled.  PMC counters cannot be collected inside the timed run itself: the figure is a constant
+    from the builder's profiling lease, labelled as such (`traffic_source`)."""
     import glob
     sym = kernel_symbol(kernel_label)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), reverse=True):
@@ -91,8 +112,29 @@ def pmc_traffic(kernel_label):
         except Exception:
             continue
         if sym in ks:
-            return ks[sym]["hbm_bytes_per_launch"]
-    return None
+            return ks[sym]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+    return None, None
+
+
+def algorithmic_bytes(op):
+    """HBM bytes one launch has to move: input + output (+ residual, + offsets/masks) + weights, once each, fp32."""
+    d = op[4]
+    if d is None:
+        return None
+    if hasattr(d, "Ho"):                                  # m3d_conv_desc
+        o = d.N * d.Ho * d.Wo * d.Cout * 4
+        b = d.N * d.H * d.W * d.Cin * 4 + o + (o if d.res else 0) + d.Cout * d.kh * d.kw * d.Cin * 4
+        if d.dcn_offmask:
+            b += d.N * d.Ho * d.Wo * 3 * d.kh * d.kw * 4
+        return b
+    b = 0                                                 # m3d_mlp_desc or an array of them (batched heads)
+    seen = set()
+    for h in (d if hasattr(d, "__len__") else [d]):
+        if h.inp not in seen:                             # heads of one launch that read the same map read it once
+            seen.add(h.inp)
+            b += h.M * h.Cin * 4
+        b += h.M * h.Cout * 4 + ((h.Cin * 256 if h.w1 else 0) + 256 * 256 + 256 * h.Cout) * 4
+    return b
 
 
 def main():
@@ -251,20 +293,25 @@ def main():
     dom_n = len(eng.profile)
     eng.profile, eng.profile_kinds = None, None
 
-    # algorithmic HBM bytes of the dominant kernel's launches: input + output (+ residual) + weights, once each
+    # algorithmic HBM bytes per launch, per MFMA kernel family (dominant one included)
     plan = eng.plan_for(B, CROP[0], CROP[1])
-    ab, an = 0.0, 0
+    alg = {}
     for op in plan.ops:
-        if op[1] == dominant and op[4] is not None:
-            d = op[4]
-            if hasattr(d, "Ho"):                              # m3d_conv_desc
-                o = d.N * d.Ho * d.Wo * d.Cout * 4
-                ab += d.N * d.H * d.W * d.Cin * 4 + o + (o if d.res else 0) + d.Cout * d.kh * d.kw * d.Cin * 4
-            else:                                             # m3d_mlp_desc or an array of them (batched heads)
-                for h in (d if hasattr(d, "__len__") else [d]):
-                    ab += h.M * h.Cin * 4 + h.M * h.Cout * 4 + ((h.Cin * 256 if h.w1 else 0) + 256 * 256 + 256 * h.Cout) * 4
-            an += 1
-    alg_bytes = int(ab / an) if an else None
+        ab = algorithmic_bytes(op)
+        if ab is not None and op[1] in igemm:
+            a = alg.setdefault(op[1], [0.0, 0])
+            a[0] += ab
+            a[1] += 1
+    alg_bytes = int(alg[dominant][0] / alg[dominant][1]) if dominant in alg else None
+    families = {}
+    for k, (ms, fl, cnt) in sorted(igemm.items(), key=lambda kv: -kv[1][0]):
+        div = 2.25 if k.startswith("wino") else 1.0
+        tf = fl / (ms * 1e-3) / 1e12 / div if ms > 0 else 0.0
+        tr, src = pmc_traffic(k)
+        families[k] = {"kernel": kernel_symbol(k), "launches_per_step": cnt, "ms_per_step": round(ms, 3),
+                       "executed_tflops": round(tf, 1), "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 3),
+                       "algorithmic_bytes_per_launch": int(alg[k][0] / alg[k][1]) if k in alg else None,
+                       "traffic": tr, "traffic_source": src}
 
     if rank == 0:
         value = world * B * args.steps / dt
@@ -293,16 +340,17 @@ def main():
                                   "the 2.4 GHz boost clock") if wino_div > 1 else
                                  "achieved = algorithmic FLOPs of the launches / HIP-event time",
                          "direct_conv_equivalent_tflops": round(achieved, 2),
-                         "traffic": pmc_traffic(dominant), "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
+                         "traffic": pmc_traffic(dominant)[0], "traffic_source": pmc_traffic(dominant)[1],
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes committed under profiles/, not this run)",
                          "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": dom_n,
                          "avg_launch_ms": round(dom_ms / max(dom_n, 1), 4),
                          "avg_launch_gflop": round(dom_flops / max(dom_n, 1) / 1e9, 3),
                          "share_of_gpu_time": round(igemm[dominant][0] / gpu_ms_all, 3)},
             "gpu_ms_by_kernel_one_step": breakdown,
+            "mfma_kernel_families": families,
         }
         if world == 1 and not args.no_cpu_baseline:
-            cconf = synth.synth_conf(CROP, 0, batch_size=1, device="cpu")
-            out["cpu_baseline"] = cpu_baseline(sd, cconf)
+            out["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

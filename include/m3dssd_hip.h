@@ -135,6 +135,59 @@ int m3d_wino_conv3x3_forward_ex(const m3d_conv_desc *d, int variant, m3d_stream_
 int m3d_conv2d_tile(const m3d_conv_desc *d, int *bm, int *bn, int *bk, int *grid);
 
 /* ------------------------------------------------------------------------------------------
+ * bf16 path (BASELINE.json configs[2]: bs = 64, bf16 storage, MFMA v_mfma_f32_32x32x16_bf16, fp32 accumulation).
+ * Same operator as m3d_conv2d_forward -- conv (+ optional DCNv2 gather) + folded BatchNorm / bias + residual +
+ * LeakyReLU / sigmoid in ONE launch -- on bf16 NHWC activations and bf16 weights packed [Cout_pad][Kpad],
+ * K index = (i*kw + j)*Cin + c, zero padded to Kpad % 64 == 0 and Cout_pad % 32 == 0.  scale / shift / offsets / masks
+ * stay fp32.  A kernel larger than 1x1 needs a power-of-two Cin; Cin % 8 == 0, in_cs % 8 == 0.
+ * `groups` > 1 runs that many independent problems of identical geometry in one launch (the RPN heads that read the same
+ * map): group g reads in + g*in_group_off, wgt + g*wgt_group_off, scale/shift + g*ss_group_off and writes
+ * out + g*out_group_off (element units of the respective type).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct m3d_conv_bf16_desc {
+    const void *in;           /* bf16 NHWC view, pixel stride in_cs elements                                 */
+    int in_cs;
+    int N, H, W, Cin;
+    const void *wgt;          /* bf16 [Cout_pad][Kpad]                                                       */
+    long long wgt_img_stride; /* 0, or bf16 elements between per-image weight sets (needs Ho*Wo % 128 == 0)  */
+    int Cout, Cout_pad, Kpad;
+    int kh, kw, stride, pad;
+    int Ho, Wo;
+    void *out;
+    int out_cs;               /* NHWC pixel stride in output elements (modes 0, 1)                           */
+    int out_mode;             /* 0: bf16 NHWC   1: fp32 NHWC   2: fp32 planar out[n*out_img_stride + c*Ho*Wo + p] */
+    long long out_img_stride;
+    const float *scale;       /* [groups][Cout] or NULL (=1)                                                 */
+    const float *shift;       /* [groups][Cout] or NULL (=0)                                                 */
+    const void *res;          /* bf16 NHWC residual view or NULL                                             */
+    int res_cs;
+    int res_mode;             /* 0: acc*scale+shift+res   1: (acc+res)*scale+shift                           */
+    int act;                  /* 0 none, 1 LeakyReLU(0.01)                                                   */
+    int sigmoid_from;         /* channels >= this get sigmoid instead of act; <0: none                       */
+    const float *dcn_offmask; /* fp32 NHWC [.., 3*kh*kw] (2k = dh, 2k+1 = dw, 2*kh*kw + k = mask); NULL = plain conv */
+    int dcn_om_cs;
+    int groups;
+    long long in_group_off, wgt_group_off, out_group_off;
+    int ss_group_off;
+} m3d_conv_bf16_desc;
+int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t stream);
+
+/* HBM-bound helpers of the bf16 path: NHWC bf16 views (pixel strides in bf16 elements, multiples of 8), fp32 arithmetic.
+ * m3d_stem_conv7x7_bf16: DLA.base_layer from the fp32 [N][3][H][W] image (is_u8 = 0; img_h/img_w/mean3/stds3 ignored) or
+ * from uint8 BGR frames [N][img_h][img_w][3] with the reference's test-time Preprocess fused into the loads (is_u8 = 1,
+ * mean3 / stds3 host pointers as in m3d_stem_conv7x7_u8); wgt [7*7*3][16] fp32. */
+int m3d_stem_conv7x7_bf16(const void *img, int is_u8, int img_h, int img_w, const float *mean3, const float *stds3,
+                          const float *wgt, const float *scale, const float *shift, void *out, int out_cs, int N, int H, int W,
+                          m3d_stream_t stream);
+int m3d_maxpool2x2_bf16(const void *in, int in_cs, void *out, int out_cs, int N, int H, int W, int C, m3d_stream_t stream);
+int m3d_upsample2x_add_bf16(const void *in, int in_cs, const float *wgt /*[4][4][C] fp32*/, const void *skip, int skip_cs,
+                            void *out, int out_cs, int N, int H, int W, int C, m3d_stream_t stream);
+int m3d_f32_to_bf16(const float *src, void *dst, long long n /* % 8 == 0 */, m3d_stream_t stream);
+/* softmax over the first `valid` fp32 columns of each row (pixel stride cs) -> bf16 probabilities (row stride out_cs <= 512,
+ * columns [valid, out_cs) zeroed): the P operand of the bf16 P.V GEMM of ANAB (attention.py:208-209). */
+int m3d_softmax_rows_bf16(const float *x, int rows, int valid, int cs, void *out, int out_cs, m3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused RPN head (model/M3d_inference_align.py:77-210): per-pixel MLP
  *   [1x1 Cin->256 + affine + LeakyReLU] -> 1x1 256->256 + affine + LeakyReLU -> 1x1 256->Cout + affine
  * in ONE launch; hidden activations stay in LDS.  Cin = 128 with w1 given (3 layers) or Cin = 256 with

@@ -47,12 +47,39 @@ class MlpDesc(ctypes.Structure):
     ]
 
 
+class ConvBf16Desc(ctypes.Structure):
+    """Mirror of ``m3d_conv_bf16_desc``."""
+    _fields_ = [
+        ("inp", c_void_p), ("in_cs", c_int),
+        ("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int),
+        ("wgt", c_void_p), ("wgt_img_stride", c_ll),
+        ("Cout", c_int), ("Cout_pad", c_int), ("Kpad", c_int),
+        ("kh", c_int), ("kw", c_int), ("stride", c_int), ("pad", c_int),
+        ("Ho", c_int), ("Wo", c_int),
+        ("out", c_void_p), ("out_cs", c_int), ("out_mode", c_int), ("out_img_stride", c_ll),
+        ("scale", c_void_p), ("shift", c_void_p),
+        ("res", c_void_p), ("res_cs", c_int), ("res_mode", c_int),
+        ("act", c_int), ("sigmoid_from", c_int),
+        ("dcn_offmask", c_void_p), ("dcn_om_cs", c_int),
+        ("groups", c_int),
+        ("in_group_off", c_ll), ("wgt_group_off", c_ll), ("out_group_off", c_ll),
+        ("ss_group_off", c_int),
+    ]
+
+
 P = c_void_p
 # name -> (restype, argtypes); every name here must be declared in include/m3dssd_hip.h
 SIGNATURES = {
     "m3d_last_error": (ctypes.c_char_p, []),
     "m3d_abi_version": (c_int, []),
     "m3d_conv2d_forward": (c_int, [ctypes.POINTER(ConvDesc), P]),
+    "m3d_conv_bf16_forward": (c_int, [ctypes.POINTER(ConvBf16Desc), P]),
+    "m3d_stem_conv7x7_bf16": (c_int, [P, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
+                                      P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "m3d_maxpool2x2_bf16": (c_int, [P, c_int, P, c_int] + [c_int] * 4 + [P]),
+    "m3d_upsample2x_add_bf16": (c_int, [P, c_int, P, P, c_int, P, c_int] + [c_int] * 4 + [P]),
+    "m3d_f32_to_bf16": (c_int, [P, P, c_ll, P]),
+    "m3d_softmax_rows_bf16": (c_int, [P, c_int, c_int, c_int, P, c_int, P]),
     "m3d_head_mlp_forward": (c_int, [ctypes.POINTER(MlpDesc), P]),
     "m3d_head_mlp_forward_batched": (c_int, [ctypes.POINTER(MlpDesc), c_int, P]),
     "m3d_wino_conv3x3_forward": (c_int, [ctypes.POINTER(ConvDesc), P]),

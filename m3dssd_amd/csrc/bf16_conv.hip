@@ -1,0 +1,409 @@
+// bf16 implicit-GEMM convolution / DCNv2 for the bs=64 configuration (BASELINE.json configs[2]): bf16 activations and
+// weights in HBM, v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fp32 epilogue (folded BatchNorm + bias, residual,
+// LeakyReLU / sigmoid) and bf16 stores -- every activation crosses HBM once as bf16 (in bf16 the network is
+// HBM-bound unless the element-wise work is fused into the producing kernel).
+//
+//   GEMM view: rows of D = output channels (MFMA "A" operand = weight tile), columns of D = pixels ("B" operand = the
+//   im2col / modulated bilinear gather of the input, built on the fly).  With this orientation a lane of the 32x32
+//   accumulator holds ONE pixel and 4 consecutive channels per register group, so the epilogue works on channel-contiguous
+//   vectors (f32x4 scale / shift / residual, packed bf16 stores) with no LDS transpose.
+//   Workgroup = 256 threads = 4 waves; tile = 128 pixels x BN channels (BN in {32, 64, 128}), K-step 64 (one 128-byte line
+//   per pixel / weight row); LDS tiles [rows][64 bf16] with the 16-byte chunk index XOR-swizzled by (row >> 1) & 7 so that
+//   both the staging ds_write_b128 and the fragment ds_read_b128 are bank-conflict free; register-staged double buffering
+//   (global loads of K-step k+1 are in flight under the MFMAs of K-step k).
+//   Out-of-image taps, rows past M and the zero padding of K use buffer loads whose masked lanes read 0.
+//   blockIdx -> tile mapping is XCD-aware: each XCD owns a contiguous range of tiles, and the channel tiles of one pixel tile
+//   are adjacent (they re-read the same pixels from that XCD's L2).
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+struct Bf16Args {
+    const void *in;            // bf16 NHWC view, pixel stride in_cs elements
+    const void *wgt;           // bf16 [Cout_pad][Kpad] (K = (i*kw + j)*Cin + c), zero padded
+    void *out;
+    const float *scale, *shift;
+    const void *res;           // bf16 NHWC residual view or null
+    const float *om;           // fp32 NHWC [.., 3*kh*kw] offsets / masks (deformable) or null
+    long long wgt_img_stride;  // elements between per-image weight sets (0 = shared)
+    long long out_img_stride;  // planar mode: floats between images
+    long long in_goff, wgt_goff, out_goff;   // per-group element offsets (grouped launch: blockIdx.y = group)
+    unsigned in_bytes, wgt_bytes, res_bytes;
+    int in_cs, N, H, W, Cin, log2Cin;
+    int Cout, Cout_pad, K, KT, kh, kw, stride, pad;
+    int Ho, Wo, HoWo, M;
+    int out_cs, res_cs, om_cs, ss_goff;
+    int out_mode;              // 0 bf16 NHWC, 1 fp32 NHWC, 2 fp32 planar [img][c][HoWo]
+    int res_mode, act, sigmoid_from;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ u32x4 buf_load_u32x4(__amdgpu_buffer_rsrc_t r, unsigned voffset, unsigned soffset)
+{
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voffset, soffset, 0);
+}
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
+{
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ f32x2 unpack_bf16(unsigned u)
+{
+    f32x2 r;
+    r[0] = __uint_as_float(u << 16);
+    r[1] = __uint_as_float(u & 0xFFFF0000u);
+    return r;
+}
+
+template <int BN, bool DEFORM>
+__global__ __launch_bounds__(256) void bf16_conv_kernel(const Bf16Args a)
+{
+    constexpr int BM = 128, BK = 64;
+    constexpr int WN = BN >= 64 ? 2 : 1;          // waves along the channel dim
+    constexpr int WM = 4 / WN;                    // waves along the pixel dim
+    constexpr int TN = BN / (32 * WN);            // 32-channel MFMA tiles per wave
+    constexpr int TM = BM / (32 * WM);            // 32-pixel MFMA tiles per wave
+    constexpr int PB = BN / 32;                   // weight rows per thread and K-step (32 rows per pass)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (BM + BN) * BK * 2];
+    unsigned char *Ps = lds;                      // pixel tiles  [2][BM][128 B]
+    unsigned char *Ws = lds + 2 * BM * BK * 2;    // weight tiles [2][BN][128 B]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave / WN) * (TM * 32), wn = (wave % WN) * (TN * 32);
+
+    // XCD-aware tile mapping (consecutive workgroup ids round-robin over the 8 XCDs)
+    const int ntiles = a.tiles_m * a.tiles_n;
+    int tile = blockIdx.x;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = tile & 7, idx = tile >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = tile / a.tiles_n, tile_n = tile - tile_m * a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int grp = blockIdx.y;
+
+    const __bf16 *inp = (const __bf16 *)a.in + grp * a.in_goff;
+    const __bf16 *wgt = (const __bf16 *)a.wgt + grp * a.wgt_goff;
+    if (a.wgt_img_stride) wgt += (long long)(m0 / a.HoWo) * a.wgt_img_stride;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(inp, a.in_bytes);
+    const __amdgpu_buffer_rsrc_t rwgt = make_rsrc(wgt, a.wgt_bytes);
+
+    // ---- staging map: thread = (row within a 32-row pass, 16-byte chunk of the 128-byte K line) ----------------------
+    const int chunk = tid & 7, rsub = tid >> 3;
+    int pix_base[4], hi0[4], wi0[4];
+    bool rvalid[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int m = m0 + p * 32 + rsub;
+        rvalid[p] = m < a.M;
+        const int mm = rvalid[p] ? m : 0;
+        const int n = mm / a.HoWo, rem = mm - n * a.HoWo;
+        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        pix_base[p] = n * a.H * a.W;
+        hi0[p] = ho * a.stride - a.pad;
+        wi0[p] = wo * a.stride - a.pad;
+    }
+    unsigned woff[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p)
+        woff[p] = ((unsigned)min(n0 + p * 32 + rsub, a.Cout_pad - 1) * (unsigned)(a.KT * BK) + (unsigned)chunk * 8u) * 2u;
+
+    u32x4 rp[4][DEFORM ? 4 : 1];
+    u32x4 rw[PB];
+    float bw[DEFORM ? 4 : 1][4];
+    unsigned doff[DEFORM ? 4 : 1][4];
+    int samp_tap = -1;
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK + chunk * 8;
+        int tap, c;
+        if (a.kh * a.kw == 1) { tap = 0; c = k0; }
+        else { tap = k0 >> a.log2Cin; c = k0 & (a.Cin - 1); }
+        const bool kvalid = k0 < a.K;
+        const int ti = a.kw == 1 ? tap : (a.kw == 3 ? (tap * 11) >> 5 : tap / a.kw);
+        const int tj = tap - ti * a.kw;
+        if constexpr (!DEFORM) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int hi = hi0[p] + ti, wi = wi0[p] + tj;
+                const bool ok = kvalid && rvalid[p] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                const unsigned off = ok ? ((unsigned)(pix_base[p] + hi * a.W + wi) * (unsigned)a.in_cs + (unsigned)c) * 2u
+                                        : M3D_BUF_OOB;
+                rp[p][0] = buf_load_u32x4(rin, off, 0);
+            }
+        } else {
+            if (tap != samp_tap) {      // sampling state of this thread's 4 pixels for the tap (dcn_v2_im2col_cuda.cu:18-47,150-178)
+                samp_tap = tap;
+                const int KK = a.kh * a.kw;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f, mk = 0.f;
+                    int o1 = 0, o2 = 0, o3 = 0, o4 = 0;
+                    if (rvalid[p] && kvalid) {
+                        const float *omp = a.om + (size_t)(m0 + p * 32 + rsub) * a.om_cs;
+                        const float dh = omp[2 * tap], dw = omp[2 * tap + 1];
+                        mk = omp[2 * KK + tap];
+                        const float h_im = (float)(hi0[p] + ti) + dh;
+                        const float w_im = (float)(wi0[p] + tj) + dw;
+                        if (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
+                            const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
+                            const int hh = hl + 1, wh = wl + 1;
+                            const float lh = h_im - (float)hl, lw = w_im - (float)wl;
+                            const float uh = 1.f - lh, uw = 1.f - lw;
+                            if (hl >= 0 && wl >= 0) { w1 = uh * uw; o1 = hl * a.W + wl; }
+                            if (hl >= 0 && wh <= a.W - 1) { w2 = uh * lw; o2 = hl * a.W + wh; }
+                            if (hh <= a.H - 1 && wl >= 0) { w3 = lh * uw; o3 = hh * a.W + wl; }
+                            if (hh <= a.H - 1 && wh <= a.W - 1) { w4 = lh * lw; o4 = hh * a.W + wh; }
+                        }
+                    }
+                    bw[p][0] = w1 * mk; bw[p][1] = w2 * mk; bw[p][2] = w3 * mk; bw[p][3] = w4 * mk;
+                    doff[p][0] = (unsigned)(pix_base[p] + o1) * (unsigned)a.in_cs * 2u;
+                    doff[p][1] = (unsigned)(pix_base[p] + o2) * (unsigned)a.in_cs * 2u;
+                    doff[p][2] = (unsigned)(pix_base[p] + o3) * (unsigned)a.in_cs * 2u;
+                    doff[p][3] = (unsigned)(pix_base[p] + o4) * (unsigned)a.in_cs * 2u;
+                }
+            }
+            const unsigned cb = (unsigned)c * 2u;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rp[p][q] = buf_load_u32x4(rin, doff[p][q] + cb, 0);
+        }
+        const unsigned wso = (unsigned)kt * (BK * 2u);
+#pragma unroll
+        for (int p = 0; p < PB; ++p) rw[p] = buf_load_u32x4(rwgt, woff[p], wso);
+    };
+
+    auto store_tile = [&](int buf) {
+        unsigned char *Pb = Ps + buf * BM * 128, *Wb = Ws + buf * BN * 128;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = p * 32 + rsub;
+            u32x4 v;
+            if constexpr (!DEFORM) {
+                v = rp[p][0];
+            } else {
+                // (w1*v1 + w2*v2 + w3*v3 + w4*v4) with the modulation mask folded into the corner weights, fp32, then one
+                // rounding to bf16 (dcn_v2_im2col_cuda.cu:44-46,174)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x2 v1 = unpack_bf16(rp[p][0][e]), v2 = unpack_bf16(rp[p][1][e]);
+                    const f32x2 v3 = unpack_bf16(rp[p][2][e]), v4 = unpack_bf16(rp[p][3][e]);
+                    const f32x2 r = v1 * bw[p][0] + v2 * bw[p][1] + v3 * bw[p][2] + v4 * bw[p][3];
+                    v[e] = pack_bf16(r[0], r[1]);
+                }
+            }
+            *reinterpret_cast<u32x4 *>(Pb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = v;
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int row = p * 32 + rsub;
+            *reinterpret_cast<u32x4 *>(Wb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = rw[p];
+        }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int sw = (l31 >> 1) & 7;                 // fragment rows are (multiple of 32) + l31: the swizzle term is per lane
+    for (int kt = 0; kt < a.KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < a.KT) load_tile(kt + 1);
+        const unsigned char *Pb = Ps + buf * BM * 128 + (wm + l31) * 128;
+        const unsigned char *Wb = Ws + buf * BN * 128 + (wn + l31) * 128;
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            const int co = ((2 * s + lh) ^ sw) << 4;
+            bf16x8 fw[TN], fp[TM];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fw[j] = *reinterpret_cast<const bf16x8 *>(Wb + j * 32 * 128 + co);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fp[i] = *reinterpret_cast<const bf16x8 *>(Pb + i * 32 * 128 + co);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fp[i], acc[j][i], 0, 0, 0);
+        }
+        if (kt + 1 < a.KT) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[row = channel][col = pixel]; lane = pixel l31, channels 8g + 4*lh + (0..3) per register group g --
+    const float *scale = a.scale ? a.scale + grp * a.ss_goff : nullptr;
+    const float *shift = a.shift ? a.shift + grp * a.ss_goff : nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm + i * 32 + l31;
+        const bool mok = m < a.M;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cb = n0 + wn + j * 32 + 4 * lh;          // + 8g
+            f32x4 v[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = cb + 8 * g;
+                f32x4 x = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
+                f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                // scale / shift hold Cout floats: the last vector of a channel count that is not a multiple of 4 is read by element
+                if (c0 + 3 < a.Cout) {
+                    if (scale) sc = *reinterpret_cast<const f32x4 *>(scale + c0);
+                    if (shift) sh = *reinterpret_cast<const f32x4 *>(shift + c0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c0 + e < a.Cout) {
+                            if (scale) sc[e] = scale[c0 + e];
+                            if (shift) sh[e] = shift[c0 + e];
+                        }
+                }
+                f32x4 rs = {0.f, 0.f, 0.f, 0.f};
+                if (a.res && mok && c0 < a.Cout) {
+                    const u32x2 rr = *reinterpret_cast<const u32x2 *>((const __bf16 *)a.res + (size_t)m * a.res_cs + c0);
+                    const f32x2 r01 = unpack_bf16(rr[0]), r23 = unpack_bf16(rr[1]);
+                    rs[0] = r01[0]; rs[1] = r01[1]; rs[2] = r23[0]; rs[3] = r23[1];
+                }
+                if (a.res_mode == 1) x = (x + rs) * sc + sh;
+                else x = x * sc + sh + rs;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (a.sigmoid_from >= 0 && c0 + e >= a.sigmoid_from) x[e] = sigmoidf_(x[e]);
+                    else if (a.act) x[e] = leaky(x[e]);
+                }
+                v[g] = x;
+            }
+            if (a.out_mode == 0) {
+                // bf16 NHWC: pack 4 channels per group, then v_permlane32_swap pairs lane (pixel, lh = 0) with (pixel, lh = 1)
+                // so that each lane ends up with 8 CONSECUTIVE channels of its pixel -> 16-byte stores
+                unsigned pk[4][2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    pk[g][0] = pack_bf16(v[g][0], v[g][1]);
+                    pk[g][1] = pack_bf16(v[g][2], v[g][3]);
+                }
+                // before: lanes lh=0 hold channels 8g + 0..3, lanes lh=1 hold 8g + 4..7.  Swap the upper half of group g (g even)
+                // with the lower half of group g + 1: lh=0 lanes then hold channels 8g + 0..7 in (pk[g], pk[g+1]); lh=1 lanes hold
+                // 8(g+1) + 0..7.
+#pragma unroll
+                for (int g = 0; g < 4; g += 2)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const auto r = __builtin_amdgcn_permlane32_swap(pk[g][e], pk[g + 1][e], false, false);
+                        pk[g][e] = r[0]; pk[g + 1][e] = r[1];
+                    }
+                if (mok) {
+                    __bf16 *op = (__bf16 *)a.out + grp * a.out_goff + (size_t)m * a.out_cs;
+#pragma unroll
+                    for (int g = 0; g < 4; g += 2) {
+                        const int c0 = n0 + wn + j * 32 + 8 * (g + lh);
+                        const u32x4 o = {pk[g][0], pk[g][1], pk[g + 1][0], pk[g + 1][1]};
+                        if (c0 + 7 < a.Cout) *reinterpret_cast<u32x4 *>(op + c0) = o;
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if (c0 + e < a.Cout)
+                                    reinterpret_cast<unsigned short *>(op)[c0 + e] = (unsigned short)(o[e >> 1] >> ((e & 1) * 16));
+                        }
+                    }
+                }
+            } else if (a.out_mode == 1) {
+                if (mok) {
+                    float *op = (float *)a.out + grp * a.out_goff + (size_t)m * a.out_cs;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c0 = cb + 8 * g;
+                        if (c0 + 3 < a.Cout) *reinterpret_cast<f32x4 *>(op + c0) = v[g];
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (c0 + e < a.Cout) op[c0 + e] = v[g][e];
+                        }
+                    }
+                }
+            } else {
+                if (mok) {
+                    const int img = m / a.HoWo, p = m - img * a.HoWo;
+                    float *op = (float *)a.out + grp * a.out_goff + (size_t)img * a.out_img_stride + p;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int c = cb + 8 * g + e;
+                            if (c < a.Cout) op[(size_t)c * a.HoWo] = v[g][e];
+                        }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+static int ilog2_exact(int v)
+{
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+
+extern "C" int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t stream)
+{
+    M3D_REQUIRE(d && d->in && d->wgt && d->out, "conv_bf16: null pointer");
+    M3D_REQUIRE(d->Cin % 8 == 0 && d->in_cs % 8 == 0, "conv_bf16: Cin (%d) and in_cs (%d) must be multiples of 8", d->Cin, d->in_cs);
+    M3D_REQUIRE(d->Cout_pad % 32 == 0 && d->Cout <= d->Cout_pad, "conv_bf16: Cout_pad %% 32");
+    M3D_REQUIRE(d->groups >= 1, "conv_bf16: groups >= 1");
+    const int taps = d->kh * d->kw;
+    const int lg = ilog2_exact(d->Cin);
+    M3D_REQUIRE(taps == 1 || lg >= 3, "conv_bf16: a %dx%d kernel needs a power-of-two Cin (got %d)", d->kh, d->kw, d->Cin);
+    const int ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1, wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
+    M3D_REQUIRE(ho == d->Ho && wo == d->Wo, "conv_bf16: Ho/Wo (%d, %d) do not match the geometry (%d, %d)", d->Ho, d->Wo, ho, wo);
+    const int K = taps * d->Cin;
+    M3D_REQUIRE(d->Kpad % 64 == 0 && d->Kpad >= K, "conv_bf16: Kpad (%d) must be a multiple of 64 >= K (%d)", d->Kpad, K);
+    const long long M = (long long)d->N * ho * wo;
+    const long long in_bytes = (long long)d->N * d->H * d->W * d->in_cs * 2;
+    M3D_REQUIRE(in_bytes < 0x7FFFFFFFLL && M < 0x7FFFFFFFLL, "conv_bf16: input view must be < 2 GiB");
+    if (d->out_mode == 0) M3D_REQUIRE(d->out_cs % 8 == 0 && ((uintptr_t)d->out & 15) == 0, "conv_bf16: bf16 output needs out_cs %% 8 == 0 and 16-byte alignment");
+    if (d->out_mode == 1) M3D_REQUIRE(d->out_cs % 4 == 0 && ((uintptr_t)d->out & 15) == 0, "conv_bf16: fp32 NHWC output needs out_cs %% 4 == 0");
+    if (d->res) M3D_REQUIRE(d->res_cs % 4 == 0 && ((uintptr_t)d->res & 7) == 0, "conv_bf16: residual view alignment");
+    if (d->wgt_img_stride) M3D_REQUIRE((ho * wo) % 128 == 0, "conv_bf16: per-image weights need Ho*Wo %% 128 == 0");
+    if (d->dcn_offmask) M3D_REQUIRE(d->stride == 1 && d->groups == 1, "conv_bf16: deformable mode is stride 1, ungrouped");
+
+    Bf16Args a;
+    a.in = d->in; a.wgt = d->wgt; a.out = d->out; a.scale = d->scale; a.shift = d->shift; a.res = d->res; a.om = d->dcn_offmask;
+    a.wgt_img_stride = d->wgt_img_stride; a.out_img_stride = d->out_img_stride;
+    a.in_goff = d->in_group_off; a.wgt_goff = d->wgt_group_off; a.out_goff = d->out_group_off; a.ss_goff = d->ss_group_off;
+    a.in_bytes = (unsigned)in_bytes;
+    const long long wrows = d->wgt_img_stride ? d->wgt_img_stride : (long long)d->Cout_pad * d->Kpad;
+    a.wgt_bytes = (unsigned)(wrows * 2);
+    a.res_bytes = 0;
+    a.in_cs = d->in_cs; a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.log2Cin = lg < 0 ? 0 : lg;
+    a.Cout = d->Cout; a.Cout_pad = d->Cout_pad; a.K = K; a.KT = d->Kpad / 64; a.kh = d->kh; a.kw = d->kw; a.stride = d->stride;
+    a.pad = d->pad; a.Ho = ho; a.Wo = wo; a.HoWo = ho * wo; a.M = (int)M;
+    a.out_cs = d->out_cs; a.res_cs = d->res_cs; a.om_cs = d->dcn_om_cs;
+    a.out_mode = d->out_mode; a.res_mode = d->res_mode; a.act = d->act; a.sigmoid_from = d->sigmoid_from;
+    const int bn = d->Cout_pad % 128 == 0 ? 128 : (d->Cout_pad % 64 == 0 ? 64 : 32);
+    a.tiles_m = cdiv(M, 128); a.tiles_n = d->Cout_pad / bn;
+    const dim3 grid(a.tiles_m * a.tiles_n, d->groups), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const bool deform = d->dcn_offmask != nullptr;
+#define LAUNCH(BN_, DF_) hipLaunchKernelGGL((bf16_conv_kernel<BN_, DF_>), grid, block, 0, st, a)
+    if (bn == 128) { if (deform) LAUNCH(128, true); else LAUNCH(128, false); }
+    else if (bn == 64) { if (deform) LAUNCH(64, true); else LAUNCH(64, false); }
+    else { if (deform) LAUNCH(32, true); else LAUNCH(32, false); }
+#undef LAUNCH
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}

@@ -1,0 +1,475 @@
+"""bf16 inference engine (BASELINE.json configs[2]: bs = 64, bf16 storage, MFMA v_mfma_f32_32x32x16_bf16).
+
+Same graph and the same plan / launch machinery as ``engine.Engine`` (model/M3d_inference_align.py:215-313), with
+
+  * activations and weights stored as bf16 in HBM, fp32 accumulation, fp32 folded-BatchNorm / bias / residual / activation
+    epilogues inside the producing kernel (``m3d_conv_bf16_forward``) -- every activation crosses HBM once, as bf16;
+  * everything that decides something discrete or addresses memory stays fp32: DCN offsets / masks, the class logits
+    and box regressions written by the last head layers (planar fp32, consumed unchanged by ``m3d_anchor_select``,
+    ``m3d_align_offsets``, ``m3d_bundle_outputs`` and the detection stage), the ANAB keys / values before pooling and
+    the attention logits before the softmax;
+  * the three layers of the RPN heads that read the same feature map run as grouped launches (layer 1 is ONE GEMM
+    128 -> G*256, layers 2 / 3 are ``groups = G`` launches).
+
+Numerics contract: bf16 has an 8-bit significand (relative rounding 2^-9); through ~50 layers the 3-D box parameters agree
+with the fp32 oracle to ~1e-1 absolute (measured and asserted in tests/test_gpu_bf16.py), against 1e-3 for the fp32 path.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import _hip
+from ._hip import ConvBf16Desc
+from .engine import BN_EPS, PSP_SIZES, Engine, _Plan, _rup, _Stream
+
+BF16 = torch.bfloat16
+
+
+class View16:
+    """NHWC bf16 view (possibly a channel slice) of a device buffer; strides in elements."""
+    __slots__ = ("t", "ptr", "n", "h", "w", "c", "cs", "esize")
+
+    def __init__(self, t, n, h, w, c, cs=None, ptr=None):
+        self.t, self.n, self.h, self.w, self.c = t, n, h, w, c
+        self.cs = c if cs is None else cs
+        self.esize = t.element_size()
+        self.ptr = t.data_ptr() if ptr is None else ptr
+
+    def slice(self, c0, c):
+        assert c0 % 8 == 0 and c0 + c <= self.cs
+        return View16(self.t, self.n, self.h, self.w, c, self.cs, self.ptr + self.esize * c0)
+
+    def torch_nchw(self):
+        full = self.t.view(self.n, self.h, self.w, self.cs)
+        off = (self.ptr - self.t.data_ptr()) // self.esize
+        return full[..., off:off + self.c].permute(0, 3, 1, 2).float().contiguous()
+
+
+def pack_conv_bf16(weight, cout_pad=None, cin_pad=None, device=None):
+    """[Cout, Cin, kh, kw] -> bf16 [Cout_pad][Kpad], K = (i*kw + j)*Cin_pad + c (tap-major), zero padded; Kpad % 64 == 0."""
+    w = weight.detach().to(device if device is not None else weight.device, torch.float32)
+    co, ci, kh, kw = w.shape
+    cip = ci if cin_pad is None else cin_pad
+    cop = _rup(co, 32) if cout_pad is None else cout_pad
+    k = kh * kw * cip
+    kpad = _rup(k, 64)
+    p = torch.zeros(cop, kh * kw, cip, device=w.device, dtype=torch.float32)
+    p[:co, :, :ci] = w.permute(0, 2, 3, 1).reshape(co, kh * kw, ci)
+    out = torch.zeros(cop, kpad, device=w.device, dtype=BF16)
+    out[:, :k] = p.reshape(cop, k).to(BF16)
+    return out.contiguous(), kpad
+
+
+class PackedBf16:
+    def __init__(self, eng, weight, bias=None, bn=None, cout_pad=None):
+        dev = eng.device
+        self.cout, self.cin, self.kh, self.kw = weight.shape
+        self.wp, self.kpad = pack_conv_bf16(weight, cout_pad, None, dev)
+        self.cout_pad = self.wp.shape[0]
+        scale = torch.ones(self.cout, device=dev, dtype=torch.float32)
+        shift = torch.zeros(self.cout, device=dev, dtype=torch.float32)
+        if bias is not None:
+            shift = bias.detach().to(dev, torch.float32).clone()
+        if bn is not None:
+            g, b, m, v = (t.detach().to(dev, torch.float32) for t in bn)
+            s = g / torch.sqrt(v + BN_EPS)
+            shift = (shift - m) * s + b
+            scale = s
+        self.scale, self.shift = scale.contiguous(), shift.contiguous()
+        self.has_affine = (bias is not None) or (bn is not None)
+
+
+class EngineBF16(Engine):
+    compute_dtype = "bf16"
+
+    # ------------------------------------------------------------------ parameters
+    def _pc(self, conv, bn=None, **kw):
+        sd = self.sd
+        return PackedBf16(self, sd[conv + ".weight"], sd.get(conv + ".bias"), self._bn(bn) if bn else None, **kw)
+
+    def _pack(self, sd):
+        dev = self.device
+        P = {}
+        b = "base.base"
+        w = sd[b + ".base_layer.0.weight"].detach().to(dev, torch.float32)
+        P["stem.w"] = w.permute(2, 3, 1, 0).contiguous()
+        g, be, m, v = (t.detach().to(dev, torch.float32) for t in self._bn(b + ".base_layer.1"))
+        s = g / torch.sqrt(v + BN_EPS)
+        P["stem.scale"], P["stem.shift"] = s.contiguous(), (be - m * s).contiguous()
+        P["level0"] = self._pc(b + ".level0.0", b + ".level0.1")
+        P["level1"] = self._pc(b + ".level1.0", b + ".level1.1")
+
+        def block(p):
+            P[p + ".conv1"] = self._pc(p + ".conv1", p + ".bn1")
+            P[p + ".conv2"] = self._pc(p + ".conv2", p + ".bn2")
+
+        def tree1(p):
+            block(p + ".tree1")
+            block(p + ".tree2")
+            P[p + ".root"] = self._pc(p + ".root.conv", p + ".root.bn")
+            if (p + ".project.0.weight") in sd:
+                P[p + ".project"] = self._pc(p + ".project.0", p + ".project.1")
+
+        tree1(b + ".level2")
+        for lv in (3, 4):
+            tree1("%s.level%d.tree1" % (b, lv))
+            tree1("%s.level%d.tree2" % (b, lv))
+        tree1(b + ".level5")
+
+        def deform(p):
+            P[p + ".om"] = self._pc(p + ".conv.conv_offset_mask")
+            P[p + ".dcn"] = PackedBf16(self, sd[p + ".conv.weight"], sd[p + ".conv.bias"], self._bn(p + ".actf.0"))
+
+        def ida(p, n):
+            for i in range(1, n):
+                deform("%s.proj_%d" % (p, i))
+                deform("%s.node_%d" % (p, i))
+                up = sd["%s.up_%d.weight" % (p, i)].detach().to(dev, torch.float32)
+                P["%s.up_%d" % (p, i)] = up[:, 0].permute(1, 2, 0).contiguous()
+
+        ida("base.dla_up.ida_0", 2)
+        ida("base.dla_up.ida_1", 3)
+        ida("base.ida_up", 2)
+        self.P = P
+        if not self.backbone_only:
+            self._pack_heads_bf16(sd, P)
+        torch.cuda.synchronize(self.device)
+
+    def _pack_heads_bf16(self, sd, P):
+        dev = self.device
+        self.box_heads = ["bbox_x", "bbox_y", "bbox_w", "bbox_h", "bbox_x3d", "bbox_y3d", "bbox_z3d", "bbox_w3d",
+                          "bbox_h3d", "bbox_l3d", "bbox_rY3d"]
+        for p in ["cls"] + self.box_heads:
+            P[p + ".0"] = self._pc(p + ".0", p + ".1")
+            P[p + ".3"] = self._pc(p + ".3", p + ".4")
+            P[p + ".6"] = self._pc(p + ".6", cout_pad=_rup(sd[p + ".6.weight"].shape[0], 64))
+        for p in ("shape_align", "center_align2d", "center_align3d"):
+            P[p] = PackedBf16(self, sd[p + ".align.weight"], sd[p + ".align.bias"], None)
+        a = "bbox_z3d_gl.0"
+        wq, wk, wv, ws = (sd[a + n].detach().cpu().float() for n in
+                          (".query_conv.weight", ".key_conv.weight", ".value_conv.weight", ".spatial_conv.weight"))
+        self.ck, self.cv, self.ns = wq.shape[0], wv.shape[0], ws.shape[0]
+        self.ck_pad = _rup(self.ck, 64)                                  # K of the logits GEMM
+        P["anab.q"] = PackedBf16(self, wq, None, None, cout_pad=self.ck_pad)
+        P["anab.kvs"] = PackedBf16(self, torch.cat([wk, wv, ws], 0), None, None)
+        g, be, m, v = (t.detach().to(dev, torch.float32) for t in self._bn("bbox_z3d_gl.1"))
+        s = g / torch.sqrt(v + BN_EPS)
+        P["anab.bn.scale"], P["anab.bn.shift"] = s.contiguous(), (be - m * s).contiguous()
+        anchors = torch.as_tensor(np.asarray(self.conf.anchors), dtype=torch.float32)
+        aw = (anchors[:, 2] - anchors[:, 0])
+        ah = (anchors[:, 3] - anchors[:, 1])
+        tab = torch.zeros(self.A, 18, dtype=torch.float32)
+        h_step, w_step = ah / self.stride / 3, aw / self.stride / 3
+        for i in range(3):
+            for j in range(3):
+                k = i * 3 + j
+                tab[:, 2 * k] = (h_step - 1) * (i - 3 / 2 + 0.5)
+                tab[:, 2 * k + 1] = (w_step - 1) * (j - 3 / 2 + 0.5)
+        P["shape.table"] = tab.to(dev).contiguous()
+        P["anchor_wh"] = torch.stack([aw / self.stride, ah / self.stride], 1).to(dev).contiguous()
+        P["anchors"] = anchors.to(dev).contiguous()
+        P["means"] = torch.as_tensor(np.asarray(self.conf.bbox_means), dtype=torch.float32).reshape(-1).to(dev)
+        P["stds"] = torch.as_tensor(np.asarray(self.conf.bbox_stds), dtype=torch.float32).reshape(-1).to(dev)
+
+    # ------------------------------------------------------------------ launch helpers
+    def _buf16(self, plan, n, h, w, c, cs=None, name=None, dtype=BF16, zero=False):
+        cs = c if cs is None else cs
+        t = (torch.zeros if zero else torch.empty)(n * h * w * cs, device=self.device, dtype=dtype)
+        plan.keep.append(t)
+        v = View16(t, n, h, w, c, cs)
+        if name:
+            plan.named[name] = v
+        return v
+
+    def _conv16(self, plan, name, x, out=None, wgt=None, kpad=None, cout=None, cout_pad=None, kh=1, kw=1, stride=1, pad=0,
+                scale=None, shift=None, act=0, res=None, res_mode=0, sigmoid_from=-1, om=None, out_mode=0, planar=None,
+                wgt_img_stride=0, groups=1, in_goff=0, wgt_goff=0, out_goff=0, ss_goff=0, cin=None, flops_cin=None):
+        """One m3d_conv_bf16_forward launch appended to the plan.  x: View16 (bf16); out: View16 (bf16 or fp32 NHWC) or
+        planar = (tensor, img_stride, channel offset) for the fp32 planar staging of the head outputs."""
+        d = ConvBf16Desc()
+        cin = x.c if cin is None else cin
+        d.inp, d.in_cs, d.N, d.H, d.W, d.Cin = x.ptr, x.cs, x.n, x.h, x.w, cin
+        d.wgt, d.wgt_img_stride = wgt.data_ptr() if hasattr(wgt, "data_ptr") else wgt, wgt_img_stride
+        d.Cout, d.Cout_pad, d.Kpad = cout, cout_pad, kpad
+        d.kh, d.kw, d.stride, d.pad = kh, kw, stride, pad
+        d.Ho = (x.h + 2 * pad - kh) // stride + 1
+        d.Wo = (x.w + 2 * pad - kw) // stride + 1
+        if planar is not None:
+            t, img_stride, ch_off = planar
+            d.out, d.out_mode, d.out_img_stride = t.data_ptr() + 4 * ch_off * d.Ho * d.Wo, 2, img_stride
+        else:
+            assert out.h == d.Ho and out.w == d.Wo, (name, out.h, out.w, d.Ho, d.Wo)
+            d.out, d.out_cs, d.out_mode = out.ptr, out.cs, out_mode
+        if scale is not None:
+            d.scale = scale.data_ptr()
+        if shift is not None:
+            d.shift = shift.data_ptr()
+        plan.keep += [t for t in (scale, shift, wgt) if hasattr(t, "data_ptr")]
+        if res is not None:
+            d.res, d.res_cs, d.res_mode = res.ptr, res.cs, res_mode
+        d.act, d.sigmoid_from = act, sigmoid_from
+        if om is not None:
+            d.dcn_offmask, d.dcn_om_cs = om.ptr, om.cs
+        d.groups, d.in_group_off, d.wgt_group_off, d.out_group_off, d.ss_group_off = groups, in_goff, wgt_goff, out_goff, ss_goff
+        L = self.L
+        ref = ctypes.byref(d)
+        flops = 2.0 * x.n * d.Ho * d.Wo * cout * kh * kw * (flops_cin if flops_cin is not None else cin) * groups
+        bn = 128 if cout_pad % 128 == 0 else (64 if cout_pad % 64 == 0 else 32)
+        kind = "bf16_conv<%d%s>" % (bn, ",deform" if om is not None else "")
+        plan.ops.append((name, kind, flops, lambda st: _hip.check(L.m3d_conv_bf16_forward(ref, st)), d))
+
+    def _pconv(self, plan, name, pc, x, out, stride=1, pad=0, act=0, res=None, res_mode=0, sigmoid_from=-1, om=None, out_mode=0,
+               affine=True):
+        self._conv16(plan, name, x, out, wgt=pc.wp, kpad=pc.kpad, cout=pc.cout, cout_pad=pc.cout_pad, kh=pc.kh, kw=pc.kw,
+                     stride=stride, pad=pad, scale=pc.scale if (affine and pc.has_affine) else None,
+                     shift=pc.shift if (affine and pc.has_affine) else None, act=act, res=res, res_mode=res_mode,
+                     sigmoid_from=sigmoid_from, om=om, out_mode=out_mode, cin=pc.cin)
+
+    # ------------------------------------------------------------------ plan construction
+    def _build_plan(self, B, H, W):
+        L, P = self.L, self.P
+        plan = _Plan()
+        b = "base.base"
+        in_ptr = [0]
+        plan.named["input_ptr"] = in_ptr
+        in_u8 = [0, 0, 0]
+        plan.named["input_u8"] = in_u8
+        mean3 = (ctypes.c_float * 3)(*[float(v) for v in self.conf.image_means])
+        stds3 = (ctypes.c_float * 3)(*[float(v) for v in self.conf.image_stds])
+        s0 = self._buf16(plan, B, H, W, 16)
+
+        def stem(st):
+            u8 = 1 if in_u8[0] else 0
+            _hip.check(L.m3d_stem_conv7x7_bf16(in_u8[0] if u8 else in_ptr[0], u8, in_u8[1], in_u8[2], mean3, stds3,
+                                               P["stem.w"].data_ptr(), P["stem.scale"].data_ptr(), P["stem.shift"].data_ptr(),
+                                               s0.ptr, s0.cs, B, H, W, st))
+        self._op(plan, "stem", "stem_bf16", stem)
+        l0 = self._buf16(plan, B, H, W, 16, name="level0")
+        self._pconv(plan, "level0", P["level0"], s0, l0, 1, 1, act=1)
+        l1 = self._buf16(plan, B, H // 2, W // 2, 32, name="level1")
+        self._pconv(plan, "level1", P["level1"], l0, l1, 2, 1, act=1)
+
+        def maxpool(name, x, out):
+            self._op(plan, name, "maxpool_bf16", lambda st: _hip.check(L.m3d_maxpool2x2_bf16(
+                x.ptr, x.cs, out.ptr, out.cs, x.n, x.h, x.w, x.c, st)))
+
+        def block(p, x, res, out, stride):
+            co = P[p + ".conv1"].cout
+            t = self._buf16(plan, B, out.h, out.w, co)
+            self._pconv(plan, p + ".conv1", P[p + ".conv1"], x, t, stride, 1, act=1)
+            self._pconv(plan, p + ".conv2", P[p + ".conv2"], t, out, 1, 1, act=1, res=res)
+
+        def tree1(p, x, co, stride, out, bottom=None):
+            h, w = x.h // stride, x.w // stride
+            cat = self._buf16(plan, B, h, w, 2 * co)
+            x2v, x1v = cat.slice(0, co), cat.slice(co, co)
+            if stride == 1:
+                bottom = x
+            elif bottom is None:
+                bottom = self._buf16(plan, B, h, w, x.c)
+                maxpool(p + ".downsample", x, bottom)
+            if (p + ".project") in P:
+                res = self._buf16(plan, B, h, w, co)
+                self._pconv(plan, p + ".project", P[p + ".project"], bottom, res, 1, 0, act=0)
+            else:
+                res = bottom
+            block(p + ".tree1", x, res, x1v, stride)
+            block(p + ".tree2", x1v, x1v, x2v, 1)
+            self._pconv(plan, p + ".root", P[p + ".root"], cat, out, 1, 0, act=1)
+
+        l2 = self._buf16(plan, B, H // 4, W // 4, 64, name="level2")
+        tree1(b + ".level2", l1, 64, 2, l2)
+
+        def tree2(p, x, co, out):
+            ci = x.c
+            h, w = x.h // 2, x.w // 2
+            catb = self._buf16(plan, B, h, w, 2 * co + ci + co)
+            bottom = catb.slice(2 * co, ci)
+            X1 = catb.slice(2 * co + ci, co)
+            maxpool(p + ".downsample", x, bottom)
+            tree1(p + ".tree1", x, co, 2, X1, bottom=bottom)
+            x2v, x1v = catb.slice(0, co), catb.slice(co, co)
+            block(p + ".tree2.tree1", X1, X1, x1v, 1)
+            block(p + ".tree2.tree2", x1v, x1v, x2v, 1)
+            self._pconv(plan, p + ".tree2.root", P[p + ".tree2.root"], catb, out, 1, 0, act=1)
+
+        l3 = self._buf16(plan, B, H // 8, W // 8, 128, name="level3")
+        tree2(b + ".level3", l2, 128, l3)
+        l4 = self._buf16(plan, B, H // 16, W // 16, 256, name="level4")
+        tree2(b + ".level4", l3, 256, l4)
+        l5 = self._buf16(plan, B, H // 32, W // 32, 512, name="level5")
+        h5, w5 = H // 32, W // 32
+        cat5 = self._buf16(plan, B, h5, w5, 1024 + 256)
+        bottom5 = cat5.slice(1024, 256)
+        maxpool(b + ".level5.downsample", l4, bottom5)
+        res5 = self._buf16(plan, B, h5, w5, 512)
+        self._pconv(plan, b + ".level5.project", P[b + ".level5.project"], bottom5, res5, 1, 0, act=0)
+        block(b + ".level5.tree1", l4, res5, cat5.slice(512, 512), 2)
+        block(b + ".level5.tree2", cat5.slice(512, 512), cat5.slice(512, 512), cat5.slice(0, 512), 1)
+        self._pconv(plan, b + ".level5.root", P[b + ".level5.root"], cat5, l5, 1, 0, act=1)
+
+        # ---- DLAUp / IDAUp: offsets / masks stay fp32 (they address memory) ---------------------------
+        def deform(p, x, out):
+            om = self._buf16(plan, B, x.h, x.w, 27, 32, dtype=torch.float32)
+            self._pconv(plan, p + ".offset_mask", P[p + ".om"], x, om, 1, 1, act=0, sigmoid_from=18, out_mode=1)
+            self._pconv(plan, p + ".dcn", P[p + ".dcn"], x, out, 1, 1, act=1, om=om)
+            plan.named[p + ".out"] = out
+
+        def ida_step(p, i, x, skip, co):
+            proj = self._buf16(plan, B, x.h, x.w, co)
+            deform("%s.proj_%d" % (p, i), x, proj)
+            summed = self._buf16(plan, B, 2 * x.h, 2 * x.w, co)
+            upw = P["%s.up_%d" % (p, i)]
+            self._op(plan, "%s.up_%d" % (p, i), "upsample_bf16", lambda st: _hip.check(L.m3d_upsample2x_add_bf16(
+                proj.ptr, proj.cs, upw.data_ptr(), skip.ptr, skip.cs, summed.ptr, summed.cs, B, proj.h, proj.w, co, st)))
+            node = self._buf16(plan, B, 2 * x.h, 2 * x.w, co)
+            deform("%s.node_%d" % (p, i), summed, node)
+            return node
+
+        L5a = ida_step("base.dla_up.ida_0", 1, l5, l4, 256)
+        L4b = ida_step("base.dla_up.ida_1", 1, l4, l3, 128)
+        L5b = ida_step("base.dla_up.ida_1", 2, L5a, L4b, 128)
+        feats0 = ida_step("base.ida_up", 1, L5a, L5b, 128)
+        plan.named["feats0"] = feats0
+        plan.feat = (feats0.h, feats0.w)
+        if self.backbone_only:
+            return plan
+
+        # ---- RPN heads ----------------------------------------------------------------
+        fh, fw = feats0.h, feats0.w
+        HW = fh * fw
+        A, NC = self.A, self.NC
+        R = A * HW
+        cls_pl = torch.empty(B * NC * A * HW, device=self.device, dtype=torch.float32)
+        box_pl = torch.empty(B * 11 * A * HW, device=self.device, dtype=torch.float32)
+        plan.keep += [cls_pl, box_pl]
+        plan.named["cls_planar"], plan.named["box_planar"] = cls_pl, box_pl
+
+        def stacked(names, li):
+            key = "+".join(names) + li
+            if key not in P:
+                P[key] = (torch.cat([P[n + li].wp for n in names], 0).contiguous(),
+                          torch.cat([P[n + li].scale for n in names]).contiguous(),
+                          torch.cat([P[n + li].shift for n in names]).contiguous())
+            return P[key]
+
+        def heads(names, x, first_box_index):
+            """The heads `names` (consecutive rows of the planar box staging starting at first_box_index) read the same map x:
+            layer 1 as ONE GEMM Cin -> G*256, layers 2 and 3 as grouped launches."""
+            G = len(names)
+            w1, s1, t1 = stacked(names, ".0")
+            h1 = self._buf16(plan, B, fh, fw, G * 256)
+            self._conv16(plan, "+".join(names) + ".0", x, h1, wgt=w1, kpad=P[names[0] + ".0"].kpad, cout=G * 256, cout_pad=G * 256,
+                         scale=s1, shift=t1, act=1)
+            w2, s2, t2 = stacked(names, ".3")
+            h2 = self._buf16(plan, B, fh, fw, G * 256)
+            self._conv16(plan, "+".join(names) + ".3", h1, h2, wgt=w2, kpad=256, cout=256, cout_pad=256, scale=s2, shift=t2, act=1,
+                         groups=G, in_goff=256, wgt_goff=256 * 256, out_goff=256, ss_goff=256, cin=256)
+            w3, s3, t3 = stacked(names, ".6")
+            cp = P[names[0] + ".6"].cout_pad
+            self._conv16(plan, "+".join(names) + ".6", h2, None, wgt=w3, kpad=256, cout=A, cout_pad=cp, scale=s3, shift=t3,
+                         planar=(box_pl, 11 * A * HW, first_box_index * A), groups=G, in_goff=256, wgt_goff=cp * 256,
+                         out_goff=A * HW, ss_goff=A, cin=256)
+
+        # cls head: 3x3 128 -> 256, 1x1 256 -> 256, 1x1 256 -> NC*A (planar fp32)
+        c1 = self._buf16(plan, B, fh, fw, 256)
+        self._pconv(plan, "cls.0", P["cls.0"], feats0, c1, 1, 1, act=1)
+        c2 = self._buf16(plan, B, fh, fw, 256)
+        self._pconv(plan, "cls.3", P["cls.3"], c1, c2, 1, 0, act=1)
+        pc = P["cls.6"]
+        self._conv16(plan, "cls.6", c2, None, wgt=pc.wp, kpad=pc.kpad, cout=pc.cout, cout_pad=pc.cout_pad, scale=pc.scale,
+                     shift=pc.shift, planar=(cls_pl, NC * A * HW, 0), cin=256)
+        sel_idx = torch.empty(B * HW, device=self.device, dtype=torch.int32)
+        sel_prob = torch.empty(B * HW, device=self.device, dtype=torch.float32)
+        plan.keep += [sel_idx, sel_prob]
+        plan.named["sel_idx"], plan.named["sel_prob"] = sel_idx, sel_prob
+        self._op(plan, "anchor_select", "select", lambda st: _hip.check(L.m3d_anchor_select(
+            cls_pl.data_ptr(), B, A, NC, HW, sel_idx.data_ptr(), sel_prob.data_ptr(), None, st)))
+        means = np.asarray(self.conf.bbox_means, dtype=np.float32).reshape(-1)
+        stds = np.asarray(self.conf.bbox_stds, dtype=np.float32).reshape(-1)
+
+        def box_ptr(k):
+            return box_pl.data_ptr() + 4 * k * A * HW
+
+        om_sa = self._buf16(plan, B, fh, fw, 27, 28, dtype=torch.float32)
+        self._op(plan, "shape_align.offsets", "align", lambda st: _hip.check(L.m3d_align_offsets(
+            0, sel_idx.data_ptr(), sel_prob.data_ptr(), 0.5, P["shape.table"].data_ptr(), None, None, None, 0.0, 1.0, 0.0,
+            1.0, om_sa.ptr, om_sa.cs, B, A, HW, 9, 0, st)))
+        feats = self._buf16(plan, B, fh, fw, 128, name="feats")
+        self._pconv(plan, "shape_align.dcn", P["shape_align"], feats0, feats, 1, 1, act=0, res=feats0, om=om_sa)
+        heads(["bbox_x", "bbox_y"], feats, 0)
+        heads(["bbox_x3d", "bbox_y3d"], feats, 4)
+
+        def center_align(p, x, kx, ky, mi, out):
+            om = self._buf16(plan, B, fh, fw, 3, 4, dtype=torch.float32)
+            self._op(plan, p + ".offsets", "align", lambda st: _hip.check(L.m3d_align_offsets(
+                1, sel_idx.data_ptr(), sel_prob.data_ptr(), 0.5, None, box_ptr(kx), box_ptr(ky),
+                P["anchor_wh"].data_ptr(), float(means[mi]), float(stds[mi]), float(means[mi + 1]),
+                float(stds[mi + 1]), om.ptr, om.cs, B, A, HW, 1, 11 * A * HW, st)))
+            self._pconv(plan, p + ".dcn", P[p], x, out, 1, 0, act=0, res=x, om=om)
+
+        f2d = self._buf16(plan, B, fh, fw, 128, name="feats_align2d")
+        center_align("center_align2d", feats, 0, 1, 0, f2d)
+        f3d = self._buf16(plan, B, fh, fw, 128, name="feats_align3d")
+        center_align("center_align3d", feats, 4, 5, 4, f3d)
+        heads(["bbox_w", "bbox_h"], f2d, 2)
+        heads(["bbox_w3d", "bbox_h3d", "bbox_l3d", "bbox_rY3d"], f3d, 7)
+
+        gl = self._buf16(plan, B, fh, fw, 128, name="feats_gl")
+        self._anab_bf16(plan, f3d, gl)
+        heads(["bbox_z3d"], gl, 6)
+
+        cls = torch.empty(B, R, NC, device=self.device, dtype=torch.float32)
+        prob = torch.empty(B, R, NC, device=self.device, dtype=torch.float32)
+        b2 = torch.empty(B, R, 4, device=self.device, dtype=torch.float32)
+        b3 = torch.empty(B, R, 7, device=self.device, dtype=torch.float32)
+        key = torch.empty(B, R, device=self.device, dtype=torch.int32)
+        plan.named.update(cls=cls, prob=prob, bbox_2d=b2, bbox_3d=b3, score_bits=key)
+        self._op(plan, "bundle_outputs", "bundle", lambda st: _hip.check(L.m3d_bundle_outputs(
+            cls_pl.data_ptr(), box_pl.data_ptr(), cls.data_ptr(), prob.data_ptr(), b2.data_ptr(), b3.data_ptr(),
+            key.data_ptr(), B, A, HW, st)))
+        return plan
+
+    def _anab_bf16(self, plan, x, out):
+        """ANAB (attention.py:183-216) + the BN / LeakyReLU that follows it: Q as bf16, K|V|S in fp32 for the gated pyramid
+        pooling (fp32 sums over up to 7680 pixels), pooled keys / values converted to bf16 operands, logits in fp32, softmax
+        -> bf16 probabilities, P.V with the residual + BN + LeakyReLU epilogue."""
+        L, P = self.L, self.P
+        B, fh, fw = x.n, x.h, x.w
+        HW = fh * fw
+        if not (fh % 16 == 0 and fw % 16 == 0 and PSP_SIZES == (1, 4, 8, 16) and HW % 128 == 0):
+            raise RuntimeError("bf16 ANAB: the feature map (%dx%d) must be a multiple of 16 with H*W %% 128 == 0" % (fh, fw))
+        ck, cv, ns, ck_pad = self.ck, self.cv, self.ns, self.ck_pad
+        n_bins = sum(s * s for s in PSP_SIZES)
+        keys_pad = _rup(n_bins, 64)
+        q = self._buf16(plan, B, fh, fw, ck_pad, zero=True)       # channels [ck, ck_pad) are never written: they must be 0, not NaN
+        self._pconv(plan, "anab.q", P["anab.q"], x, q, 1, 0, affine=False)
+        ckvs = ck + cv + ns
+        kvs = self._buf16(plan, B, fh, fw, ckvs, _rup(ckvs, 4), dtype=torch.float32)
+        self._pconv(plan, "anab.kvs", P["anab.kvs"], x, kvs, 1, 0, sigmoid_from=ck + cv, out_mode=1, affine=False)
+        khat = torch.zeros(B * keys_pad * ck_pad, device=self.device, dtype=torch.float32)
+        vhatT = torch.zeros(B * cv * keys_pad, device=self.device, dtype=torch.float32)
+        khat16 = torch.zeros(B * keys_pad * ck_pad, device=self.device, dtype=BF16)
+        vhat16 = torch.zeros(B * cv * keys_pad, device=self.device, dtype=BF16)
+        scratch = torch.empty(L.m3d_anab_pool_nested_scratch_bytes(B, ck + cv) // 4, device=self.device, dtype=torch.float32)
+        plan.keep += [khat, vhatT, khat16, vhat16, scratch]
+        plan.named["anab.khat"], plan.named["anab.vhatT"] = khat, vhatT
+        kv_ptr, s_ptr = kvs.ptr, kvs.ptr + 4 * (ck + cv)
+        self._op(plan, "anab.pool_nested", "anab_pool", lambda st: _hip.check(L.m3d_anab_pool_nested(
+            kv_ptr, kvs.cs, s_ptr, kvs.cs, B, fh, fw, ck, cv, scratch.data_ptr(), khat.data_ptr(), keys_pad, ck_pad,
+            vhatT.data_ptr(), 0, st)))
+        self._op(plan, "anab.khat_bf16", "convert", lambda st: _hip.check(L.m3d_f32_to_bf16(
+            khat.data_ptr(), khat16.data_ptr(), khat.numel(), st)))
+        self._op(plan, "anab.vhat_bf16", "convert", lambda st: _hip.check(L.m3d_f32_to_bf16(
+            vhatT.data_ptr(), vhat16.data_ptr(), vhatT.numel(), st)))
+        logits = self._buf16(plan, B, fh, fw, n_bins, keys_pad, dtype=torch.float32)
+        self._conv16(plan, "anab.logits", q, logits, wgt=khat16, kpad=ck_pad, cout=n_bins, cout_pad=keys_pad, out_mode=1,
+                     wgt_img_stride=keys_pad * ck_pad, cin=ck_pad, flops_cin=ck)
+        pm = self._buf16(plan, B, fh, fw, keys_pad)
+        self._op(plan, "anab.softmax", "softmax_bf16", lambda st: _hip.check(L.m3d_softmax_rows_bf16(
+            logits.ptr, B * HW, n_bins, keys_pad, pm.ptr, keys_pad, st)))
+        self._conv16(plan, "anab.pv", pm, out, wgt=vhat16, kpad=keys_pad, cout=cv, cout_pad=_rup(cv, 32), scale=P["anab.bn.scale"],
+                     shift=P["anab.bn.shift"], act=1, res=x, res_mode=1, wgt_img_stride=cv * keys_pad, cin=keys_pad,
+                     flops_cin=n_bins)

@@ -66,10 +66,16 @@ class RPN(nn.Module):
         self._conf = conf
         self._engine = None
         self._engine_version = None
+        self.compute_dtype = str(conf.compute_dtype) if "compute_dtype" in conf else "f32"
 
     # -- engine management: (re)pack parameters whenever they change ------------------------------
     def _param_version(self):
-        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        return (self.compute_dtype,) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def set_compute_dtype(self, dtype):
+        """'f32' (default: the reference's arithmetic) or 'bf16' (bf16 storage / MFMA, fp32 accumulation; see engine_bf16.py)."""
+        self.compute_dtype = str(dtype)
+        return self
 
     def engine(self):
         ver = self._param_version()
@@ -78,7 +84,13 @@ class RPN(nn.Module):
             if dev.type != "cuda":
                 raise NotImplementedError("RPN.forward runs on a ROCm device only; move the module with .to('cuda') "
                                           "(the reference's DCNv2 has no CPU path either, dcn_v2_func.py:23-24)")
-            self._engine = Engine(self.state_dict(), self._conf, device=dev)
+            if self.compute_dtype == "bf16":      # BASELINE.json configs[2]: bf16 storage + bf16 MFMA, fp32 accumulation
+                from ..engine_bf16 import EngineBF16
+                self._engine = EngineBF16(self.state_dict(), self._conf, device=dev)
+            elif self.compute_dtype in ("f32", "fp32", "float32"):
+                self._engine = Engine(self.state_dict(), self._conf, device=dev)
+            else:
+                raise ValueError("compute_dtype must be 'f32' or 'bf16' (got %r)" % (self.compute_dtype,))
             self._engine_version = ver
         return self._engine
 

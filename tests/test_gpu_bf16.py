@@ -1,0 +1,429 @@
+"""GPU tests of the bf16 path (BASELINE.json configs[2]: bs = 64, bf16 storage, v_mfma_f32_32x32x16_bf16, fp32 accumulation).
+
+Kernel level: ``m3d_conv_bf16_forward`` against torch fp32 convolutions / the CPU DCNv2 oracle evaluated on the SAME
+bf16-rounded inputs and weights (products of bf16 numbers are exact in fp32, so only the accumulation order and the final
+rounding differ): fp32 output modes to 2e-4 relative, bf16 outputs to one bf16 ulp of the result (2^-8 relative).
+Network level: the bf16 engine against the fp32 CPU oracle with the engine's discrete decisions injected; the tolerance the
+bf16 path meets is measured, logged and asserted (`BF16_BBOX3D_TOL`), next to the 1e-3 of the fp32 path.
+"""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from m3dssd_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BF16 = torch.bfloat16
+# what the bf16 path meets against the fp32 oracle (max abs over every row and all 7 box parameters), see DESIGN.md
+BF16_BBOX3D_TOL = 0.25
+BF16_PROB_TOL = 0.05
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _log(name, payload):
+    d = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "parity_r02.jsonl"), "a") as f:
+            f.write(json.dumps({"test": name, **payload}) + "\n")
+
+
+def _st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _r(t):
+    """Round to bf16 and back: the value the kernel sees."""
+    return t.to(BF16).float()
+
+
+def _nhwc16(x, cs=None):
+    """[N,C,H,W] fp32 -> bf16 NHWC device tensor with pixel stride cs (extra channels filled with a sentinel)."""
+    n, c, h, w = x.shape
+    cs = c if cs is None else cs
+    t = torch.full((n, h, w, cs), 777.0, dtype=BF16)
+    t[..., :c] = x.permute(0, 2, 3, 1).to(BF16)
+    return t.contiguous().to(_dev())
+
+
+def _run_conv(x, wt, bias=None, bn=None, stride=1, pad=0, act=0, res=None, res_mode=0, sigmoid_from=-1, out_mode=0, om=None,
+              in_cs=None):
+    """Through the C ABI.  Returns [N, Cout, Ho, Wo] fp32 (bf16 outputs widened)."""
+    from m3dssd_amd import _hip
+    from m3dssd_amd.engine_bf16 import pack_conv_bf16
+    L = _hip.lib()
+    dev = _dev()
+    n, c, h, w = x.shape
+    co, _, kh, kw = wt.shape
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+    xin = _nhwc16(x, in_cs)
+    wp, kpad = pack_conv_bf16(wt, None, None, dev)
+    d = _hip.ConvBf16Desc()
+    d.inp, d.in_cs, d.N, d.H, d.W, d.Cin = xin.data_ptr(), xin.shape[3], n, h, w, c
+    d.wgt, d.Cout, d.Cout_pad, d.Kpad = wp.data_ptr(), co, wp.shape[0], kpad
+    d.kh, d.kw, d.stride, d.pad, d.Ho, d.Wo = kh, kw, stride, pad, ho, wo
+    keep = [xin, wp]
+    scale = torch.ones(co)
+    shift = torch.zeros(co) if bias is None else bias.clone()
+    if bn is not None:
+        g, b, m, v = bn
+        s = g / torch.sqrt(v + 1e-5)
+        shift = (shift - m) * s + b
+        scale = s
+    if bias is not None or bn is not None:
+        sc, sh = scale.to(dev).contiguous(), shift.to(dev).contiguous()
+        d.scale, d.shift = sc.data_ptr(), sh.data_ptr()
+        keep += [sc, sh]
+    if res is not None:
+        r = _nhwc16(res)
+        d.res, d.res_cs, d.res_mode = r.data_ptr(), r.shape[3], res_mode
+        keep.append(r)
+    d.act, d.sigmoid_from, d.groups = act, sigmoid_from, 1
+    if om is not None:
+        o = om.to(dev).contiguous()
+        d.dcn_offmask, d.dcn_om_cs = o.data_ptr(), o.shape[-1]
+        keep.append(o)
+    if out_mode == 0:
+        ocs = (co + 7) // 8 * 8 + 8
+        out = torch.full((n, ho, wo, ocs), 555.0, device=dev, dtype=BF16)
+        d.out, d.out_cs = out.data_ptr(), ocs
+    elif out_mode == 1:
+        ocs = (co + 3) // 4 * 4 + 4
+        out = torch.full((n, ho, wo, ocs), 555.0, device=dev, dtype=torch.float32)
+        d.out, d.out_cs = out.data_ptr(), ocs
+    else:
+        out = torch.full((n, co + 1, ho * wo), 555.0, device=dev, dtype=torch.float32)
+        d.out, d.out_img_stride = out.data_ptr(), (co + 1) * ho * wo
+    d.out_mode = out_mode
+    _hip.check(L.m3d_conv_bf16_forward(ctypes.byref(d), _st()))
+    torch.cuda.synchronize()
+    if out_mode == 2:
+        assert (out[:, co] == 555.0).all()                     # the channel past Cout is untouched
+        return out[:, :co].view(n, co, ho, wo).cpu()
+    assert (out[..., co:].float() == 555.0).all()              # nothing is written past Cout
+    return out[..., :co].float().permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def _check(got, ref, out_mode):
+    scale = ref.abs().max().item() + 1e-6
+    if out_mode == 0:        # one bf16 rounding of the result (+ fp32 accumulation noise)
+        tol = 2.0 ** -8 * ref.abs() + 1e-3 * scale
+    else:
+        tol = 2e-4 * ref.abs() + 2e-4 * scale
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), ((got - ref).abs().max().item(), scale, int(bad.sum()))
+
+
+CONV_CASES = [
+    # n, c, h, w, co, k, stride, pad, act, res, sigmoid_from, out_mode
+    (2, 16, 24, 40, 16, 3, 1, 1, 1, False, -1, 0),        # level0: Cin 16, K = 144 -> 192 (zero-padded K), Cout 16 < 32
+    (2, 16, 24, 40, 32, 3, 2, 1, 1, False, -1, 0),        # level1: stride 2
+    (1, 32, 17, 23, 64, 3, 2, 1, 1, False, -1, 0),        # odd sizes, M tail
+    (2, 64, 12, 20, 64, 3, 1, 1, 1, True, -1, 0),         # residual block conv2
+    (1, 128, 16, 40, 128, 3, 1, 1, 1, True, -1, 0),
+    (1, 448, 12, 20, 128, 1, 1, 0, 1, False, -1, 0),      # tree root: Cin not a power of two (1x1)
+    (1, 256, 6, 10, 512, 3, 2, 1, 1, False, -1, 0),
+    (2, 128, 16, 40, 27, 3, 1, 1, 0, False, 18, 1),       # offset / mask conv: fp32 NHWC out, sigmoid on the mask channels
+    (2, 256, 8, 20, 144, 1, 1, 0, 0, False, -1, 2),       # cls.6: planar fp32 out, Cout_pad 192
+    (1, 256, 8, 20, 36, 1, 1, 0, 0, False, -1, 2),
+    (1, 128, 16, 40, 300, 1, 1, 0, 0, False, 296, 1),     # ANAB K|V|S conv: Cout 300 (pad 320), fp32 out
+    (1, 128, 16, 40, 168, 1, 1, 0, 0, False, -1, 0),      # ANAB Q conv: Cout 168, partial last 8-channel store
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_bf16_matches_torch(case):
+    n, c, h, w, co, k, stride, pad, act, use_res, sg, om = case
+    g = torch.Generator().manual_seed(sum(case) + 3)
+    x = _r(torch.randn(n, c, h, w, generator=g))
+    wt = _r(torch.randn(co, c, k, k, generator=g) / (c * k * k) ** 0.5)
+    bias = torch.randn(co, generator=g) * 0.1
+    bn = (torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.1, torch.randn(co, generator=g) * 0.1,
+          torch.rand(co, generator=g) + 0.5)
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    res = _r(torch.randn(n, co, ho, wo, generator=g)) if use_res else None
+    ref = F.batch_norm(F.conv2d(x, wt, bias, stride=stride, padding=pad), bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)
+    if res is not None:
+        ref = ref + res
+    if sg >= 0:
+        ref = torch.cat([F.leaky_relu(ref[:, :sg], 0.01) if act else ref[:, :sg], torch.sigmoid(ref[:, sg:])], 1)
+    elif act:
+        ref = F.leaky_relu(ref, 0.01)
+    got = _run_conv(x, wt, bias, bn, stride, pad, act, res, 0, sg, om, in_cs=c + 8 if c % 16 == 0 else None)
+    assert got.shape == ref.shape
+    _check(got, ref, om)
+
+
+def test_conv_bf16_residual_before_affine_and_argument_checks():
+    """res_mode 1 (ANAB: BN after the residual add) and the C-ABI argument validation."""
+    from m3dssd_amd import _hip
+    L = _hip.lib()
+    g = torch.Generator().manual_seed(11)
+    x = _r(torch.randn(1, 64, 8, 16, generator=g))
+    wt = _r(torch.randn(128, 64, 1, 1, generator=g) / 8)
+    res = _r(torch.randn(1, 128, 8, 16, generator=g))
+    bn = (torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.1, torch.randn(128, generator=g) * 0.1,
+          torch.rand(128, generator=g) + 0.5)
+    ref = F.leaky_relu(F.batch_norm(F.conv2d(x, wt) + res, bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5), 0.01)
+    got = _run_conv(x, wt, None, bn, 1, 0, 1, res, 1)
+    _check(got, ref, 0)
+    d = _hip.ConvBf16Desc()
+    assert L.m3d_conv_bf16_forward(ctypes.byref(d), _st()) == -1            # null pointers
+    t = torch.zeros(64, device=_dev())
+    d.inp = d.wgt = d.out = t.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.in_cs, d.Cout, d.Cout_pad, d.Kpad = 1, 4, 4, 24, 24, 32, 32, 256
+    d.kh = d.kw = 3
+    d.stride, d.pad, d.Ho, d.Wo, d.groups, d.out_cs = 1, 1, 4, 4, 1, 32
+    assert L.m3d_conv_bf16_forward(ctypes.byref(d), _st()) == -1            # 3x3 with Cin = 24 (not a power of two)
+    assert b"power-of-two" in L.m3d_last_error()
+
+
+def test_conv_bf16_grouped_and_per_image_weights():
+    """groups (the RPN heads of one feature map in one launch) and per-image weights (ANAB logits / P.V GEMMs)."""
+    from m3dssd_amd import _hip
+    from m3dssd_amd.engine_bf16 import pack_conv_bf16
+    L = _hip.lib()
+    dev = _dev()
+    g = torch.Generator().manual_seed(4)
+    G, n, h, w, ci, co = 3, 2, 8, 16, 64, 36
+    x = _r(torch.randn(n, G * ci, h, w, generator=g))
+    wts = [_r(torch.randn(co, ci, 1, 1, generator=g) / 8) for _ in range(G)]
+    sc = torch.rand(G, co, generator=g) + 0.5
+    sh = torch.randn(G, co, generator=g) * 0.1
+    xin = _nhwc16(x)
+    wp = torch.cat([pack_conv_bf16(wt, 64, None, dev)[0] for wt in wts], 0).contiguous()
+    out = torch.zeros(n, G * co, h * w, device=dev)
+    d = _hip.ConvBf16Desc()
+    d.inp, d.in_cs, d.N, d.H, d.W, d.Cin = xin.data_ptr(), G * ci, n, h, w, ci
+    d.wgt, d.Cout, d.Cout_pad, d.Kpad = wp.data_ptr(), co, 64, 64
+    d.kh = d.kw = d.stride = 1
+    d.Ho, d.Wo, d.out, d.out_mode, d.out_img_stride = h, w, out.data_ptr(), 2, G * co * h * w
+    scd, shd = sc.to(dev).contiguous(), sh.to(dev).contiguous()
+    d.scale, d.shift, d.sigmoid_from = scd.data_ptr(), shd.data_ptr(), -1
+    d.groups, d.in_group_off, d.wgt_group_off, d.out_group_off, d.ss_group_off = G, ci, 64 * 64, co * h * w, co
+    _hip.check(L.m3d_conv_bf16_forward(ctypes.byref(d), _st()))
+    torch.cuda.synchronize()
+    got = out.view(n, G, co, h, w).cpu()
+    for gi in range(G):
+        ref = F.conv2d(x[:, gi * ci:(gi + 1) * ci], wts[gi]) * sc[gi].view(1, -1, 1, 1) + sh[gi].view(1, -1, 1, 1)
+        _check(got[:, gi], ref, 2)
+    # per-image weights: image b multiplies by its own [Cout][K] matrix (Ho*Wo = 128 pixels per image)
+    n, h, w, ci, co = 3, 8, 16, 192, 337
+    x = _r(torch.randn(n, ci, h, w, generator=g))
+    wimg = _r(torch.randn(n, co, ci, generator=g) / 14)
+    cop = 384
+    wp = torch.zeros(n, cop, ci, dtype=BF16)
+    wp[:, :co] = wimg.to(BF16)
+    wp = wp.to(dev).contiguous()
+    xin = _nhwc16(x)
+    out = torch.zeros(n, h, w, cop, device=dev)
+    d = _hip.ConvBf16Desc()
+    d.inp, d.in_cs, d.N, d.H, d.W, d.Cin = xin.data_ptr(), ci, n, h, w, ci
+    d.wgt, d.wgt_img_stride, d.Cout, d.Cout_pad, d.Kpad = wp.data_ptr(), cop * ci, co, cop, ci
+    d.kh = d.kw = d.stride = 1
+    d.Ho, d.Wo, d.out, d.out_cs, d.out_mode, d.groups, d.sigmoid_from = h, w, out.data_ptr(), cop, 1, 1, -1
+    _hip.check(L.m3d_conv_bf16_forward(ctypes.byref(d), _st()))
+    torch.cuda.synchronize()
+    got = out[..., :co].permute(0, 3, 1, 2).cpu()
+    ref = torch.einsum("nok,nkhw->nohw", wimg, x)
+    _check(got, ref, 1)
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 16, 40, 128, 3, 1), (1, 256, 8, 20, 128, 3, 1), (1, 512, 6, 10, 256, 3, 1),
+                                   (2, 128, 16, 40, 128, 1, 0), (1, 64, 9, 13, 64, 3, 1)])
+def test_dcn_bf16_matches_oracle(shape):
+    """Deformable mode against oracle/dcn.py on the bf16-rounded input / weights; offsets and masks are fp32 in both.  The
+    kernel rounds the modulated bilinear sample to bf16 before the GEMM (one extra 2^-9 relative rounding per sample), so the
+    bound is sqrt(K)-scaled bf16 noise: 1% of the output scale."""
+    from oracle import dcn as odcn
+    n, c, h, w, co, k, pad = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = _r(torch.randn(n, c, h, w, generator=g))
+    wt = _r(torch.randn(co, c, k, k, generator=g) / (c * k * k) ** 0.5)
+    b = torch.randn(co, generator=g) * 0.1
+    off = torch.randn(n, 2 * k * k, h, w, generator=g) * 3.0
+    off[0, 0, 0, 0] = -1.0 + pad
+    m = torch.rand(n, k * k, h, w, generator=g)
+    ref = odcn.dcn_v2_forward(x, off, m, wt, b, 1, pad, 1, 1)
+    om = torch.cat([off, m], 1).permute(0, 2, 3, 1).contiguous()            # NHWC [.., 3*k*k]
+    om = torch.cat([om, torch.zeros(n, h, w, (-om.shape[-1]) % 4)], -1).contiguous()
+    got = _run_conv(x, wt, b, None, 1, pad, 0, None, 0, -1, 0, om)
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item()
+    _log("dcn_bf16", dict(shape=list(shape), err=err, scale=scale))
+    assert err < 1e-2 * scale + 2.0 ** -8 * scale
+    # fp32 output mode isolates the sample rounding from the output rounding
+    got32 = _run_conv(x, wt, b, None, 1, pad, 0, None, 0, -1, 1, om)
+    assert (got32 - ref).abs().max().item() < 1e-2 * scale
+
+
+def test_bf16_helpers_match_torch():
+    from m3dssd_amd import _hip
+    L = _hip.lib()
+    dev = _dev()
+    g = torch.Generator().manual_seed(8)
+    # maxpool (exact) on a channel-sliced view
+    x = _r(torch.randn(2, 32, 8, 12, generator=g))
+    xin = _nhwc16(x, 48)
+    out = torch.zeros(2, 4, 6, 40, device=dev, dtype=BF16)
+    _hip.check(L.m3d_maxpool2x2_bf16(xin.data_ptr(), 48, out.data_ptr(), 40, 2, 8, 12, 32, _st()))
+    assert torch.equal(out[..., :32].float().permute(0, 3, 1, 2).cpu(), F.max_pool2d(x, 2, 2))
+    assert (out[..., 32:] == 0).all()
+    # depthwise ConvTranspose2d(4, 2, 1) + skip
+    c = 16
+    x = _r(torch.randn(2, c, 5, 7, generator=g))
+    wt = torch.rand(c, 1, 4, 4, generator=g)
+    skip = _r(torch.randn(2, c, 10, 14, generator=g))
+    ref = F.conv_transpose2d(x, wt, None, stride=2, padding=1, groups=c) + skip
+    xin, sk = _nhwc16(x), _nhwc16(skip)
+    wd = wt[:, 0].permute(1, 2, 0).contiguous().to(dev)
+    out = torch.zeros(2, 10, 14, c, device=dev, dtype=BF16)
+    _hip.check(L.m3d_upsample2x_add_bf16(xin.data_ptr(), c, wd.data_ptr(), sk.data_ptr(), c, out.data_ptr(), c, 2, 5, 7, c, _st()))
+    got = out.float().permute(0, 3, 1, 2).cpu()
+    assert ((got - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-6).all()
+    # fp32 -> bf16 (round to nearest even, like torch)
+    v = torch.randn(4096, generator=g) * 100
+    o = torch.zeros(4096, device=dev, dtype=BF16)
+    vd = v.to(dev)
+    _hip.check(L.m3d_f32_to_bf16(vd.data_ptr(), o.data_ptr(), 4096, _st()))
+    assert torch.equal(o.cpu(), v.to(BF16))
+    # softmax rows -> bf16
+    lg = torch.randn(50, 384, generator=g) * 3
+    p = torch.full((50, 384), 9.0, device=dev, dtype=BF16)
+    ld = lg.to(dev)
+    _hip.check(L.m3d_softmax_rows_bf16(ld.data_ptr(), 50, 337, 384, p.data_ptr(), 384, _st()))
+    ref = torch.softmax(lg[:, :337], -1)
+    got = p.float().cpu()
+    assert ((got[:, :337] - ref).abs() <= 2.0 ** -8 * ref + 1e-7).all() and (got[:, 337:] == 0).all()
+    # stem: fp32 image and uint8 frames (Preprocess fused) against the fp32 stem on the same input
+    w7 = torch.randn(16, 3, 7, 7, generator=g) / 12
+    sc, sh = torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.1
+    img = torch.randn(2, 3, 16, 64, generator=g)
+    ref = F.leaky_relu(F.conv2d(img, w7, None, padding=3) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), 0.01)
+    wd = w7.permute(2, 3, 1, 0).contiguous().to(dev)
+    out = torch.zeros(2, 16, 64, 16, device=dev, dtype=BF16)
+    imd, scd, shd = img.to(dev), sc.to(dev), sh.to(dev)
+    _hip.check(L.m3d_stem_conv7x7_bf16(imd.data_ptr(), 0, 0, 0, None, None, wd.data_ptr(), scd.data_ptr(), shd.data_ptr(),
+                                       out.data_ptr(), 16, 2, 16, 64, _st()))
+    got = out.float().permute(0, 3, 1, 2).cpu()
+    assert ((got - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-4).all()
+    from oracle import preprocess as opre
+    frames = torch.randint(0, 256, (2, 12, 50, 3), generator=g, dtype=torch.uint8)
+    conf = synth.synth_conf((16, 64), 0, batch_size=2, device="cpu")
+    mean_np, stds_np = np.asarray(conf.image_means, dtype=np.float32), np.asarray(conf.image_stds, dtype=np.float32)
+    pre = torch.from_numpy(np.stack([opre.preprocess(f.numpy(), (16, 64), mean_np, stds_np) for f in frames]))
+    ref = F.leaky_relu(F.conv2d(pre, w7, None, padding=3) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), 0.01)
+    mean3 = (ctypes.c_float * 3)(*[float(v) for v in conf.image_means])
+    stds3 = (ctypes.c_float * 3)(*[float(v) for v in conf.image_stds])
+    fd = frames.to(dev)
+    _hip.check(L.m3d_stem_conv7x7_bf16(fd.data_ptr(), 1, 12, 50, mean3, stds3, wd.data_ptr(), scd.data_ptr(), shd.data_ptr(),
+                                       out.data_ptr(), 16, 2, 16, 64, _st()))
+    got = out.float().permute(0, 3, 1, 2).cpu()
+    assert ((got - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-4).all()
+
+
+# ------------------------------------------------------------------------------------ whole network
+def _net(crop, B, dtype):
+    from model.M3d_inference_align import build
+    conf = synth.synth_conf(crop, 0, batch_size=B, device="cuda:0")
+    net = build(conf, "test")
+    net.load_state_dict(synth.synth_state_dict(0), strict=True)
+    return net.to(_dev()).set_compute_dtype(dtype), conf
+
+
+@pytest.mark.parametrize("crop,B,pad", [((128, 320), 2, False), ((384, 1280), 2, True)])
+def test_bf16_network_matches_fp32_oracle_within_stated_tolerance(crop, B, pad):
+    """bf16 engine vs the fp32 CPU oracle, the engine's discrete decisions (top-1 anchor, hard mask) injected into the
+    oracle.  Reports the L-inf of every output and of the stage taps; asserts the stated bf16 tolerance."""
+    from oracle import model_cpu
+    net, conf = _net(crop, B, "bf16")
+    sd = synth.synth_state_dict(0)
+    x = synth.synth_frames(B, crop, 1234, pad_right_third=pad)
+    with torch.no_grad():
+        cls, prob, b2, b3 = (t.cpu() for t in net(x.to(_dev()))[:4])
+    eng = net.engine()
+    assert type(eng).__name__ == "EngineBF16"
+    plan = eng.plan_for(B, *crop)
+    assert all(not k[1].startswith(("igemm", "wino", "conv_wave", "head_mlp")) for k in plan.ops), "fp32 MFMA kernel in the bf16 plan"
+    fh, fw = crop[0] // 8, crop[1] // 8
+    ind = plan.named["sel_idx"].view(B, 1, fh, fw).long().cpu()
+    prob_sel = plan.named["sel_prob"].view(B, 1, fh, fw).cpu()
+    cconf = synth.synth_conf(crop, 0, batch_size=B, device="cpu")
+    taps, taps_free = {}, {}
+    with torch.no_grad():
+        free = model_cpu.rpn_forward(sd, cconf, x, taps_free)
+        inj = model_cpu.rpn_forward(sd, cconf, x, taps, inject={"sel": {"ind": ind, "hard": (prob_sel > 0.5).float()}})
+    fg = taps_free["fg_prob"]
+    o_mask, o_ind = fg.max(dim=1, keepdim=True)
+    n_idx, n_flip = int((o_ind != ind).sum()), int(((o_mask > 0.5) != (prob_sel > 0.5)).sum())
+    rep = {"crop": list(crop), "B": B, "n_idx": n_idx, "n_flip": n_flip, "pixels": int(ind.numel())}
+    for name in ("level2", "level5", "feats0", "feats", "feats_align2d", "feats_align3d", "feats_gl"):
+        got = plan.named[name].torch_nchw().cpu()
+        ref = (taps_free if name in ("level2", "level5", "feats0") else taps)[name]
+        rep["rel_" + name] = ((got - ref).abs().max() / ref.abs().max()).item()
+    rep["cls"] = (cls - free[0]).abs().max().item()
+    rep["prob"] = (prob - inj[1]).abs().max().item()
+    rep["bbox_2d"] = (b2 - inj[2]).abs().max().item()
+    e3 = (b3 - inj[3]).abs()
+    rep["bbox_3d"] = e3.max().item()
+    rep["bbox_3d_cols"] = [v.item() for v in e3.view(-1, 7).max(0)[0]]
+    rep["bbox_3d_rms"] = e3.pow(2).mean().sqrt().item()
+    _log("bf16_network", rep)
+    assert torch.isfinite(b3).all() and torch.isfinite(cls).all()
+    assert rep["bbox_3d"] < BF16_BBOX3D_TOL and rep["bbox_2d"] < BF16_BBOX3D_TOL and rep["prob"] < BF16_PROB_TOL, rep
+    # the decisions differ from the fp32 oracle's only where its margins are within bf16 noise
+    diff = o_ind != ind
+    if diff.any():
+        assert ((o_mask - torch.gather(fg, 1, ind))[diff].abs() < BF16_PROB_TOL).all()
+
+
+def test_bf16_batch64_full_size_properties():
+    """BASELINE.json configs[2] at its own size: 64 frames of 1280x384.  Size-independent properties: finite outputs, run-to-run
+    bit determinism, image i of the batch == the same image in a batch of 2 (bf16 kernels are batch-invariant: same tiles,
+    same accumulation order), detections produced for every image."""
+    from lib.rpn_util import detect_batch
+    net, conf = _net((384, 1280), 64, "bf16")
+    dev = _dev()
+    x = synth.synth_frames(64, (384, 1280), 7).to(dev)
+    with torch.no_grad():
+        a = [t.clone() for t in net(x)[:4]]
+        b = [t.clone() for t in net(x)[:4]]
+        two = [t.clone() for t in net(x[40:42])[:4]]
+        dets, counts = (t.clone() for t in detect_batch(net, x, conf))
+    for u, v in zip(a, b):
+        assert torch.isfinite(u).all() and torch.equal(u, v)
+    for name, u, s_ in zip(("cls", "prob", "bbox_2d", "bbox_3d"), a, two):
+        assert torch.equal(u[40:42], s_), name
+    assert dets.shape == (64, conf.nms_topN_post, 14) and torch.isfinite(dets).all()
+    assert (counts > 0).all()
+
+
+def test_bf16_and_fp32_engines_agree_on_detections():
+    """End to end at 1280x384: the bf16 path keeps (almost all of) the fp32 path's detections -- same anchors after NMS for the
+    overwhelming majority of rows, boxes within the stated tolerance (decoded pixels / metres)."""
+    from lib.rpn_util import detect_batch
+    dev = _dev()
+    x = synth.synth_frames(4, (384, 1280), 55).to(dev)
+    out = {}
+    for dt in ("f32", "bf16"):
+        net, conf = _net((384, 1280), 4, dt)
+        d, c = detect_batch(net, x, conf)
+        out[dt] = (d.clone().cpu(), c.clone().cpu())
+    (d32, c32), (d16, c16) = out["f32"], out["bf16"]
+    common, total = 0, 0
+    for i in range(4):
+        a32 = set(zip(d32[i, :c32[i], 13].tolist(), d32[i, :c32[i], 0].round().tolist()))
+        a16 = set(zip(d16[i, :c16[i], 13].tolist(), d16[i, :c16[i], 0].round().tolist()))
+        common += len(a32 & a16)
+        total += max(len(a32), 1)
+    _log("bf16_vs_fp32_detections", dict(common=common, total=total, counts32=c32.tolist(), counts16=c16.tolist()))
+    assert common >= 0.5 * total
