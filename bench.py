@@ -30,6 +30,8 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD, 256 CUs, 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16), measured 2495
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming copy)
 CROP = (384, 1280)
 PER_GPU_BATCH = 8
 
@@ -83,6 +85,9 @@ def cpu_baseline(sd, budget_s=10.0):
 def kernel_symbol(label):
     """engine label -> demangled kernel name as rocprofv3 prints it."""
     import re
+    if label.startswith("bf16_conv"):
+        return "void bf16_conv_kernel<%s, %s>(Bf16Args)" % (re.findall(r"\d+", label.split("<", 1)[1])[0],
+                                                            "true" if "deform" in label else "false")
     if label.startswith("wino_wave"):
         return "void wino_wave_kernel<%s>(WinoArgs)" % ("true" if "splitk" in label else "false")
     if label.startswith("wino"):
@@ -121,6 +126,17 @@ def algorithmic_bytes(op):
     d = op[4]
     if d is None:
         return None
+    if hasattr(d, "Kpad"):                                # m3d_conv_bf16_desc: bf16 in / weights, bf16 or fp32 out
+        g = max(d.groups, 1)
+        o = d.N * d.Ho * d.Wo * d.Cout * (2 if d.out_mode == 0 else 4) * g
+        b = d.N * d.H * d.W * d.Cin * 2 * (g if d.in_group_off else 1) + o + d.Cout * d.kh * d.kw * d.Cin * 2 * g
+        if d.wgt_img_stride:
+            b += (d.N - 1) * d.Cout * d.Cin * 2
+        if d.res:
+            b += d.N * d.Ho * d.Wo * d.Cout * 2
+        if d.dcn_offmask:
+            b += d.N * d.Ho * d.Wo * 3 * d.kh * d.kw * 4
+        return b
     if hasattr(d, "Ho"):                                  # m3d_conv_desc
         o = d.N * d.Ho * d.Wo * d.Cout * 4
         b = d.N * d.H * d.W * d.Cin * 4 + o + (o if d.res else 0) + d.Cout * d.kh * d.kw * d.Cin * 4
@@ -142,7 +158,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 8 for f32, 64 for bf16)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 = BASELINE.json configs[1] (the headline metric); bf16 = configs[2] (bs=64, bf16 storage / MFMA)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-layers", default=None, help="write the per-launch table of one instrumented step here")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
@@ -176,13 +194,14 @@ def main():
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    B = args.batch
+    bf16 = args.dtype == "bf16"
+    B = args.batch if args.batch is not None else (64 if bf16 else PER_GPU_BATCH)
 
     conf = synth.synth_conf(CROP, 0, batch_size=B, device=str(dev))
     sd = synth.synth_state_dict(0)
     net = build(conf, "test")
     net.load_state_dict(sd, strict=True)
-    net = net.to(dev)
+    net = net.to(dev).set_compute_dtype(args.dtype)
     x = synth.synth_frames(B, CROP, 1234 + rank).to(dev)          # inputs resident in HBM before the timed region
     eng = net.engine()
 
@@ -211,7 +230,7 @@ def main():
         a[1] += flops
         a[2] += 1
     # MFMA-bound kernel families (everything else is a small HBM/latency-bound helper)
-    igemm = {k: v for k, v in per_kind.items() if k.startswith(("igemm", "wino", "head_mlp", "conv_wave"))}
+    igemm = {k: v for k, v in per_kind.items() if k.startswith(("igemm", "wino", "head_mlp", "conv_wave", "bf16_conv"))}
     dominant = max(igemm, key=lambda k: igemm[k][0])
     gpu_ms_all = sum(v[0] for v in per_kind.values())
     breakdown = {k: round(v[0], 3) for k, v in sorted(per_kind.items(), key=lambda kv: -kv[1][0])}
@@ -303,14 +322,16 @@ def main():
             a[0] += ab
             a[1] += 1
     alg_bytes = int(alg[dominant][0] / alg[dominant][1]) if dominant in alg else None
+    peak_tf = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
     families = {}
     for k, (ms, fl, cnt) in sorted(igemm.items(), key=lambda kv: -kv[1][0]):
         div = 2.25 if k.startswith("wino") else 1.0
         tf = fl / (ms * 1e-3) / 1e12 / div if ms > 0 else 0.0
         tr, src = pmc_traffic(k)
         families[k] = {"kernel": kernel_symbol(k), "launches_per_step": cnt, "ms_per_step": round(ms, 3),
-                       "executed_tflops": round(tf, 1), "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 3),
+                       "executed_tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / peak_tf, 3),
                        "algorithmic_bytes_per_launch": int(alg[k][0] / alg[k][1]) if k in alg else None,
+                       "algorithmic_gbs": round(alg[k][0] / (ms * 1e-3) / 1e9, 1) if (k in alg and ms > 0) else None,
                        "traffic": tr, "traffic_source": src}
 
     if rank == 0:
@@ -318,13 +339,15 @@ def main():
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         wino_div = 2.25 if dominant.startswith("wino") else 1.0
         out = {
-            "metric": "images/sec at 1280x384 bs=8, 1/2/4/8 MI355X; 3D-box Linf vs ref",
+            "metric": ("images/sec at 1280x384 bs=8, 1/2/4/8 MI355X; 3D-box Linf vs ref" if not bf16 else
+                       "images/sec at 1280x384 bs=64 bf16 (BASELINE.json configs[2]), 1/2/4/8 MI355X"),
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: full M3d_inference_align (DLA-34 + DCNv2 align + ANAB) "
-                                   "forward + decode + top-3000 + NMS, bs=%d/GPU, 1280x384, fp32, random-init "
-                                   "synthetic weights and frames" % B,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[%d]: full M3d_inference_align (DLA-34 + DCNv2 align + ANAB) "
+                                   "forward + decode + top-3000 + NMS, bs=%d/GPU, 1280x384, %s, random-init "
+                                   "synthetic weights and frames" % (2 if bf16 else 1, B, "bf16 storage + bf16 MFMA, fp32 "
+                                                                     "accumulation / epilogues" if bf16 else "fp32"),
                        "per_gpu_batch": B, "global_batch": B * world, "resolution": [CROP[1], CROP[0]],
                        "parallelism": "dp%d (batch sharded, 1 all-gather of [B,40,14] detections)" % world},
             "launch": ("hipGraph replay, detect(k-1) overlapped with forward(k)" if use_pipe else
@@ -333,8 +356,8 @@ def main():
             # tile and channel pair = the direct-convolution count / 2.25), so frac is the MFMA-pipe utilisation and cannot
             # exceed 1; the direct-convolution-equivalent rate is reported next to it.
             "roofline": {"bound": "mfma", "kernel": kernel_symbol(dominant), "achieved": round(achieved / wino_div, 2),
-                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / wino_div / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "peak": peak_tf, "unit": "TFLOP/s",
+                         "frac": round(achieved / wino_div / peak_tf, 4),
                          "note": ("achieved = MFMA FLOPs executed by the Winograd F(2x2,3x3) launches (2*16*Cin*Cout per 2x2 output "
                                   "tile = direct-convolution FLOPs of SURVEY 8d / 2.25) / HIP-event time; peak = dense fp32 MFMA at "
                                   "the 2.4 GHz boost clock") if wino_div > 1 else
@@ -343,12 +366,23 @@ def main():
                          "traffic": pmc_traffic(dominant)[0], "traffic_source": pmc_traffic(dominant)[1],
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes committed under profiles/, not this run)",
                          "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": dom_n,
+                         "algorithmic_gbs": round(alg_bytes / (dom_ms / max(dom_n, 1) * 1e-3) / 1e9, 1) if alg_bytes and dom_ms > 0 else None,
+                         "hbm_frac_of_peak": round(alg_bytes / (dom_ms / max(dom_n, 1) * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if alg_bytes and dom_ms > 0 else None,
                          "avg_launch_ms": round(dom_ms / max(dom_n, 1), 4),
                          "avg_launch_gflop": round(dom_flops / max(dom_n, 1) / 1e9, 3),
                          "share_of_gpu_time": round(igemm[dominant][0] / gpu_ms_all, 3)},
             "gpu_ms_by_kernel_one_step": breakdown,
             "mfma_kernel_families": families,
         }
+        if bf16:
+            # whole-step figures against both roofs (in bf16 the network is HBM-bound unless fused)
+            step_s = dt / args.steps
+            out["step_roofline"] = {
+                "algorithmic_tflops": round(B * 105.8e9 / step_s / 1e12, 1), "mfma_frac": round(B * 105.8e9 / step_s / 1e12 / peak_tf, 4),
+                "algorithmic_gbs_bf16": round((B * (501.8e6 + 21e6 + 5.9e6) + 41.3e6) / step_s / 1e9, 1),
+                "hbm_frac": round((B * (501.8e6 + 21e6 + 5.9e6) + 41.3e6) / step_s / 1e9 / PEAK_HBM_GBS, 4),
+                "note": "SURVEY 8d algorithmic work per image: 105.8 GFLOP; 501.8 MB bf16 activations + 21 MB outputs + 5.9 MB input, "
+                        "weights 41.3 MB (bf16) per batch"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(out))

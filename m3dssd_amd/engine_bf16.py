@@ -348,7 +348,7 @@ class EngineBF16(Engine):
         plan.named["cls_planar"], plan.named["box_planar"] = cls_pl, box_pl
 
         def stacked(names, li):
-            key = "+".join(names) + li
+            key = "stack:" + "+".join(names) + li
             if key not in P:
                 P[key] = (torch.cat([P[n + li].wp for n in names], 0).contiguous(),
                           torch.cat([P[n + li].scale for n in names]).contiguous(),
@@ -439,8 +439,9 @@ class EngineBF16(Engine):
         L, P = self.L, self.P
         B, fh, fw = x.n, x.h, x.w
         HW = fh * fw
-        if not (fh % 16 == 0 and fw % 16 == 0 and PSP_SIZES == (1, 4, 8, 16) and HW % 128 == 0):
-            raise RuntimeError("bf16 ANAB: the feature map (%dx%d) must be a multiple of 16 with H*W %% 128 == 0" % (fh, fw))
+        if HW % 128:
+            raise RuntimeError("bf16 ANAB: H*W of the feature map (%dx%d) must be a multiple of 128 (per-image GEMM operands)" % (fh, fw))
+        nested = fh % 16 == 0 and fw % 16 == 0 and PSP_SIZES == (1, 4, 8, 16)
         ck, cv, ns, ck_pad = self.ck, self.cv, self.ns, self.ck_pad
         n_bins = sum(s * s for s in PSP_SIZES)
         keys_pad = _rup(n_bins, 64)
@@ -453,13 +454,28 @@ class EngineBF16(Engine):
         vhatT = torch.zeros(B * cv * keys_pad, device=self.device, dtype=torch.float32)
         khat16 = torch.zeros(B * keys_pad * ck_pad, device=self.device, dtype=BF16)
         vhat16 = torch.zeros(B * cv * keys_pad, device=self.device, dtype=BF16)
-        scratch = torch.empty(L.m3d_anab_pool_nested_scratch_bytes(B, ck + cv) // 4, device=self.device, dtype=torch.float32)
-        plan.keep += [khat, vhatT, khat16, vhat16, scratch]
+        plan.keep += [khat, vhatT, khat16, vhat16]
         plan.named["anab.khat"], plan.named["anab.vhatT"] = khat, vhatT
         kv_ptr, s_ptr = kvs.ptr, kvs.ptr + 4 * (ck + cv)
-        self._op(plan, "anab.pool_nested", "anab_pool", lambda st: _hip.check(L.m3d_anab_pool_nested(
-            kv_ptr, kvs.cs, s_ptr, kvs.cs, B, fh, fw, ck, cv, scratch.data_ptr(), khat.data_ptr(), keys_pad, ck_pad,
-            vhatT.data_ptr(), 0, st)))
+        if nested:      # the windows of the four scales nest (48x160 map): one pass over the features
+            scratch = torch.empty(L.m3d_anab_pool_nested_scratch_bytes(B, ck + cv) // 4, device=self.device, dtype=torch.float32)
+            plan.keep.append(scratch)
+            self._op(plan, "anab.pool_nested", "anab_pool", lambda st: _hip.check(L.m3d_anab_pool_nested(
+                kv_ptr, kvs.cs, s_ptr, kvs.cs, B, fh, fw, ck, cv, scratch.data_ptr(), khat.data_ptr(), keys_pad, ck_pad,
+                vhatT.data_ptr(), 0, st)))
+        else:
+            items, bin_scale, bin_slots, bin_inv = self._anab_items(fh, fw)
+            max_slots = int(bin_slots.max())
+            d_items, d_bscale = torch.from_numpy(items).to(self.device), torch.from_numpy(bin_scale).to(self.device)
+            d_bslots, d_binv = torch.from_numpy(bin_slots).to(self.device), torch.from_numpy(bin_inv).to(self.device)
+            partial = torch.empty(B * n_bins * max_slots * (ck + cv), device=self.device, dtype=torch.float32)
+            plan.keep += [d_items, d_bscale, d_bslots, d_binv, partial]
+            self._op(plan, "anab.pool_partial", "anab_pool", lambda st: _hip.check(L.m3d_anab_pool_partial(
+                kv_ptr, kvs.cs, s_ptr, kvs.cs, d_items.data_ptr(), items.shape[0], d_bscale.data_ptr(), n_bins,
+                partial.data_ptr(), max_slots, B, fh, fw, ck + cv, st)))
+            self._op(plan, "anab.pool_finish", "anab_pool", lambda st: _hip.check(L.m3d_anab_pool_finish(
+                partial.data_ptr(), d_bslots.data_ptr(), d_binv.data_ptr(), n_bins, max_slots, ck, cv, khat.data_ptr(),
+                keys_pad, ck_pad, vhatT.data_ptr(), B, 0, st)))
         self._op(plan, "anab.khat_bf16", "convert", lambda st: _hip.check(L.m3d_f32_to_bf16(
             khat.data_ptr(), khat16.data_ptr(), khat.numel(), st)))
         self._op(plan, "anab.vhat_bf16", "convert", lambda st: _hip.check(L.m3d_f32_to_bf16(
