@@ -360,6 +360,37 @@ int m3d_refine_3d(const float *aboxes, const int *counts, int B, int K, const do
                   double score_thresh, int hill_climbing, double step_r_init, double r_lim, double *out, m3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * KITTI AP evaluator natives (lib/eval/eval.py, lib/eval/rotate_iou.py of the reference, which compiles them
+ * with numba / numba.cuda).
+ * m3d_rotate_iou_eval: rotate_iou_gpu_eval (rotate_iou.py:264-326).  boxes [N][5], qboxes [K][5] = (cx, cy, dx, dy, angle)
+ *   float32 DEVICE pointers; iou [N][K] float32 device: entry [n][k] = devRotateIoUEval(qboxes[k], boxes[n], criterion) with
+ *   criterion -1 IoU, 0 / qbox area, 1 / box area, 2 the intersection area itself.
+ * The remaining entry points are HOST functions on float64 / int64 numpy-style arrays (synchronous, no device work):
+ * m3d_eval_image_box_overlap: image_box_overlap (eval.py:84-113), boxes [N][4], q [K][4] -> out [N][K].
+ * m3d_eval_d3_overlap: d3_box_overlap_kernel (eval.py:116-141) on boxes [N][7] / qboxes [K][7] = (x, y, z, l, h, w, ry);
+ *   rinc [N][K] holds the BEV intersection areas on entry, the 3-D overlaps on return.
+ * m3d_eval_statistics: compute_statistics_jit (eval.py:152-272) for one image.  overlaps [det][ov_stride] (detection j vs
+ *   ground truth i at [j*ov_stride + i]), gt_datas [gt][5] = bbox, alpha; dt_datas [det][6] = bbox, alpha, score;
+ *   ignored_* int64 (0 evaluate, 1 ignore, -1 other class); stats[4] = tp, fp, fn, similarity; thresholds_out (optional,
+ *   room for gt_size values) gets the scores of the true positives, *n_thresholds their number.
+ * m3d_eval_fused_statistics: fused_compute_statistics (eval.py:287-333) over a part of n_images images whose overlaps form
+ *   one [sum det][sum gt] matrix; pr [n_thresholds][4] is accumulated into (tp, fp, fn, similarity).
+ * ------------------------------------------------------------------------------------------ */
+int m3d_rotate_iou_eval(const float *boxes_dev, int N, const float *qboxes_dev, int K, int criterion, float *iou_dev,
+                        m3d_stream_t stream);
+int m3d_eval_image_box_overlap(const double *boxes, int N, const double *q, int K, int criterion, double *out);
+int m3d_eval_d3_overlap(const double *boxes, int N, const double *qboxes, int K, double *rinc, int criterion);
+int m3d_eval_statistics(const double *overlaps, long long ov_stride, const double *gt_datas, int gt_size, const double *dt_datas,
+                        int det_size, const long long *ignored_gt, const long long *ignored_det, const double *dc_bboxes, int n_dc,
+                        int metric, double min_overlap, double thresh, int compute_fp, int compute_aos, double *stats,
+                        double *thresholds_out, int *n_thresholds);
+int m3d_eval_fused_statistics(const double *overlaps, long long ov_stride, double *pr, const long long *gt_nums,
+                              const long long *dt_nums, const long long *dc_nums, int n_images, const double *gt_datas,
+                              const double *dt_datas, const double *dontcares, const long long *ignored_gts,
+                              const long long *ignored_dets, int metric, double min_overlap, const double *thresholds,
+                              int n_thresholds, int compute_aos);
+
+/* ------------------------------------------------------------------------------------------
  * Instrumentation: HIP-event timing of a launch sequence on a stream (used by bench.py).
  * ------------------------------------------------------------------------------------------ */
 int m3d_event_create(void **ev);

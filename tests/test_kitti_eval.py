@@ -1,0 +1,209 @@
+"""KITTI AP evaluator.
+
+CPU: the oracle restatement (oracle/kitti_eval.py) against the vectors the REFERENCE's own lib/eval produced
+(tests/golden/kitti_eval.npz, tools/gen_golden_eval.py), and the host natives of libm3dssd_hip.so (2-D overlaps, 3-D height
+intersection, greedy matching) against the oracle -- none of them touches the device.
+GPU: the rotated-IoU HIP kernel and the whole product evaluator / test_kitti_3d against the golden.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from oracle import kitti_eval as OK
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kitti_eval.npz")
+
+
+def _annos(tmp_path, reader):
+    g = np.load(GOLDEN)
+    for nm, texts in (("gt", g["gt_texts"]), ("dt", g["dt_texts"])):
+        os.makedirs(os.path.join(str(tmp_path), nm), exist_ok=True)
+        for i, t in enumerate(texts):
+            with open(os.path.join(str(tmp_path), nm, "%06d.txt" % i), "w") as f:
+                f.write(str(t))
+    return g, reader(os.path.join(str(tmp_path), "gt")), reader(os.path.join(str(tmp_path), "dt"))
+
+
+# ------------------------------------------------------------------------------------ oracle vs the reference's numbers
+def test_oracle_rotated_iou_and_3d_overlap_match_reference():
+    g = np.load(GOLDEN)
+    for c in (-1, 0, 1, 2):
+        assert np.abs(OK.rotate_iou_eval(g["rb"], g["qb"], c) - g["riou_%d" % (c + 1)]).max() < 5e-6, c
+    assert np.abs(OK.d3_box_overlap(g["b7"], g["q7"]) - g["d3"]).max() < 5e-6
+    # identical boxes: IoU 1 (the corner / edge coincidences that overflow the reference's scratch are handled)
+    b = np.array([[1.0, 2.0, 4.0, 2.0, 0.7]])
+    assert abs(OK.rotate_iou_eval(b, b, -1)[0, 0] - 1.0) < 1e-5
+    assert OK.rotate_iou_eval(b, b + np.array([100.0, 0, 0, 0, 0]), -1)[0, 0] == 0.0
+    assert OK.rotate_iou_eval(np.zeros((0, 5)), b).shape == (0, 1)
+
+
+def test_oracle_official_result_matches_reference(tmp_path):
+    g, gt, dt = _annos(tmp_path, OK.get_label_annos)
+    assert len(gt) == len(dt) == len(g["gt_texts"])
+    assert gt[5]["name"].shape[0] == 0 and dt[7]["bbox"].shape == (0, 4)          # the empty label / result files
+    assert dt[0]["score"].shape[0] == dt[0]["bbox"].shape[0] and gt[0]["score"].sum() == 0
+    ret = OK.eval_class(gt, dt, [0, 1, 2], [0, 1, 2], 1, np.array([[0.7, 0.5, 0.5]] * 3)[np.newaxis], compute_aos=False)
+    assert np.allclose(ret["precision"], g["bev_precision"], rtol=0, atol=1e-12, equal_nan=True)
+    assert np.allclose(ret["recall"], g["bev_recall"], rtol=0, atol=1e-12, equal_nan=True)
+    text, stats = OK.get_official_eval_result(gt, dt, [0, 1, 2])
+    assert text == str(g["result_text"])
+    for k, v in zip(g["stat_keys"], g["stat_vals"]):
+        assert abs(stats[str(k)] - v) < 1e-9, k
+
+
+def test_oracle_get_thresholds_and_filters():
+    # 10 true-positive scores, 10 valid ground truths, 41 sample points -> every score is a threshold
+    s = np.linspace(0.95, 0.05, 10)
+    assert np.allclose(OK.get_thresholds(s.copy(), 10), s)
+    assert len(OK.get_thresholds(np.linspace(1, 0, 500), 500)) == 41
+    gt = dict(name=np.array(["Car", "Van", "Pedestrian", "DontCare", "Car"]), occluded=np.array([0, 0, 0, -1, 2]),
+              truncated=np.array([0.0, 0.0, 0.0, -1.0, 0.0]), bbox=np.array([[0, 0, 50, 50], [0, 0, 50, 60], [0, 0, 20, 50],
+                                                                             [5, 5, 60, 60], [0, 0, 30, 30.0]]))
+    dt = dict(name=np.array(["Car", "Cyclist", "Car"]), bbox=np.array([[0, 0, 40, 45.0], [0, 0, 10, 60], [0, 0, 10, 20]]))
+    n, ig, idt, dc = OK.clean_data(gt, dt, 0, 0)
+    assert n == 1 and ig == [0, 1, -1, -1, 1] and idt == [0, -1, 1] and len(dc) == 1
+
+
+# ------------------------------------------------------------------------------------ host natives vs the oracle (no GPU)
+def _lib():
+    from m3dssd_amd import _hip
+    return _hip, _hip.lib()
+
+
+def _dp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def test_native_overlaps_match_oracle():
+    _hip, L = _lib()
+    rng = np.random.default_rng(3)
+    b = np.sort(rng.uniform(0, 100, (13, 2, 2)), axis=1).reshape(13, 4)[:, [0, 1, 2, 3]]
+    b = np.stack([b[:, 0], b[:, 1], b[:, 2], b[:, 3]], 1)
+    q = b[::-1][:7] + rng.normal(0, 3, (7, 4))
+    for c in (-1, 0, 1, 2):
+        out = np.zeros((13, 7))
+        _hip.check(L.m3d_eval_image_box_overlap(_dp(np.ascontiguousarray(b)), 13, _dp(np.ascontiguousarray(q)), 7, c, _dp(out)))
+        assert np.array_equal(out, OK.image_box_overlap(b, q, c)), c
+    g = np.load(GOLDEN)
+    b7, q7 = np.ascontiguousarray(g["b7"]), np.ascontiguousarray(g["q7"])
+    rinc = OK.rotate_iou_eval(b7[:, [0, 2, 3, 5, 6]], q7[:, [0, 2, 3, 5, 6]], 2).astype(np.float64)
+    r = np.ascontiguousarray(rinc)
+    _hip.check(L.m3d_eval_d3_overlap(_dp(b7), b7.shape[0], _dp(q7), q7.shape[0], _dp(r), -1))
+    assert np.abs(r - g["d3"]).max() < 5e-6
+
+
+def test_native_statistics_match_oracle(tmp_path):
+    _hip, L = _lib()
+    g, gt, dt = _annos(tmp_path, OK.get_label_annos)
+    overlaps, parted, total_dt, total_gt = OK.calculate_iou_partly(dt, gt, 0, 50)
+    for cls, diff in ((0, 0), (0, 2), (1, 1), (2, 2)):
+        gds, dds, igs, ids_, dcs, dcn, nvalid = OK._prepare_data(gt, dt, cls, diff)
+        for i in range(len(gt)):
+            for compute_fp, thresh, aos in ((False, 0.0, False), (True, 0.3, True), (True, 0.6, False)):
+                want = OK.compute_statistics(overlaps[i], gds[i], dds[i], igs[i], ids_[i], dcs[i], 0, 0.5, thresh, compute_fp, aos)
+                ov = np.ascontiguousarray(overlaps[i], dtype=np.float64)
+                st, thr, nthr = np.zeros(4), np.zeros(max(1, gds[i].shape[0])), ctypes.c_int(0)
+                gd, dd = np.ascontiguousarray(gds[i], dtype=np.float64), np.ascontiguousarray(dds[i], dtype=np.float64)
+                _hip.check(L.m3d_eval_statistics(_dp(ov), ov.shape[1] if ov.ndim == 2 and ov.size else 1, _dp(gd), gd.shape[0],
+                                                 _dp(dd), dd.shape[0], _dp(igs[i]), _dp(ids_[i]), _dp(dcs[i]), dcs[i].shape[0], 0, 0.5,
+                                                 thresh, int(compute_fp), int(aos), _dp(st), _dp(thr), ctypes.byref(nthr)))
+                assert (st[0], st[1], st[2]) == (want[0], want[1], want[2]), (cls, diff, i)
+                assert abs(st[3] - want[3]) < 1e-12
+                assert np.array_equal(thr[:nthr.value], want[4])
+
+
+# ------------------------------------------------------------------------------------ GPU: kernel + whole evaluator
+@pytest.mark.gpu
+def test_rotate_iou_kernel_matches_reference_and_oracle():
+    from lib.eval.rotate_iou import rotate_iou_gpu_eval
+    g = np.load(GOLDEN)
+    for c in (-1, 0, 1, 2):
+        got = rotate_iou_gpu_eval(g["rb"], g["qb"], c)
+        assert got.dtype == g["rb"].dtype and np.abs(got - g["riou_%d" % (c + 1)]).max() < 5e-6, c
+    rng = np.random.default_rng(5)
+    b = rng.uniform([-20, -20, 0.5, 0.5, -3.2], [20, 20, 6, 3, 3.2], (300, 5))
+    q = np.concatenate([b[:150] + rng.normal(0, 0.3, (150, 5)), rng.uniform([-20, -20, 0.5, 0.5, -3.2], [20, 20, 6, 3, 3.2], (57, 5))])
+    got = rotate_iou_gpu_eval(b, q, -1)
+    sub = OK.rotate_iou_eval(b[:40], q[:60], -1)
+    assert np.abs(got[:40, :60] - sub).max() < 5e-6
+    assert got.min() >= 0 and got.max() <= 1.0 + 1e-5 and (got > 0.3).sum() > 50
+    bb = np.array([[1.0, 2.0, 4.0, 2.0, 0.7]])
+    assert abs(rotate_iou_gpu_eval(bb, bb, -1)[0, 0] - 1.0) < 1e-5
+    assert rotate_iou_gpu_eval(np.zeros((0, 5)), bb).shape == (0, 1)
+
+
+@pytest.mark.gpu
+def test_product_evaluator_matches_reference(tmp_path):
+    from lib.eval.eval import eval_class, get_official_eval_result
+    from lib.eval.kitti_common import get_label_annos
+    g, gt, dt = _annos(tmp_path, get_label_annos)
+    o_gt = OK.get_label_annos(os.path.join(str(tmp_path), "gt"))
+    for a, b in zip(gt, o_gt):
+        for k in b:
+            assert np.array_equal(a[k], b[k]), k
+    ret = eval_class(gt, dt, [0, 1, 2], [0, 1, 2], 1, np.array([[0.7, 0.5, 0.5]] * 3)[np.newaxis], compute_aos=False)
+    assert np.allclose(ret["precision"], g["bev_precision"], rtol=0, atol=1e-9, equal_nan=True)
+    assert np.allclose(ret["recall"], g["bev_recall"], rtol=0, atol=1e-9, equal_nan=True)
+    pr = {}
+    text, stats = get_official_eval_result(gt, dt, [0, 1, 2], PR_detail_dict=pr)
+    assert text == str(g["result_text"])
+    for k, v in zip(g["stat_keys"], g["stat_vals"]):
+        assert abs(stats[str(k)] - v) < 1e-9, k
+    assert set(pr) == {"bbox", "aos", "bev", "3d"}
+    # class names instead of ids, a single class
+    t1, s1 = get_official_eval_result(gt, dt, "Car")
+    assert t1 == "".join(l + "\n" for l in text.split("\n")[:10]) and s1["Car_3d_moderate_R40"] == stats["Car_3d_moderate_R40"]
+
+
+@pytest.mark.gpu
+def test_test_kitti_3d_writes_results_and_evaluates(tmp_path):
+    """lib.rpn_util.test_kitti_3d with the reference's signature: detect (batched) -> refine on the device -> '<id>.txt'
+    (identical to the per-image reference-style path) -> AP against a label folder."""
+    import torch
+    from lib.rpn_util import im_detect_3d, test_kitti_3d
+    from m3dssd_amd import synth
+    from m3dssd_amd.config import Conf
+    from m3dssd_amd.host import refine as R
+    from model.M3d_inference_align import build
+    dev = torch.device("cuda:0")
+    crop = (128, 320)
+    conf = synth.synth_conf(crop, 0, batch_size=3, device="cuda:0")
+    conf.datasets_validation = [Conf(name="kitti_synth")]
+    conf.hill_climbing = True
+    net = build(conf, "test")
+    net.load_state_dict(synth.synth_state_dict(0))
+    net = net.to(dev)
+    p2 = np.array([[721.5377, 0.0, 609.5593, 44.85728], [0.0, 721.5377, 172.854, 0.2163791], [0.0, 0.0, 1.0, 0.002745884],
+                   [0.0, 0.0, 0.0, 1.0]])
+    frames = synth.synth_frames(7, crop, 77)
+    dataset = [(frames[i:i + 1], Conf(id="%06d" % i, p2=p2, scale_factor=1.0)) for i in range(7)]
+    label_dir = tmp_path / "kitti_synth" / "validation" / "label_2"
+    os.makedirs(label_dir)
+    # labels = the detector's own output of a first pass with alpha jittered -> a non-trivial AP
+    res_dir = tmp_path / "results" / "data"
+    text, stats = test_kitti_3d(dataset, net, conf, str(res_dir), str(tmp_path), use_log=False, phase="train")
+    assert text is None                                              # no label folder for that phase: results only
+    files = sorted(os.listdir(res_dir))
+    assert files == ["%06d.txt" % i for i in range(7)]
+    for i in (0, 3, 6):                                              # batch path == the per-image path of the reference loop
+        ab = im_detect_3d(frames[i], net, conf)
+        dets = torch.zeros(1, conf.nms_topN_post, 14, device=dev)
+        k = min(len(ab), conf.nms_topN_post)
+        dets[0, :k] = torch.from_numpy(ab[:k]).to(dev)
+        ref = R.refine_detections(dets, torch.tensor([k], dtype=torch.int32, device=dev), p2).cpu().numpy()
+        assert open(res_dir / ("%06d.txt" % i)).read() == R.kitti_text(ref[0], conf.lbls)
+    n_lines = 0
+    for f in files:
+        lines = open(res_dir / f).read().splitlines()
+        n_lines += len(lines)
+        with open(label_dir / f, "w") as out:
+            for ln in lines[::2]:                                    # every second detection becomes a ground-truth object
+                p = ln.split(" ")
+                out.write(" ".join([p[0], "0.00", "0"] + p[3:15]) + "\n")
+    assert n_lines > 0
+    text, stats = test_kitti_3d(dataset, net, conf, str(res_dir), str(tmp_path), use_log=False, phase="validation")
+    assert "Car AP@0.70, 0.70, 0.70:" in text and "Cyclist AP_R40@0.50, 0.50, 0.50:" in text
+    assert all(np.isfinite(v) or np.isnan(v) for v in stats.values()) and len(stats) >= 36
+    assert max(stats["%s_3d_easy_R40" % c] for c in conf.lbls if np.isfinite(stats["%s_3d_easy_R40" % c])) > 10.0
