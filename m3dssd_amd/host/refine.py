@@ -33,7 +33,7 @@ def refine_detections(dets, counts, p2, score_thresh=0.75, hill_climbing=True, s
         raise RuntimeError("refine_detections: p2 must be [B, 4, 4]")
     p2_inv = np.stack([np.linalg.inv(m) for m in p2])                    # the reference's np.linalg.inv (rpn_util.py:1790)
     dev = dets.device
-    d_p2 = torch.from_numpy(np.ascontiguousarray(p2)).to(dev)
+    d_p2 = torch.from_numpy(np.array(p2, dtype=np.float64, order="C")).to(dev)
     d_pi = torch.from_numpy(np.ascontiguousarray(p2_inv)).to(dev)
     dets = dets.contiguous()
     counts = counts.to(device=dev, dtype=torch.int32).contiguous()

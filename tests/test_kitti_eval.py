@@ -187,13 +187,14 @@ def test_test_kitti_3d_writes_results_and_evaluates(tmp_path):
     assert text is None                                              # no label folder for that phase: results only
     files = sorted(os.listdir(res_dir))
     assert files == ["%06d.txt" % i for i in range(7)]
-    for i in (0, 3, 6):                                              # batch path == the per-image path of the reference loop
-        ab = im_detect_3d(frames[i], net, conf)
-        dets = torch.zeros(1, conf.nms_topN_post, 14, device=dev)
-        k = min(len(ab), conf.nms_topN_post)
-        dets[0, :k] = torch.from_numpy(ab[:k]).to(dev)
-        ref = R.refine_detections(dets, torch.tensor([k], dtype=torch.int32, device=dev), p2).cpu().numpy()
-        assert open(res_dir / ("%06d.txt" % i)).read() == R.kitti_text(ref[0], conf.lbls)
+    from lib.rpn_util import detect_batch
+    for lo, hi in ((0, 3), (3, 6), (6, 7)):                          # the batches the wrapper formed (batch_size 3, 7 frames)
+        dets, counts = detect_batch(net, frames[lo:hi].to(dev), conf)
+        ref = R.refine_detections(dets.clone(), counts, np.stack([p2] * (hi - lo))).cpu().numpy()
+        for b in range(hi - lo):
+            assert open(res_dir / ("%06d.txt" % (lo + b))).read() == R.kitti_text(ref[b], conf.lbls)
+    ab = im_detect_3d(frames[6], net, conf)                          # and the reference-style single-image entry (same batch of 1)
+    assert np.array_equal(ab[:conf.nms_topN_post], detect_batch(net, frames[6:7].to(dev), conf)[0][0, :len(ab)].cpu().numpy())
     n_lines = 0
     for f in files:
         lines = open(res_dir / f).read().splitlines()
