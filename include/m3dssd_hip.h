@@ -172,6 +172,26 @@ typedef struct m3d_conv_bf16_desc {
 } m3d_conv_bf16_desc;
 int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t stream);
 
+/* Fused 3-layer RPN head of the bf16 path (model/M3d_inference_align.py:77-210): [1x1 128 -> 256, affine, LeakyReLU] ->
+ * [1x1 256 -> 256, affine, LeakyReLU] -> [1x1 256 -> Cout, affine] per 128-pixel tile in ONE launch, hidden activations in LDS.
+ * `groups` heads that read the same map share the launch: weights bf16 row-major [groups][256][128], [groups][256][256],
+ * [groups][Cout_pad = 64][256]; scale / shift fp32 [groups][256], [groups][256], [groups][Cout]; output planar fp32
+ * out[g*out_group_off + img*out_img_stride + c*HW + p]. */
+typedef struct m3d_head_bf16_desc {
+    const void *in;           /* bf16 [M][in_cs], first 128 channels used */
+    int in_cs;
+    long long M;
+    int Cin;                  /* 128 */
+    const void *w1, *w2, *w3;
+    const float *s1, *t1, *s2, *t2, *s3, *t3;
+    int Cout, Cout_pad;       /* Cout <= 64, Cout_pad == 64 */
+    float *out;
+    long long out_group_off, out_img_stride;
+    int HW;
+    int groups;
+} m3d_head_bf16_desc;
+int m3d_head_mlp_bf16_forward(const m3d_head_bf16_desc *d, m3d_stream_t stream);
+
 /* HBM-bound helpers of the bf16 path: NHWC bf16 views (pixel strides in bf16 elements, multiples of 8), fp32 arithmetic.
  * m3d_stem_conv7x7_bf16: DLA.base_layer from the fp32 [N][3][H][W] image (is_u8 = 0; img_h/img_w/mean3/stds3 ignored) or
  * from uint8 BGR frames [N][img_h][img_w][3] with the reference's test-time Preprocess fused into the loads (is_u8 = 1,
@@ -179,6 +199,15 @@ int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t stream);
 int m3d_stem_conv7x7_bf16(const void *img, int is_u8, int img_h, int img_w, const float *mean3, const float *stds3,
                           const float *wgt, const float *scale, const float *shift, void *out, int out_cs, int N, int H, int W,
                           m3d_stream_t stream);
+/* Fused front end of the bf16 path: base_layer 7x7 3->16 -> level0 3x3 16->16 -> level1 3x3/2 16->32, each + folded BN +
+ * LeakyReLU (pose_dla_dcn.py:336-345,391-397), image read once, only the level1 map [N][H/2][W/2][out_cs >= 32] bf16 written.
+ * img / is_u8 / img_h / img_w / mean3 / stds3 as in m3d_stem_conv7x7_bf16.  Weights bf16: w_stem [16][7*32] with
+ * k = i*32 + j*4 + c (tap row i, tap column j < 7, channel c < 3, other slots 0); w_l0 [16][160], w_l1 [32][160] with
+ * k = (i*3 + j)*16 + c, zero padded from 144. */
+int m3d_frontend_bf16_forward(const void *img, int is_u8, int img_h, int img_w, const float *mean3, const float *stds3,
+                              const void *w_stem, const float *s_stem, const float *t_stem, const void *w_l0, const float *s_l0,
+                              const float *t_l0, const void *w_l1, const float *s_l1, const float *t_l1, void *out, int out_cs,
+                              int N, int H, int W, m3d_stream_t stream);
 int m3d_maxpool2x2_bf16(const void *in, int in_cs, void *out, int out_cs, int N, int H, int W, int C, m3d_stream_t stream);
 int m3d_upsample2x_add_bf16(const void *in, int in_cs, const float *wgt /*[4][4][C] fp32*/, const void *skip, int skip_cs,
                             void *out, int out_cs, int N, int H, int W, int C, m3d_stream_t stream);

@@ -67,6 +67,18 @@ class ConvBf16Desc(ctypes.Structure):
     ]
 
 
+class HeadBf16Desc(ctypes.Structure):
+    """Mirror of ``m3d_head_bf16_desc``."""
+    _fields_ = [
+        ("inp", c_void_p), ("in_cs", c_int), ("M", c_ll), ("Cin", c_int),
+        ("w1", c_void_p), ("w2", c_void_p), ("w3", c_void_p),
+        ("s1", c_void_p), ("t1", c_void_p), ("s2", c_void_p), ("t2", c_void_p), ("s3", c_void_p), ("t3", c_void_p),
+        ("Cout", c_int), ("Cout_pad", c_int),
+        ("out", c_void_p), ("out_group_off", c_ll), ("out_img_stride", c_ll),
+        ("HW", c_int), ("groups", c_int),
+    ]
+
+
 P = c_void_p
 # name -> (restype, argtypes); every name here must be declared in include/m3dssd_hip.h
 SIGNATURES = {
@@ -74,8 +86,11 @@ SIGNATURES = {
     "m3d_abi_version": (c_int, []),
     "m3d_conv2d_forward": (c_int, [ctypes.POINTER(ConvDesc), P]),
     "m3d_conv_bf16_forward": (c_int, [ctypes.POINTER(ConvBf16Desc), P]),
+    "m3d_head_mlp_bf16_forward": (c_int, [ctypes.POINTER(HeadBf16Desc), P]),
     "m3d_stem_conv7x7_bf16": (c_int, [P, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                       P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "m3d_frontend_bf16_forward": (c_int, [P, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+                                  + [P] * 10 + [c_int] * 4 + [P]),
     "m3d_maxpool2x2_bf16": (c_int, [P, c_int, P, c_int] + [c_int] * 4 + [P]),
     "m3d_upsample2x_add_bf16": (c_int, [P, c_int, P, P, c_int, P, c_int] + [c_int] * 4 + [P]),
     "m3d_f32_to_bf16": (c_int, [P, P, c_ll, P]),

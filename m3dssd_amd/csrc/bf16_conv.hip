@@ -39,6 +39,7 @@ struct Bf16Args {
     int out_mode;              // 0 bf16 NHWC, 1 fp32 NHWC, 2 fp32 planar [img][c][HoWo]
     int res_mode, act, sigmoid_from;
     int tiles_m, tiles_n;
+    int uniform_k;             // Cin % 64 == 0 (or 1x1 with K % 64 == 0): every K-step lies in one tap, channel offset is wave-uniform
 };
 
 __device__ __forceinline__ u32x4 buf_load_u32x4(__amdgpu_buffer_rsrc_t r, unsigned voffset, unsigned soffset)
@@ -113,32 +114,62 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const Bf16Args a)
         woff[p] = ((unsigned)min(n0 + p * 32 + rsub, a.Cout_pad - 1) * (unsigned)(a.KT * BK) + (unsigned)chunk * 8u) * 2u;
 
     u32x4 rp[4][DEFORM ? 4 : 1];
+    unsigned poff[4] = {0u, 0u, 0u, 0u};
     u32x4 rw[PB];
     float bw[DEFORM ? 4 : 1][4];
     unsigned doff[DEFORM ? 4 : 1][4];
     int samp_tap = -1;
 
     auto load_tile = [&](int kt) {
-        const int k0 = kt * BK + chunk * 8;
-        int tap, c;
-        if (a.kh * a.kw == 1) { tap = 0; c = k0; }
-        else { tap = k0 >> a.log2Cin; c = k0 & (a.Cin - 1); }
-        const bool kvalid = k0 < a.K;
-        const int ti = a.kw == 1 ? tap : (a.kw == 3 ? (tap * 11) >> 5 : tap / a.kw);
-        const int tj = tap - ti * a.kw;
+        // Fast path (Cin % 64 == 0): the whole K-step lies in ONE tap and the channel offset is wave-uniform -> it rides in the
+        // SGPR offset of the buffer loads; per-lane byte offsets / sampling state change only when the tap does (every Cin/64
+        // K-steps).  A VALU instruction issued next to a SIMD's MFMA stream costs that stream ~12 cycles on this part
+        // (tools/ubench/mfma_side_cost.hip): address math must not run per K-step.
+        const int kb = kt * BK;
+        const bool uni = a.uniform_k != 0;
+        int tap, c;                      // uniform path: scalars; general path: per lane (a K-step may span several taps)
+        {
+            const int k0 = uni ? kb : kb + chunk * 8;
+            if (a.kh * a.kw == 1) { tap = 0; c = k0; }
+            else { tap = k0 >> a.log2Cin; c = k0 & (a.Cin - 1); }
+        }
+        const bool kvalid = uni || (kb + chunk * 8 < a.K);
+        const bool fresh = tap != samp_tap;
+        int ti = 0, tj = 0;
+        if (!uni || fresh) {
+            ti = a.kw == 1 ? tap : (a.kw == 3 ? (tap * 11) >> 5 : tap / a.kw);
+            tj = tap - ti * a.kw;
+        }
         if constexpr (!DEFORM) {
+            if (uni) {
+                if (fresh) {
+                    samp_tap = tap;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int hi = hi0[p] + ti, wi = wi0[p] + tj;
-                const bool ok = kvalid && rvalid[p] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-                const unsigned off = ok ? ((unsigned)(pix_base[p] + hi * a.W + wi) * (unsigned)a.in_cs + (unsigned)c) * 2u
-                                        : M3D_BUF_OOB;
-                rp[p][0] = buf_load_u32x4(rin, off, 0);
+                    for (int p = 0; p < 4; ++p) {
+                        const int hi = hi0[p] + ti, wi = wi0[p] + tj;
+                        const bool ok = rvalid[p] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                        poff[p] = ok ? ((unsigned)(pix_base[p] + hi * a.W + wi) * (unsigned)a.in_cs + (unsigned)chunk * 8u) * 2u
+                                     : M3D_BUF_OOB;
+                    }
+                }
+                const unsigned so = (unsigned)c * 2u;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) rp[p][0] = buf_load_u32x4(rin, poff[p], so);
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int hi = hi0[p] + ti, wi = wi0[p] + tj;
+                    const bool ok = kvalid && rvalid[p] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                    const unsigned off = ok ? ((unsigned)(pix_base[p] + hi * a.W + wi) * (unsigned)a.in_cs + (unsigned)c) * 2u
+                                            : M3D_BUF_OOB;
+                    rp[p][0] = buf_load_u32x4(rin, off, 0);
+                }
             }
         } else {
-            if (tap != samp_tap) {      // sampling state of this thread's 4 pixels for the tap (dcn_v2_im2col_cuda.cu:18-47,150-178)
+            if (fresh) {      // sampling state of this thread's 4 pixels for the tap (dcn_v2_im2col_cuda.cu:18-47,150-178)
                 samp_tap = tap;
                 const int KK = a.kh * a.kw;
+                const unsigned lane_c = uni ? (unsigned)chunk * 16u : 0u;
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f, mk = 0.f;
@@ -161,17 +192,25 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const Bf16Args a)
                         }
                     }
                     bw[p][0] = w1 * mk; bw[p][1] = w2 * mk; bw[p][2] = w3 * mk; bw[p][3] = w4 * mk;
-                    doff[p][0] = (unsigned)(pix_base[p] + o1) * (unsigned)a.in_cs * 2u;
-                    doff[p][1] = (unsigned)(pix_base[p] + o2) * (unsigned)a.in_cs * 2u;
-                    doff[p][2] = (unsigned)(pix_base[p] + o3) * (unsigned)a.in_cs * 2u;
-                    doff[p][3] = (unsigned)(pix_base[p] + o4) * (unsigned)a.in_cs * 2u;
+                    doff[p][0] = (unsigned)(pix_base[p] + o1) * (unsigned)a.in_cs * 2u + lane_c;
+                    doff[p][1] = (unsigned)(pix_base[p] + o2) * (unsigned)a.in_cs * 2u + lane_c;
+                    doff[p][2] = (unsigned)(pix_base[p] + o3) * (unsigned)a.in_cs * 2u + lane_c;
+                    doff[p][3] = (unsigned)(pix_base[p] + o4) * (unsigned)a.in_cs * 2u + lane_c;
                 }
             }
-            const unsigned cb = (unsigned)c * 2u;
+            if (uni) {
+                const unsigned so = (unsigned)c * 2u;
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
+                for (int p = 0; p < 4; ++p)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) rp[p][q] = buf_load_u32x4(rin, doff[p][q] + cb, 0);
+                    for (int q = 0; q < 4; ++q) rp[p][q] = buf_load_u32x4(rin, doff[p][q], so);
+            } else {
+                const unsigned cb = (unsigned)c * 2u;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rp[p][q] = buf_load_u32x4(rin, doff[p][q] + cb, 0);
+            }
         }
         const unsigned wso = (unsigned)kt * (BK * 2u);
 #pragma unroll
@@ -396,6 +435,7 @@ extern "C" int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t s
     a.out_mode = d->out_mode; a.res_mode = d->res_mode; a.act = d->act; a.sigmoid_from = d->sigmoid_from;
     const int bn = d->Cout_pad % 128 == 0 ? 128 : (d->Cout_pad % 64 == 0 ? 64 : 32);
     a.tiles_m = cdiv(M, 128); a.tiles_n = d->Cout_pad / bn;
+    a.uniform_k = (d->Cin % 64 == 0 && K % 64 == 0) ? 1 : 0;
     const dim3 grid(a.tiles_m * a.tiles_n, d->groups), block(256);
     hipStream_t st = (hipStream_t)stream;
     const bool deform = d->dcn_offmask != nullptr;

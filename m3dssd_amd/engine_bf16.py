@@ -21,10 +21,26 @@ import numpy as np
 import torch
 
 from . import _hip
-from ._hip import ConvBf16Desc
+from ._hip import ConvBf16Desc, HeadBf16Desc
 from .engine import BN_EPS, PSP_SIZES, Engine, _Plan, _rup, _Stream
 
 BF16 = torch.bfloat16
+FUSED_HEADS = os.environ.get("M3D_BF16_FUSED_HEADS", "1") != "0"
+FUSED_FRONT = os.environ.get("M3D_BF16_FUSED_FRONT", "1") != "0"
+
+
+def pack_frontend_bf16(w_stem, w_l0, w_l1, device):
+    """Weights of m3d_frontend_bf16_forward: stem [16,3,7,7] -> [16][7*32] (k = i*32 + j*4 + c), level0 / level1
+    [Co,16,3,3] -> [Co][160] (k = (i*3 + j)*16 + c)."""
+    ws = torch.zeros(16, 7, 8, 4)
+    ws[:, :, :7, :3] = w_stem.detach().float().cpu().permute(0, 2, 3, 1)
+    out = [ws.reshape(16, 224)]
+    for w in (w_l0, w_l1):
+        co = w.shape[0]
+        t = torch.zeros(co, 160)
+        t[:, :144] = w.detach().float().cpu().permute(0, 2, 3, 1).reshape(co, 144)
+        out.append(t)
+    return [t.to(device, BF16).contiguous() for t in out]
 
 
 class View16:
@@ -100,6 +116,7 @@ class EngineBF16(Engine):
         P["stem.scale"], P["stem.shift"] = s.contiguous(), (be - m * s).contiguous()
         P["level0"] = self._pc(b + ".level0.0", b + ".level0.1")
         P["level1"] = self._pc(b + ".level1.0", b + ".level1.1")
+        P["front.w"] = pack_frontend_bf16(sd[b + ".base_layer.0.weight"], sd[b + ".level0.0.weight"], sd[b + ".level1.0.weight"], dev)
 
         def block(p):
             P[p + ".conv1"] = self._pc(p + ".conv1", p + ".bn1")
@@ -238,18 +255,31 @@ class EngineBF16(Engine):
         plan.named["input_u8"] = in_u8
         mean3 = (ctypes.c_float * 3)(*[float(v) for v in self.conf.image_means])
         stds3 = (ctypes.c_float * 3)(*[float(v) for v in self.conf.image_stds])
-        s0 = self._buf16(plan, B, H, W, 16)
-
-        def stem(st):
-            u8 = 1 if in_u8[0] else 0
-            _hip.check(L.m3d_stem_conv7x7_bf16(in_u8[0] if u8 else in_ptr[0], u8, in_u8[1], in_u8[2], mean3, stds3,
-                                               P["stem.w"].data_ptr(), P["stem.scale"].data_ptr(), P["stem.shift"].data_ptr(),
-                                               s0.ptr, s0.cs, B, H, W, st))
-        self._op(plan, "stem", "stem_bf16", stem)
-        l0 = self._buf16(plan, B, H, W, 16, name="level0")
-        self._pconv(plan, "level0", P["level0"], s0, l0, 1, 1, act=1)
         l1 = self._buf16(plan, B, H // 2, W // 2, 32, name="level1")
-        self._pconv(plan, "level1", P["level1"], l0, l1, 2, 1, act=1)
+        if FUSED_FRONT:
+            # stem -> level0 -> level1 in one launch: the 16-channel full-resolution maps never reach HBM
+            fwts, p0, p1 = P["front.w"], P["level0"], P["level1"]
+
+            def front(st):
+                u8 = 1 if in_u8[0] else 0
+                _hip.check(L.m3d_frontend_bf16_forward(
+                    in_u8[0] if u8 else in_ptr[0], u8, in_u8[1], in_u8[2], mean3, stds3, fwts[0].data_ptr(),
+                    P["stem.scale"].data_ptr(), P["stem.shift"].data_ptr(), fwts[1].data_ptr(), p0.scale.data_ptr(),
+                    p0.shift.data_ptr(), fwts[2].data_ptr(), p1.scale.data_ptr(), p1.shift.data_ptr(), l1.ptr, l1.cs, B, H, W, st))
+            flops = 2.0 * B * H * W * (147 * 16 + 144 * 16) + 2.0 * B * (H // 2) * (W // 2) * 144 * 32
+            plan.ops.append(("stem+level0+level1", "bf16_frontend", flops, front, None))
+        else:
+            s0 = self._buf16(plan, B, H, W, 16)
+
+            def stem(st):
+                u8 = 1 if in_u8[0] else 0
+                _hip.check(L.m3d_stem_conv7x7_bf16(in_u8[0] if u8 else in_ptr[0], u8, in_u8[1], in_u8[2], mean3, stds3,
+                                                   P["stem.w"].data_ptr(), P["stem.scale"].data_ptr(), P["stem.shift"].data_ptr(),
+                                                   s0.ptr, s0.cs, B, H, W, st))
+            self._op(plan, "stem", "stem_bf16", stem)
+            l0 = self._buf16(plan, B, H, W, 16, name="level0")
+            self._pconv(plan, "level0", P["level0"], s0, l0, 1, 1, act=1)
+            self._pconv(plan, "level1", P["level1"], l0, l1, 2, 1, act=1)
 
         def maxpool(name, x, out):
             self._op(plan, name, "maxpool_bf16", lambda st: _hip.check(L.m3d_maxpool2x2_bf16(
@@ -357,18 +387,32 @@ class EngineBF16(Engine):
 
         def heads(names, x, first_box_index):
             """The heads `names` (consecutive rows of the planar box staging starting at first_box_index) read the same map x:
-            layer 1 as ONE GEMM Cin -> G*256, layers 2 and 3 as grouped launches."""
+            one fused 3-layer launch (m3d_head_mlp_bf16_forward, blockIdx.y = head), hidden activations in LDS.  With
+            M3D_BF16_FUSED_HEADS=0: layer 1 as ONE GEMM Cin -> G*256, layers 2 and 3 as grouped launches."""
             G = len(names)
             w1, s1, t1 = stacked(names, ".0")
+            w2, s2, t2 = stacked(names, ".3")
+            w3, s3, t3 = stacked(names, ".6")
+            cp = P[names[0] + ".6"].cout_pad
+            if FUSED_HEADS and x.c == 128 and cp == 64:
+                d = HeadBf16Desc()
+                d.inp, d.in_cs, d.M, d.Cin = x.ptr, x.cs, B * HW, 128
+                d.w1, d.w2, d.w3 = w1.data_ptr(), w2.data_ptr(), w3.data_ptr()
+                d.s1, d.t1, d.s2, d.t2, d.s3, d.t3 = (t.data_ptr() for t in (s1, t1, s2, t2, s3, t3))
+                d.Cout, d.Cout_pad = A, cp
+                d.out = box_pl.data_ptr() + 4 * first_box_index * A * HW
+                d.out_group_off, d.out_img_stride, d.HW, d.groups = A * HW, 11 * A * HW, HW, G
+                ref = ctypes.byref(d)
+                flops = 2.0 * B * HW * G * (128 * 256 + 256 * 256 + 256 * A)
+                plan.ops.append(("+".join(names) + ".mlp", "bf16_head_mlp", flops,
+                                 lambda st: _hip.check(L.m3d_head_mlp_bf16_forward(ref, st)), d))
+                return
             h1 = self._buf16(plan, B, fh, fw, G * 256)
             self._conv16(plan, "+".join(names) + ".0", x, h1, wgt=w1, kpad=P[names[0] + ".0"].kpad, cout=G * 256, cout_pad=G * 256,
                          scale=s1, shift=t1, act=1)
-            w2, s2, t2 = stacked(names, ".3")
             h2 = self._buf16(plan, B, fh, fw, G * 256)
             self._conv16(plan, "+".join(names) + ".3", h1, h2, wgt=w2, kpad=256, cout=256, cout_pad=256, scale=s2, shift=t2, act=1,
                          groups=G, in_goff=256, wgt_goff=256 * 256, out_goff=256, ss_goff=256, cin=256)
-            w3, s3, t3 = stacked(names, ".6")
-            cp = P[names[0] + ".6"].cout_pad
             self._conv16(plan, "+".join(names) + ".6", h2, None, wgt=w3, kpad=256, cout=A, cout_pad=cp, scale=s3, shift=t3,
                          planar=(box_pl, 11 * A * HW, first_box_index * A), groups=G, in_goff=256, wgt_goff=cp * 256,
                          out_goff=A * HW, ss_goff=A, cin=256)

@@ -242,6 +242,43 @@ def test_conv_bf16_grouped_and_per_image_weights():
     _check(got, ref, 1)
 
 
+@pytest.mark.parametrize("G,n,h,w,cout", [(1, 2, 8, 16, 36), (4, 1, 13, 21, 36), (2, 2, 16, 40, 5)])
+def test_fused_head_mlp_bf16_matches_torch_chain(G, n, h, w, cout):
+    """m3d_head_mlp_bf16_forward (3 layers, hidden activations in LDS, heads of one map in one launch) against the torch
+    chain on the same bf16-rounded input / weights with the hidden activations rounded to bf16 where the kernel rounds them."""
+    from m3dssd_amd import _hip
+    L = _hip.lib()
+    dev = _dev()
+    g = torch.Generator().manual_seed(G * 100 + h)
+    x = _r(torch.randn(n, 128, h, w, generator=g))
+    M, HW = n * h * w, h * w
+    xin = _nhwc16(x, 136)
+    w1 = _r(torch.randn(G, 256, 128, generator=g) / 128 ** 0.5)
+    w2 = _r(torch.randn(G, 256, 256, generator=g) / 16)
+    w3 = torch.zeros(G, 64, 256)
+    w3[:, :cout] = _r(torch.randn(G, cout, 256, generator=g) / 16)
+    aff = [torch.rand(G, c, generator=g) + 0.5 for c in (256, 256, cout)]
+    sh = [torch.randn(G, c, generator=g) * 0.1 for c in (256, 256, cout)]
+    out = torch.full((n, G * cout + 1, HW), 512.0, device=dev)
+    dv = [t.to(dev).contiguous() for t in (w1.to(BF16), w2.to(BF16), w3.to(BF16), aff[0], sh[0], aff[1], sh[1], aff[2], sh[2])]
+    d = _hip.HeadBf16Desc()
+    d.inp, d.in_cs, d.M, d.Cin = xin.data_ptr(), 136, M, 128
+    d.w1, d.w2, d.w3, d.s1, d.t1, d.s2, d.t2, d.s3, d.t3 = (t.data_ptr() for t in dv)
+    d.Cout, d.Cout_pad, d.out = cout, 64, out.data_ptr()
+    d.out_group_off, d.out_img_stride, d.HW, d.groups = cout * HW, (G * cout + 1) * HW, HW, G
+    _hip.check(L.m3d_head_mlp_bf16_forward(ctypes.byref(d), _st()))
+    torch.cuda.synchronize()
+    got = out.cpu()
+    assert (got[:, G * cout] == 512.0).all()
+    xf = x.permute(0, 2, 3, 1).reshape(M, 128)
+    for gi in range(G):
+        h1 = _r(F.leaky_relu(xf @ w1[gi].T * aff[0][gi] + sh[0][gi], 0.01))
+        h2 = _r(F.leaky_relu(h1 @ w2[gi].T * aff[1][gi] + sh[1][gi], 0.01))
+        ref = (h2 @ w3[gi, :cout].T * aff[2][gi] + sh[2][gi]).view(n, HW, cout).permute(0, 2, 1)
+        e = (got[:, gi * cout:(gi + 1) * cout] - ref).abs().max().item()
+        assert e < 4e-3 * (1.0 + ref.abs().max().item()), (gi, e)      # a hidden value may round to the neighbouring bf16
+
+
 @pytest.mark.parametrize("shape", [(2, 128, 16, 40, 128, 3, 1), (1, 256, 8, 20, 128, 3, 1), (1, 512, 6, 10, 256, 3, 1),
                                    (2, 128, 16, 40, 128, 1, 0), (1, 64, 9, 13, 64, 3, 1)])
 def test_dcn_bf16_matches_oracle(shape):
@@ -333,6 +370,51 @@ def test_bf16_helpers_match_torch():
                                        out.data_ptr(), 16, 2, 16, 64, _st()))
     got = out.float().permute(0, 3, 1, 2).cpu()
     assert ((got - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-4).all()
+
+
+@pytest.mark.parametrize("n,H,W,u8", [(2, 32, 128, False), (1, 48, 96, False), (2, 32, 128, True)])
+def test_fused_frontend_bf16_matches_torch_chain(n, H, W, u8):
+    """m3d_frontend_bf16_forward (stem -> level0 -> level1 in one launch, intermediates in LDS) against the torch chain with
+    bf16-rounded weights and the two intermediates rounded to bf16 where the kernel rounds them; image borders, several tiles
+    per image, a width that is not a multiple of the tile, and the uint8 input path."""
+    from m3dssd_amd import _hip
+    from m3dssd_amd.engine_bf16 import pack_frontend_bf16
+    L = _hip.lib()
+    dev = _dev()
+    g = torch.Generator().manual_seed(H + W)
+    ws = _r(torch.randn(16, 3, 7, 7, generator=g) / 12)
+    w0 = _r(torch.randn(16, 16, 3, 3, generator=g) / 12)
+    w1 = _r(torch.randn(32, 16, 3, 3, generator=g) / 12)
+    aff = [(torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1) for c in (16, 16, 32)]
+    conf = synth.synth_conf((H, W), 0, batch_size=n, device="cpu")
+    if u8:
+        from oracle import preprocess as opre
+        frames = torch.randint(0, 256, (n, H - 5, W - 9, 3), generator=g, dtype=torch.uint8)
+        mean_np, stds_np = np.asarray(conf.image_means, dtype=np.float32), np.asarray(conf.image_stds, dtype=np.float32)
+        img = torch.from_numpy(np.stack([opre.preprocess(f.numpy(), (H, W), mean_np, stds_np) for f in frames]))
+        src = frames.to(dev)
+    else:
+        img = torch.randn(n, 3, H, W, generator=g)
+        src = img.to(dev)
+
+    def stage(x, w, sc, sh, stride, pad):
+        return _r(F.leaky_relu(F.conv2d(x, w, None, stride=stride, padding=pad) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), 0.01))
+    ref = stage(stage(stage(_r(img), ws, *aff[0], 1, 3), w0, *aff[1], 1, 1), w1, *aff[2], 2, 1)
+    packs = pack_frontend_bf16(ws, w0, w1, dev)
+    dv = [t.to(dev).contiguous() for pair in aff for t in pair]
+    out = torch.full((n, H // 2, W // 2, 40), 512.0, device=dev, dtype=BF16)
+    mean3 = (ctypes.c_float * 3)(*[float(v) for v in conf.image_means])
+    stds3 = (ctypes.c_float * 3)(*[float(v) for v in conf.image_stds])
+    _hip.check(L.m3d_frontend_bf16_forward(src.data_ptr(), 1 if u8 else 0, H - 5 if u8 else 0, W - 9 if u8 else 0, mean3, stds3,
+                                           packs[0].data_ptr(), dv[0].data_ptr(), dv[1].data_ptr(), packs[1].data_ptr(),
+                                           dv[2].data_ptr(), dv[3].data_ptr(), packs[2].data_ptr(), dv[4].data_ptr(), dv[5].data_ptr(),
+                                           out.data_ptr(), 40, n, H, W, _st()))
+    torch.cuda.synchronize()
+    assert (out[..., 32:].float() == 512.0).all()
+    got = out[..., :32].float().permute(0, 3, 1, 2).cpu()
+    err = (got - ref).abs()
+    tol = 2.0 ** -7 * ref.abs() + 4e-3 * ref.abs().max()      # an intermediate may round to the neighbouring bf16
+    assert (err <= tol).all(), (err.max().item(), ref.abs().max().item(), int((err > tol).sum()))
 
 
 # ------------------------------------------------------------------------------------ whole network
