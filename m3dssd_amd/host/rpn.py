@@ -65,21 +65,33 @@ class RPN(nn.Module):
         self.softmax = nn.Softmax(dim=1)
         self._conf = conf
         self._engine = None
-        self._engine_version = None
         self.compute_dtype = str(conf.compute_dtype) if "compute_dtype" in conf else "f32"
 
-    # -- engine management: (re)pack parameters whenever they change ------------------------------
-    def _param_version(self):
-        return (self.compute_dtype,) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+    # -- engine management: parameters are folded / packed once and re-packed when they change --------------------------------
+    # Everything that replaces or moves parameters through the nn.Module API (load_state_dict, .to / .cuda / .float via _apply)
+    # marks the packed engine stale; code that writes parameter storage IN PLACE (p.data.copy_, optimiser steps) must call
+    # refresh_engine() itself -- hashing ~540 (data_ptr, _version) pairs on every forward cost 0.3 ms of host time per call.
+    def refresh_engine(self):
+        self._engine = None
+        return self
+
+    def _apply(self, fn, *args, **kwargs):
+        self._engine = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._engine = None
+        return super().load_state_dict(*args, **kwargs)
 
     def set_compute_dtype(self, dtype):
         """'f32' (default: the reference's arithmetic) or 'bf16' (bf16 storage / MFMA, fp32 accumulation; see engine_bf16.py)."""
-        self.compute_dtype = str(dtype)
+        if str(dtype) != self.compute_dtype:
+            self.compute_dtype = str(dtype)
+            self._engine = None
         return self
 
     def engine(self):
-        ver = self._param_version()
-        if self._engine is None or ver != self._engine_version:
+        if self._engine is None:
             dev = next(self.parameters()).device
             if dev.type != "cuda":
                 raise NotImplementedError("RPN.forward runs on a ROCm device only; move the module with .to('cuda') "
@@ -91,7 +103,6 @@ class RPN(nn.Module):
                 self._engine = Engine(self.state_dict(), self._conf, device=dev)
             else:
                 raise ValueError("compute_dtype must be 'f32' or 'bf16' (got %r)" % (self.compute_dtype,))
-            self._engine_version = ver
         return self._engine
 
     def forward(self, x):
