@@ -156,7 +156,7 @@ def algorithmic_bytes(op):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 for f32 bs=8, 60 for bf16 bs=64: ~1.2 s timed)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 8 for f32, 64 for bf16)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
@@ -195,6 +195,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     bf16 = args.dtype == "bf16"
+    if args.steps is None:
+        args.steps = 60 if bf16 else 200
     B = args.batch if args.batch is not None else (64 if bf16 else PER_GPU_BATCH)
 
     conf = synth.synth_conf(CROP, 0, batch_size=B, device=str(dev))
