@@ -171,6 +171,9 @@ typedef struct m3d_conv_bf16_desc {
     int ss_group_off;
 } m3d_conv_bf16_desc;
 int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t stream);
+/* Which kernel m3d_conv_bf16_forward launches for `d` (profiling labels; no launch): 0 = implicit-GEMM tile
+ * (bf16_conv_kernel), 1 = 3x3 halo tile of 8 x 16 pixels, 2 = 3x3 halo tile of 8 x 32 pixels (bf16_conv3x3_halo_kernel). */
+int m3d_conv_bf16_variant(const m3d_conv_bf16_desc *d);
 
 /* Fused 3-layer RPN head of the bf16 path (model/M3d_inference_align.py:77-210): [1x1 128 -> 256, affine, LeakyReLU] ->
  * [1x1 256 -> 256, affine, LeakyReLU] -> [1x1 256 -> Cout, affine] per 128-pixel tile in ONE launch, hidden activations in LDS.

@@ -86,6 +86,7 @@ SIGNATURES = {
     "m3d_abi_version": (c_int, []),
     "m3d_conv2d_forward": (c_int, [ctypes.POINTER(ConvDesc), P]),
     "m3d_conv_bf16_forward": (c_int, [ctypes.POINTER(ConvBf16Desc), P]),
+    "m3d_conv_bf16_variant": (c_int, [ctypes.POINTER(ConvBf16Desc)]),
     "m3d_head_mlp_bf16_forward": (c_int, [ctypes.POINTER(HeadBf16Desc), P]),
     "m3d_stem_conv7x7_bf16": (c_int, [P, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                       P, P, P, P, c_int, c_int, c_int, c_int, P]),

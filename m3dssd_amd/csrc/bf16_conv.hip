@@ -14,6 +14,8 @@
 //   Out-of-image taps, rows past M and the zero padding of K use buffer loads whose masked lanes read 0.
 //   blockIdx -> tile mapping is XCD-aware: each XCD owns a contiguous range of tiles, and the channel tiles of one pixel tile
 //   are adjacent (they re-read the same pixels from that XCD's L2).
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -39,7 +41,11 @@ struct Bf16Args {
     int out_mode;              // 0 bf16 NHWC, 1 fp32 NHWC, 2 fp32 planar [img][c][HoWo]
     int res_mode, act, sigmoid_from;
     int tiles_m, tiles_n;
+    int lane_perm;             // halo kernel: 1 = bank-conflict-free lane -> pixel map (0 = identity, for A/B)
     int uniform_k;             // Cin % 64 == 0 (or 1x1 with K % 64 == 0): every K-step lies in one tap, channel offset is wave-uniform
+#ifdef BF16_TRACE
+    long long *trace;
+#endif
 };
 
 __device__ __forceinline__ u32x4 buf_load_u32x4(__amdgpu_buffer_rsrc_t r, unsigned voffset, unsigned soffset)
@@ -63,15 +69,15 @@ __device__ __forceinline__ f32x2 unpack_bf16(unsigned u)
 // register group g.  Folded BatchNorm / bias, residual, LeakyReLU / sigmoid in fp32; bf16 NHWC (16-byte stores after a
 // v_permlane32_swap of the half-waves), fp32 NHWC or fp32 planar output.
 template <int TN, int TM>
-__device__ __forceinline__ void conv_epilogue(const Bf16Args &a, f32x16 (&acc)[TN][TM], int m0, int n0, int wm, int wn, int l31, int lh,
+__device__ __forceinline__ void conv_epilogue(const Bf16Args &a, f32x16 (&acc)[TN][TM], const int (&mpix)[TM], int n0, int wn, int lh,
                                               int grp)
 {
     const float *scale = a.scale ? a.scale + grp * a.ss_goff : nullptr;
     const float *shift = a.shift ? a.shift + grp * a.ss_goff : nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm + i * 32 + l31;
-        const bool mok = m < a.M;
+        const int m = mpix[i];                                   // this lane's output pixel (linear n*Ho*Wo index) or -1
+        const bool mok = m >= 0;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int cb = n0 + wn + j * 32 + 4 * lh;          // + 8g
@@ -173,6 +179,18 @@ __device__ __forceinline__ void conv_epilogue(const Bf16Args &a, f32x16 (&acc)[T
     }
 }
 
+#ifdef BF16_TRACE
+// Diagnostic build (make trace): s_memtime stamps of wave 0 of every workgroup -- per K-step: loop top, loads issued, MFMAs
+// issued, staging writes done (vmcnt waits), barrier passed.  tools/bf16_conv_trace.py prints the phase averages.
+static long long *g_bf16_trace = nullptr;
+extern "C" void m3d_bf16_conv_set_trace(void *buf) { g_bf16_trace = (long long *)buf; }
+#define BTRACE_INIT() long long *trp = a.trace ? a.trace + (size_t)blockIdx.x * 160 : nullptr; int tri = 0
+#define BTRACE() do { if (trp && tid == 0 && tri < 160) trp[tri++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BTRACE_INIT()
+#define BTRACE()
+#endif
+
 template <int BN, bool DEFORM>
 __global__ __launch_bounds__(256) void bf16_conv_kernel(const Bf16Args a)
 {
@@ -189,6 +207,8 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const Bf16Args a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (wave / WN) * (TM * 32), wn = (wave % WN) * (TN * 32);
+    BTRACE_INIT();
+    BTRACE();
 
     // XCD-aware tile mapping (consecutive workgroup ids round-robin over the 8 XCDs)
     const int ntiles = a.tiles_m * a.tiles_n;
@@ -375,7 +395,9 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const Bf16Args a)
     const int sw = (l31 >> 1) & 7;                 // fragment rows are (multiple of 32) + l31: the swizzle term is per lane
     for (int kt = 0; kt < a.KT; ++kt) {
         const int buf = kt & 1;
+        BTRACE();
         if (kt + 1 < a.KT) load_tile(kt + 1);
+        BTRACE();
         const unsigned char *Pb = Ps + buf * BM * 128 + (wm + l31) * 128;
         const unsigned char *Wb = Ws + buf * BN * 128 + (wn + l31) * 128;
 #pragma unroll
@@ -392,20 +414,222 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const Bf16Args a)
                 for (int i = 0; i < TM; ++i)
                     acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fp[i], acc[j][i], 0, 0, 0);
         }
+        BTRACE();
         if (kt + 1 < a.KT) store_tile(buf ^ 1);
+        BTRACE();
         __syncthreads();
     }
+    BTRACE();
 
-    conv_epilogue<TN, TM>(a, acc, m0, n0, wm, wn, l31, lh, grp);
+    int mpix[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm + i * 32 + l31;
+        mpix[i] = m < a.M ? m : -1;
+    }
+    conv_epilogue<TN, TM>(a, acc, mpix, n0, wn, lh, grp);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
+// =====================================================================================================================
+// 3x3 / stride 1 / pad 1 convolution with the input patch resident in LDS ("halo tile").
+//
+// Why (in-kernel timeline of the generic kernel, tools/bf16_conv_trace.py, 256 -> 256 @ 24x80, bs 64): a K-step takes 2360
+// cycles of which the wave spends 764 ISSUING its 8 global loads and 448 waiting for / writing them to LDS, against 820 in the
+// MFMA section.  The generic tile re-stages its 128 pixels for each of the 9 taps: per workgroup K-step that is 32
+// ds_write_b128 wave-instructions (13 LDS-path cycles each, MI355X_MICROARCH.md section LDS) + 64 ds_read_b128 (4 each) = 672
+// LDS cycles against 512 MFMA cycles per SIMD -- the LDS store path, not the matrix core, sets the pace.  Here a workgroup
+// owns an 8 x TW patch of output pixels and stages the 10 x (TW + 2) input patch of a 64-channel chunk ONCE; the 9 taps read
+// their B fragments from it at shifted addresses (pixel rows of 144 bytes: 16 consecutive pixels of a patch row cover all 64
+// banks exactly once, and the tap shift is an IMMEDIATE offset -- no swizzle arithmetic); only the weights are staged per
+// (tap, chunk).  K order is (chunk, tap) instead of (tap, chunk): fp32 accumulation order changes, nothing else.
+//
+// Lane -> pixel map inside a 32-pixel MFMA tile: ds_read_b128 is serviced in the lane groups {0-3, 12-15, 20-27},
+// {4-11, 16-19, 28-31} (+32); each group is given 16 CONSECUTIVE pixels of one patch row, so every fragment read is
+// conflict-free (the identity map puts 8 + 8 pixels of two rows in a group: 2-way conflicts on every read).
+#define HT_PS 144                        // bytes per halo pixel (128 + 16 pad)
+template <int BN, int TW, int BM, int WAVES>     // LDS allows 2 workgroups per CU (3 for the small tile): hold the register file to that
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVES / 2, WAVES / 2 + (BN * BM <= 64 * 128))))
+void bf16_conv3x3_halo_kernel(const Bf16Args a)
+{
+    constexpr int TH = BM / TW, HW = TW + 2, HPIX = (TH + 2) * HW;
+    constexpr int NT = WAVES * 64, RPP = NT / 8;       // threads; pixels (or weight rows) staged per pass
+    constexpr int WN = 2, WM = WAVES / 2;
+    constexpr int TN = BN / (32 * WN), TM = BM / (32 * WM);
+    constexpr int PB = BN * 8 / NT;                    // weight pieces (16 B) per thread per K-step
+    constexpr int HP = (HPIX * 8 + NT - 1) / NT;       // halo pieces per thread per chunk
+    constexpr int HBYTES = HPIX * HT_PS;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[HBYTES + 2 * BN * 128];
+    unsigned char *Hs = lds, *Ws = lds + HBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave / WN) * (TM * 32), wn = (wave % WN) * (TN * 32);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int ntiles = a.tiles_m * a.tiles_n;
+    int tile = blockIdx.x;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = tile & 7, idx = tile >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = tile / a.tiles_n, tile_n = tile - tile_m * a.tiles_n;
+    const int n0 = tile_n * BN;
+    const int tpx = (a.Wo + TW - 1) / TW, tpy = (a.Ho + TH - 1) / TH;
+    const int img = tile_m / (tpx * tpy), trem = tile_m - img * tpx * tpy;
+    const int y0 = (trem / tpx) * TH, x0 = (trem % tpx) * TW;
+
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
+    const __amdgpu_buffer_rsrc_t rwgt = make_rsrc(a.wgt, a.wgt_bytes);
+
+    // ---- halo staging map: piece q = tid + NT*p -> halo pixel (tid >> 3) + RPP*p, 16-byte chunk tid & 7 ------------------
+    const int chunk = tid & 7, rsub = tid >> 3;
+    // Byte offsets are rebuilt per chunk from (hy0, hx0) with a few VALU ops per piece -- once per 9 K-steps -- instead of
+    // living in HP registers: the 256-pixel tiles need every VGPR for accumulators and the in-flight patch.
+    const int hy0 = rsub / HW, hx0 = rsub - hy0 * HW;
+    const unsigned hbase = ((unsigned)((img * a.H + y0 - 1) * a.W + x0 - 1) * (unsigned)a.in_cs + (unsigned)chunk * 8u) * 2u;
+    const int hdst0 = rsub * HT_PS + chunk * 16;                                        // + p * RPP * HT_PS
+    const unsigned woff0 = ((unsigned)(n0 + rsub) * (unsigned)(a.KT * 64) + (unsigned)chunk * 8u) * 2u;
+    const unsigned wrow_step = (unsigned)RPP * (unsigned)(a.KT * 64) * 2u;             // bytes between passes (scalar)
+    const int wdst0 = rsub * 128 + ((chunk ^ ((rsub >> 1) & 7)) << 4);                  // + p * RPP * 128 (RPP % 16 == 0)
+    u32x4 rh[HP], rw[PB];
+    const int NC = a.Cin >> 6;                                  // 64-channel chunks
+    auto load_halo = [&](int c) __attribute__((always_inline)) {
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(c) * 128u;
+        int hy = hy0, hx = hx0;
+#pragma unroll
+        for (int p = 0; p < HP; ++p) {
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = hy < TH + 2 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            const unsigned off = ok ? hbase + (unsigned)(hy * a.W + hx) * (unsigned)(a.in_cs * 2) : M3D_BUF_OOB;
+            rh[p] = buf_load_u32x4(rin, off, so);
+            hx += RPP % HW; hy += RPP / HW;
+            if (hx >= HW) { hx -= HW; ++hy; }
+        }
+    };
+    auto store_halo = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < HP; ++p)
+            if ((p + 1) * RPP <= HPIX || rsub + RPP * p < HPIX)
+                *reinterpret_cast<u32x4 *>(Hs + hdst0 + p * RPP * HT_PS) = rh[p];
+    };
+    auto load_w = [&](int c, int tap) __attribute__((always_inline)) {
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(tap * a.Cin + c * 64) * 2u;
+#pragma unroll
+        for (int p = 0; p < PB; ++p) rw[p] = buf_load_u32x4(rwgt, woff0, so + (unsigned)p * wrow_step);
+    };
+    auto store_w = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < PB; ++p) *reinterpret_cast<u32x4 *>(Ws + buf * BN * 128 + wdst0 + p * RPP * 128) = rw[p];
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+    // position of this lane's pixel inside its 32-pixel MFMA tile (see the header): ds_read_b128 lane group -> one patch row
+    int lpos;
+    if (a.lane_perm == 0) lpos = l31;
+    else if (l31 < 4) lpos = l31;
+    else if (l31 < 12) lpos = 16 + (l31 - 4);
+    else if (l31 < 16) lpos = 4 + (l31 - 12);
+    else if (l31 < 20) lpos = 24 + (l31 - 16);
+    else if (l31 < 28) lpos = 8 + (l31 - 20);
+    else lpos = 28 + (l31 - 28);
+    const int sw = (l31 >> 1) & 7;
+    int pbase[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int p = wm + i * 32 + lpos;
+        pbase[i] = ((p / TW) * HW + (p % TW)) * HT_PS + lh * 16;
+    }
+
+    load_halo(0);
+    load_w(0, 0);
+    store_halo();
+    store_w(0);
+    __syncthreads();
+    int t = 0;                                                  // step index = c * 9 + tap; weight buffer t & 1
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++t) {
+            const bool last = (c == NC - 1) && tap == 8;
+            if (!last) load_w(tap == 8 ? c + 1 : c, tap == 8 ? 0 : tap + 1);
+            if (tap == 6 && c + 1 < NC) load_halo(c + 1);       // the next chunk's patch travels under the last taps of this one
+            const unsigned char *Wb = Ws + (t & 1) * BN * 128 + (wn + l31) * 128;
+            const int toff = ((tap / 3) * HW + (tap % 3)) * HT_PS;          // compile-time per unrolled tap
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int co = ((2 * s + lh) ^ sw) << 4;
+                bf16x8 fw[TN], fp[TM];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fw[j] = *reinterpret_cast<const bf16x8 *>(Wb + j * 32 * 128 + co);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fp[i] = *reinterpret_cast<const bf16x8 *>(Hs + pbase[i] + toff + s * 32);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fp[i], acc[j][i], 0, 0, 0);
+            }
+            if (!last) store_w((t + 1) & 1);
+            if (tap == 8 && c + 1 < NC) {
+                __syncthreads();                                // every wave is done reading the patch
+                store_halo();
+            }
+            __syncthreads();
+        }
+    }
+    int mpix[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int p = wm + i * 32 + lpos;
+        const int y = y0 + p / TW, x = x0 + p % TW;
+        mpix[i] = (y < a.Ho && x < a.Wo) ? (img * a.Ho + y) * a.Wo + x : -1;
+    }
+    conv_epilogue<TN, TM>(a, acc, mpix, n0, wn, lh, 0);
+}
+
 static int ilog2_exact(int v)
 {
     int l = 0;
     while ((1 << l) < v) ++l;
     return (1 << l) == v ? l : -1;
 }
+
+// Which kernel m3d_conv_bf16_forward runs for a descriptor: 0 = generic implicit-GEMM tile, 1 = halo tile 8 x 16 pixels / 4
+// waves, 2 = halo tile 8 x 32 pixels / 8 waves.  3x3 / stride 1 / pad 1 on a 64-multiple of channels goes to the halo-tile
+// kernel when its patches tile the map well.
+// M3D_BF16_HALO: 0 = generic kernel everywhere, 1 = default choice, 2 = 128-pixel patches only, +16 = identity lane map
+// (A/B of the LDS bank-conflict fix).  tools/bf16_conv_bench.py, TFLOP/s generic -> 8x16 patch / 4 waves -> 8x32 patch /
+// 8 waves: 64->64 @96x320 403 -> 599 -> 664; 128->128 @48x160 543 -> 712 -> 792; 256->256 @24x80 634 -> 845 -> 854
+// (8x32 / 4 waves with 128x64 wave tiles: 819, spills).
+static int halo_env()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("M3D_BF16_HALO"); v = e ? atoi(e) : 1; }
+    return v;
+}
+static int conv_bf16_variant(const m3d_conv_bf16_desc *d, long long *tiles)
+{
+    const int halo_on = halo_env() & 15;
+    const int bn = d->Cout_pad % 128 == 0 ? 128 : (d->Cout_pad % 64 == 0 ? 64 : 32);
+    if (!halo_on || d->dcn_offmask || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->Cin % 64 != 0 || bn < 64 ||
+        d->groups != 1 || d->wgt_img_stride != 0)
+        return 0;
+    const int ho = d->H, wo = d->W;
+    const long long M = (long long)d->N * ho * wo;
+    const long long t16 = (long long)cdiv(wo, 16) * cdiv(ho, 8) * d->N, t32 = (long long)cdiv(wo, 32) * cdiv(ho, 8) * d->N;
+    const double e16 = (double)M / (double)(t16 * 128), e32 = (double)M / (double)(t32 * 256);
+    // the 256-pixel patch halves the weight staging per MFMA; it needs >= 2 workgroups per CU in flight to pay
+    const bool big = halo_on != 2 && e32 >= 0.9 * e16 && t32 * (d->Cout_pad / bn) >= 1024;
+    if ((big ? e32 : e16) < 0.8) return 0;
+    if (tiles) *tiles = big ? t32 : t16;
+    return big ? 2 : 1;
+}
+extern "C" int m3d_conv_bf16_variant(const m3d_conv_bf16_desc *d) { return d ? conv_bf16_variant(d, nullptr) : -1; }
 
 extern "C" int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t stream)
 {
@@ -445,9 +669,25 @@ extern "C" int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t s
     const int bn = d->Cout_pad % 128 == 0 ? 128 : (d->Cout_pad % 64 == 0 ? 64 : 32);
     a.tiles_m = cdiv(M, 128); a.tiles_n = d->Cout_pad / bn;
     a.uniform_k = (d->Cin % 64 == 0 && K % 64 == 0) ? 1 : 0;
+#ifdef BF16_TRACE
+    a.trace = g_bf16_trace;
+#endif
     const dim3 grid(a.tiles_m * a.tiles_n, d->groups), block(256);
     hipStream_t st = (hipStream_t)stream;
     const bool deform = d->dcn_offmask != nullptr;
+    long long htiles = 0;
+    const int variant = conv_bf16_variant(d, &htiles);
+    a.lane_perm = (halo_env() & 16) ? 0 : 1;
+    if (variant) {
+        a.tiles_m = (int)htiles;
+        const dim3 hgrid(a.tiles_m * a.tiles_n);
+#define HLAUNCH(BN_, TW_, BM_, WV_) hipLaunchKernelGGL((bf16_conv3x3_halo_kernel<BN_, TW_, BM_, WV_>), hgrid, dim3(WV_ * 64), 0, st, a)
+        if (variant == 2) { if (bn == 128) HLAUNCH(128, 32, 256, 8); else HLAUNCH(64, 32, 256, 8); }
+        else { if (bn == 128) HLAUNCH(128, 16, 128, 4); else HLAUNCH(64, 16, 128, 4); }
+#undef HLAUNCH
+        M3D_LAUNCH_CHECK();
+        return M3D_OK;
+    }
 #define LAUNCH(BN_, DF_) hipLaunchKernelGGL((bf16_conv_kernel<BN_, DF_>), grid, block, 0, st, a)
     if (bn == 128) { if (deform) LAUNCH(128, true); else LAUNCH(128, false); }
     else if (bn == 64) { if (deform) LAUNCH(64, true); else LAUNCH(64, false); }

@@ -234,7 +234,11 @@ class EngineBF16(Engine):
         ref = ctypes.byref(d)
         flops = 2.0 * x.n * d.Ho * d.Wo * cout * kh * kw * (flops_cin if flops_cin is not None else cin) * groups
         bn = 128 if cout_pad % 128 == 0 else (64 if cout_pad % 64 == 0 else 32)
-        kind = "bf16_conv<%d%s>" % (bn, ",deform" if om is not None else "")
+        variant = L.m3d_conv_bf16_variant(ref)          # which kernel the library runs for this descriptor
+        if variant:
+            kind = "bf16_halo<%d,%d>" % (bn, 16 * variant)
+        else:
+            kind = "bf16_conv<%d%s>" % (bn, ",deform" if om is not None else "")
         plan.ops.append((name, kind, flops, lambda st: _hip.check(L.m3d_conv_bf16_forward(ref, st)), d))
 
     def _pconv(self, plan, name, pc, x, out, stride=1, pad=0, act=0, res=None, res_mode=0, sigmoid_from=-1, om=None, out_mode=0,

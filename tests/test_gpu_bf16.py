@@ -60,7 +60,7 @@ def _nhwc16(x, cs=None):
 
 
 def _run_conv(x, wt, bias=None, bn=None, stride=1, pad=0, act=0, res=None, res_mode=0, sigmoid_from=-1, out_mode=0, om=None,
-              in_cs=None):
+              in_cs=None, variant=None):
     """Through the C ABI.  Returns [N, Cout, Ho, Wo] fp32 (bf16 outputs widened)."""
     from m3dssd_amd import _hip
     from m3dssd_amd.engine_bf16 import pack_conv_bf16
@@ -108,6 +108,8 @@ def _run_conv(x, wt, bias=None, bn=None, stride=1, pad=0, act=0, res=None, res_m
         out = torch.full((n, co + 1, ho * wo), 512.0, device=dev, dtype=torch.float32)
         d.out, d.out_img_stride = out.data_ptr(), (co + 1) * ho * wo
     d.out_mode = out_mode
+    if variant is not None:
+        assert L.m3d_conv_bf16_variant(ctypes.byref(d)) == variant
     _hip.check(L.m3d_conv_bf16_forward(ctypes.byref(d), _st()))
     torch.cuda.synchronize()
     if out_mode == 2:
@@ -163,6 +165,42 @@ def test_conv_bf16_matches_torch(case):
     elif act:
         ref = F.leaky_relu(ref, 0.01)
     got = _run_conv(x, wt, bias, bn, stride, pad, act, res, 0, sg, om, in_cs=c + 8 if c % 16 == 0 else None)
+    assert got.shape == ref.shape
+    _check(got, ref, om)
+
+
+HALO_CASES = [
+    # n, c, h, w, co, act, res, sigmoid_from, out_mode, kernel variant (m3d_conv_bf16_variant)
+    (2, 64, 15, 31, 64, 1, True, -1, 0, 1),          # 8 x 16 patches, ragged right / bottom patches, BN 64
+    (1, 128, 23, 47, 128, 1, True, -1, 0, 1),        # odd map, BN 128
+    (2, 64, 12, 20, 64, 1, True, -1, 0, 0),          # 12 x 20 map: patches 47 % full -> implicit-GEMM tile
+    (3, 64, 8, 16, 27, 0, False, 18, 1, 0),          # Cout_pad 32 stays on the implicit-GEMM tile
+    (1, 256, 12, 40, 256, 1, False, -1, 0, 0),       # 12 x 40 map: patches would be 62 % full -> implicit-GEMM tile
+    (2, 128, 16, 48, 192, 0, False, -1, 2, 1),       # planar fp32 output, Cout 192 (BN 64, 3 channel tiles)
+    (56, 64, 22, 62, 512, 1, True, -1, 0, 2),        # 8 x 32 patches / 8 waves, ragged, 4 channel tiles
+    (128, 64, 24, 96, 64, 1, False, -1, 1, 2),       # 8 x 32 patches, BN 64, fp32 NHWC output
+    (128, 128, 16, 64, 256, 1, True, -1, 0, 2),      # two 64-channel chunks: the patch buffer is refilled mid-loop
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_conv_bf16_halo_tile_matches_torch(case):
+    """3x3 / stride 1 / pad 1: the halo-tile kernels (input patch resident in LDS, K order (chunk, tap)) against torch on the
+    bf16-rounded operands; the variant the library picks is pinned so a heuristic change cannot silently drop the coverage."""
+    n, c, h, w, co, act, use_res, sg, om, variant = case
+    g = torch.Generator().manual_seed(sum(case) + 5)
+    x = _r(torch.randn(n, c, h, w, generator=g))
+    wt = _r(torch.randn(co, c, 3, 3, generator=g) / (c * 9) ** 0.5)
+    bias = torch.randn(co, generator=g) * 0.1
+    res = _r(torch.randn(n, co, h, w, generator=g)) if use_res else None
+    ref = F.conv2d(x, wt, bias, padding=1)
+    if res is not None:
+        ref = ref + res
+    if sg >= 0:
+        ref = torch.cat([F.leaky_relu(ref[:, :sg], 0.01) if act else ref[:, :sg], torch.sigmoid(ref[:, sg:])], 1)
+    elif act:
+        ref = F.leaky_relu(ref, 0.01)
+    got = _run_conv(x, wt, bias, None, 1, 1, act, res, 0, sg, om, in_cs=c + 8, variant=variant)
     assert got.shape == ref.shape
     _check(got, ref, om)
 
