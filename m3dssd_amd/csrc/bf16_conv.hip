@@ -191,7 +191,7 @@ extern "C" void m3d_bf16_conv_set_trace(void *buf) { g_bf16_trace = (long long *
 #define BTRACE()
 #endif
 
-template <int BN, bool DEFORM>
+template <int BN, bool DEFORM>      // two workgroups per CU (LDS allows it): the gather of one overlaps the MFMA section of the other
 __global__ __launch_bounds__(256) void bf16_conv_kernel(const Bf16Args a)
 {
     constexpr int BM = 128, BK = 64;
@@ -242,6 +242,31 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const Bf16Args a)
         hi0[p] = ho * a.stride - a.pad;
         wi0[p] = wo * a.stride - a.pad;
     }
+    // Deformable mode, uniform K: the sampling state of a (pixel, tap) -- 4 corner weights with the mask folded in, 4 corner
+    // offsets -- is needed by the 8 lanes that stage the pixel's 128-byte line.  Lane `chunk` of the row builds the state of
+    // piece chunk & 3 and the lanes trade states with ds_bpermute; the offsets / mask of the NEXT tap are fetched a tap ahead.
+    // (Each lane building all 4 of its pieces from offsets read at the tap change: ~4800 cycles on those K-steps against
+    // ~1650 on the others, tools/bf16_conv_trace.py; now ~2800.)
+    const int sp = chunk & 3;                                       // piece this lane produces the state of
+    const int spix = m0 + sp * 32 + rsub;
+    const bool sprod = DEFORM && spix < a.M;
+    int sh0 = 0, sw0 = 0, sbase = 0;                                // that pixel's tap-(0, 0) input position / image base
+    if (sprod) {
+        const int n = spix / a.HoWo, rem = spix - n * a.HoWo;
+        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        sbase = n * a.H * a.W; sh0 = ho * a.stride - a.pad; sw0 = wo * a.stride - a.pad;
+    }
+    float omn[3] = {0.f, 0.f, 0.f};                                 // (dh, dw, mask) of the tap whose state is built next
+    auto fetch_om = [&](int tap) __attribute__((always_inline)) {
+        if constexpr (DEFORM) {
+            const int KK = a.kh * a.kw;
+            if (sprod && tap < KK) {
+                const float *omp = a.om + (size_t)spix * a.om_cs;
+                omn[0] = omp[2 * tap]; omn[1] = omp[2 * tap + 1]; omn[2] = omp[2 * KK + tap];
+            }
+        }
+    };
+    if (DEFORM && a.uniform_k) fetch_om(0);
     unsigned woff[PB];
 #pragma unroll
     for (int p = 0; p < PB; ++p)
@@ -300,36 +325,71 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const Bf16Args a)
                 }
             }
         } else {
-            if (fresh) {      // sampling state of this thread's 4 pixels for the tap (dcn_v2_im2col_cuda.cu:18-47,150-178)
+            // sampling state of a pixel for a tap (dcn_v2_im2col_cuda.cu:18-47,150-178): corner weights (mask folded in) and
+            // corner pixel offsets inside the image
+            auto sample = [&](int h0, int w0, float dh, float dw, float mk, float (&w)[4], int (&o)[4]) __attribute__((always_inline)) {
+                float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
+                int o1 = 0, o2 = 0, o3 = 0, o4 = 0;
+                const float h_im = (float)h0 + dh;
+                const float w_im = (float)w0 + dw;
+                // h_im > -1 && w_im > -1 && h_im < H && w_im < W as ONE comparison (the signs of the sums / differences are
+                // exact), and each corner's two-sided test as one sign test.  Not a style choice: with one state per lane the
+                // four-compare form compiles to back-to-back v_cmp -> s_and_b64 chains, and on the MI355X that form gave lanes
+                // 48-63 of a wave the wrong predicate about once per thousand workgroups (run-to-run different outputs,
+                // tools/dcn_determinism.py; a check build showed the received state wrong in exactly those lanes while the
+                // prefetched offsets were right).  tests/test_gpu_bf16.py::test_dcn_bf16_run_to_run_identical guards it.
+                if (fminf(fminf(h_im, w_im) + 1.f, -fmaxf(h_im - (float)a.H, w_im - (float)a.W)) > 0.f) {
+                    const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
+                    const float lh = h_im - (float)hl, lw = w_im - (float)wl;
+                    const float uh = 1.f - lh, uw = 1.f - lw;
+                    const int hr = a.H - 2 - hl, wr = a.W - 2 - wl;          // >= 0: the high corner row / column is inside
+                    if ((hl | wl) >= 0) { w1 = uh * uw; o1 = hl * a.W + wl; }
+                    if ((hl | wr) >= 0) { w2 = uh * lw; o2 = hl * a.W + wl + 1; }
+                    if ((hr | wl) >= 0) { w3 = lh * uw; o3 = (hl + 1) * a.W + wl; }
+                    if ((hr | wr) >= 0) { w4 = lh * lw; o4 = (hl + 1) * a.W + wl + 1; }
+                }
+                w[0] = w1 * mk; w[1] = w2 * mk; w[2] = w3 * mk; w[3] = w4 * mk;
+                o[0] = o1; o[1] = o2; o[2] = o3; o[3] = o4;
+            };
+            if (fresh && uni) {
+                samp_tap = tap;
+                {
+                    float w[4] = {0.f, 0.f, 0.f, 0.f};
+                    int o[4] = {0, 0, 0, 0};
+                    if (sprod) sample(sh0 + ti, sw0 + tj, omn[0], omn[1], omn[2], w, o);
+                    u32x4 sw_, so_;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        sw_[q] = __float_as_uint(w[q]);
+                        so_[q] = (unsigned)(sbase + o[q]) * (unsigned)a.in_cs * 2u;
+                    }
+                    fetch_om(tap + 1);
+                    const unsigned lane_c = (unsigned)chunk * 16u;
+                    const int src0 = (lane & ~7) * 4;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            bw[p][q] = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute(src0 + p * 4, (int)sw_[q]));
+                            doff[p][q] = (unsigned)__builtin_amdgcn_ds_bpermute(src0 + p * 4, (int)so_[q]) + lane_c;
+                        }
+                }
+            } else if (fresh) {      // general K: the tap is per lane, every lane builds the state of its 4 pieces
                 samp_tap = tap;
                 const int KK = a.kh * a.kw;
-                const unsigned lane_c = uni ? (unsigned)chunk * 16u : 0u;
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
-                    float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f, mk = 0.f;
-                    int o1 = 0, o2 = 0, o3 = 0, o4 = 0;
+                    float w[4] = {0.f, 0.f, 0.f, 0.f};
+                    int o[4] = {0, 0, 0, 0};
                     if (rvalid[p] && kvalid) {
                         const float *omp = a.om + (size_t)(m0 + p * 32 + rsub) * a.om_cs;
-                        const float dh = omp[2 * tap], dw = omp[2 * tap + 1];
-                        mk = omp[2 * KK + tap];
-                        const float h_im = (float)(hi0[p] + ti) + dh;
-                        const float w_im = (float)(wi0[p] + tj) + dw;
-                        if (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
-                            const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
-                            const int hh = hl + 1, wh = wl + 1;
-                            const float lh = h_im - (float)hl, lw = w_im - (float)wl;
-                            const float uh = 1.f - lh, uw = 1.f - lw;
-                            if (hl >= 0 && wl >= 0) { w1 = uh * uw; o1 = hl * a.W + wl; }
-                            if (hl >= 0 && wh <= a.W - 1) { w2 = uh * lw; o2 = hl * a.W + wh; }
-                            if (hh <= a.H - 1 && wl >= 0) { w3 = lh * uw; o3 = hh * a.W + wl; }
-                            if (hh <= a.H - 1 && wh <= a.W - 1) { w4 = lh * lw; o4 = hh * a.W + wh; }
-                        }
+                        sample(hi0[p] + ti, wi0[p] + tj, omp[2 * tap], omp[2 * tap + 1], omp[2 * KK + tap], w, o);
                     }
-                    bw[p][0] = w1 * mk; bw[p][1] = w2 * mk; bw[p][2] = w3 * mk; bw[p][3] = w4 * mk;
-                    doff[p][0] = (unsigned)(pix_base[p] + o1) * (unsigned)a.in_cs * 2u + lane_c;
-                    doff[p][1] = (unsigned)(pix_base[p] + o2) * (unsigned)a.in_cs * 2u + lane_c;
-                    doff[p][2] = (unsigned)(pix_base[p] + o3) * (unsigned)a.in_cs * 2u + lane_c;
-                    doff[p][3] = (unsigned)(pix_base[p] + o4) * (unsigned)a.in_cs * 2u + lane_c;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        bw[p][q] = w[q];
+                        doff[p][q] = (unsigned)(pix_base[p] + o[q]) * (unsigned)a.in_cs * 2u;
+                    }
                 }
             }
             if (uni) {
@@ -651,7 +711,7 @@ extern "C" int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t s
     if (d->out_mode == 1) M3D_REQUIRE(d->out_cs % 4 == 0 && ((uintptr_t)d->out & 15) == 0, "conv_bf16: fp32 NHWC output needs out_cs %% 4 == 0");
     if (d->res) M3D_REQUIRE(d->res_cs % 4 == 0 && ((uintptr_t)d->res & 7) == 0, "conv_bf16: residual view alignment");
     if (d->wgt_img_stride) M3D_REQUIRE((ho * wo) % 128 == 0, "conv_bf16: per-image weights need Ho*Wo %% 128 == 0");
-    if (d->dcn_offmask) M3D_REQUIRE(d->stride == 1 && d->groups == 1, "conv_bf16: deformable mode is stride 1, ungrouped");
+    if (d->dcn_offmask) M3D_REQUIRE(d->stride == 1 && d->groups == 1 && taps <= 9, "conv_bf16: deformable mode is stride 1, ungrouped, <= 9 taps");
 
     Bf16Args a;
     a.in = d->in; a.wgt = d->wgt; a.out = d->out; a.scale = d->scale; a.shift = d->shift; a.res = d->res; a.om = d->dcn_offmask;

@@ -205,6 +205,38 @@ def test_conv_bf16_halo_tile_matches_torch(case):
     _check(got, ref, om)
 
 
+def test_dcn_bf16_run_to_run_identical():
+    """Deformable mode at full-size grids (3840 workgroups): 4 launches on the same operands must agree bit for bit.  The
+    sampling state is traded between lanes (ds_bpermute) and built from predicates; a first version of that code produced wrong
+    predicates in lanes 48-63 of a wave about once per thousand workgroups -- a rate only a large grid shows."""
+    from m3dssd_amd import _hip
+    from m3dssd_amd.engine_bf16 import pack_conv_bf16
+    L, dev = _hip.lib(), _dev()
+    for cin, cout, h, w, b, k in [(128, 128, 48, 160, 64, 3), (256, 256, 24, 80, 64, 3), (128, 128, 48, 160, 64, 1)]:
+        g = torch.Generator().manual_seed(cin + k)
+        x = torch.randn(b * h * w, cin, generator=g).to(BF16).to(dev)
+        wp, kpad = pack_conv_bf16(torch.randn(cout, cin, k, k, generator=g) / (k * k * cin) ** 0.5, None, None, dev)
+        kk = k * k
+        om = torch.cat([torch.randn(b * h * w, 2 * kk, generator=g) * 2.0, torch.rand(b * h * w, kk, generator=g),
+                        torch.zeros(b * h * w, 32 - 3 * kk)], 1).contiguous().to(dev)
+        outs = []
+        for _ in range(4):
+            out = torch.zeros(b * h * w, cout, device=dev, dtype=BF16)
+            d = _hip.ConvBf16Desc()
+            d.inp, d.in_cs, d.N, d.H, d.W, d.Cin = x.data_ptr(), cin, b, h, w, cin
+            d.wgt, d.Cout, d.Cout_pad, d.Kpad = wp.data_ptr(), cout, wp.shape[0], kpad
+            d.kh = d.kw = k
+            d.stride, d.pad, d.Ho, d.Wo = 1, k // 2, h, w
+            d.out, d.out_cs, d.out_mode, d.act, d.sigmoid_from, d.groups = out.data_ptr(), cout, 0, 1, -1, 1
+            d.dcn_offmask, d.dcn_om_cs = om.data_ptr(), 32
+            _hip.check(L.m3d_conv_bf16_forward(ctypes.byref(d), _st()))
+            torch.cuda.synchronize()
+            outs.append(out)
+        assert torch.isfinite(outs[0].float()).all()
+        for o in outs[1:]:
+            assert torch.equal(outs[0], o), (cin, k, int((outs[0] != o).sum()))
+
+
 def test_conv_bf16_residual_before_affine_and_argument_checks():
     """res_mode 1 (ANAB: BN after the residual add) and the C-ABI argument validation."""
     from m3dssd_amd import _hip

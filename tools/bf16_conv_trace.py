@@ -1,5 +1,5 @@
 """In-kernel timeline of bf16_conv_kernel (diagnostic build `make -C m3dssd_amd/csrc trace`, -DBF16_TRACE):
-    python tools/bf16_conv_trace.py [Cin] [Cout] [H] [W] [B] [k]
+    python tools/bf16_conv_trace.py [Cin] [Cout] [H] [W] [B] [k] [offset std: deformable mode] [v: per-step table]
 Per K-step of wave 0 of every workgroup: cycles from loop top to loads issued, to MFMAs issued, to staging writes done
 (vmcnt waits + ds_write), to barrier passed."""
 import ctypes
@@ -18,6 +18,7 @@ H = int(sys.argv[3]) if len(sys.argv) > 3 else 24
 W = int(sys.argv[4]) if len(sys.argv) > 4 else 80
 B = int(sys.argv[5]) if len(sys.argv) > 5 else 64
 k = int(sys.argv[6]) if len(sys.argv) > 6 else 3
+deform = float(sys.argv[7]) if len(sys.argv) > 7 else -1.0      # >= 0: deformable mode, offsets ~ N(0, deform)
 dev = torch.device("cuda:0")
 L = ctypes.CDLL("m3dssd_amd/csrc/build/libm3dssd_hip_trace.so")
 L.m3d_conv_bf16_forward.argtypes = [ctypes.POINTER(_hip.ConvBf16Desc), ctypes.c_void_p]
@@ -31,6 +32,10 @@ d.wgt, d.Cout, d.Cout_pad, d.Kpad = wp.data_ptr(), cout, wp.shape[0], kpad
 d.kh = d.kw = k
 d.stride, d.pad, d.Ho, d.Wo = 1, k // 2, H, W
 d.out, d.out_cs, d.out_mode, d.act, d.sigmoid_from, d.groups = out.data_ptr(), cout, 0, 1, -1, 1
+if deform >= 0:
+    om = torch.cat([torch.randn(B * H * W, 2 * k * k, device=dev) * deform, torch.rand(B * H * W, k * k, device=dev),
+                    torch.zeros(B * H * W, 32 - 3 * k * k, device=dev)], 1).contiguous()
+    d.dcn_offmask, d.dcn_om_cs = om.data_ptr(), 32
 bn = 128 if wp.shape[0] % 128 == 0 else (64 if wp.shape[0] % 64 == 0 else 32)
 grid = (B * H * W + 127) // 128 * (wp.shape[0] // bn)
 trace = torch.zeros(grid * 160, dtype=torch.int64, device=dev)
@@ -64,3 +69,7 @@ print("per K-step medians (ticks of the 100 MHz? s_memtime counter = shader cycl
       % (int(np.median(issue)), int(np.median(mfma)), int(np.median(store)),
          (" | barrier %d" % int(np.median(nxt - s[:, :, 3]))) if nxt is not None else ""))
 print("K-step period median %d" % int(np.median(np.diff(top, axis=1))))
+if len(sys.argv) > 8:       # per-K-step medians
+    for kk in range(n):
+        print("step %2d: issue %5d mfma %5d store %5d%s" % (kk, int(np.median(issue[:, kk])), int(np.median(mfma[:, kk])),
+              int(np.median(store[:, kk])), (" barrier %5d" % int(np.median((nxt - s[:, :, 3])[:, kk]))) if nxt is not None else ""))
