@@ -508,14 +508,16 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const Bf16Args a)
 // conflict-free (the identity map puts 8 + 8 pixels of two rows in a group: 2-way conflicts on every read).
 #define HT_PS 144                        // bytes per halo pixel (128 + 16 pad)
 template <int BN, int TW, int BM, int WAVES>     // LDS allows 2 workgroups per CU (3 for the small tile): hold the register file to that
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVES / 2, WAVES / 2 + (BN * BM <= 64 * 128))))
+__global__ __launch_bounds__(WAVES * 64)
+__attribute__((amdgpu_waves_per_eu(WAVES / 2, WAVES / 2 + (BN * BM <= 64 * 128) + (BN * BM <= 32 * 128))))
 void bf16_conv3x3_halo_kernel(const Bf16Args a)
 {
     constexpr int TH = BM / TW, HW = TW + 2, HPIX = (TH + 2) * HW;
     constexpr int NT = WAVES * 64, RPP = NT / 8;       // threads; pixels (or weight rows) staged per pass
-    constexpr int WN = 2, WM = WAVES / 2;
+    constexpr int WN = BN >= 64 ? 2 : 1, WM = WAVES / WN;   // BN 32 (offset / mask convs: HBM-bound): every wave takes all channels
     constexpr int TN = BN / (32 * WN), TM = BM / (32 * WM);
     constexpr int PB = BN * 8 / NT;                    // weight pieces (16 B) per thread per K-step
+    static_assert(PB >= 1 && TM >= 1 && TN >= 1, "tile shape");
     constexpr int HP = (HPIX * 8 + NT - 1) / NT;       // halo pieces per thread per chunk
     constexpr int HBYTES = HPIX * HT_PS;
     __shared__ __attribute__((aligned(16))) unsigned char lds[HBYTES + 2 * BN * 128];
@@ -676,7 +678,7 @@ static int conv_bf16_variant(const m3d_conv_bf16_desc *d, long long *tiles)
 {
     const int halo_on = halo_env() & 15;
     const int bn = d->Cout_pad % 128 == 0 ? 128 : (d->Cout_pad % 64 == 0 ? 64 : 32);
-    if (!halo_on || d->dcn_offmask || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->Cin % 64 != 0 || bn < 64 ||
+    if (!halo_on || d->dcn_offmask || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->Cin % 64 != 0 ||
         d->groups != 1 || d->wgt_img_stride != 0)
         return 0;
     const int ho = d->H, wo = d->W;
@@ -684,7 +686,7 @@ static int conv_bf16_variant(const m3d_conv_bf16_desc *d, long long *tiles)
     const long long t16 = (long long)cdiv(wo, 16) * cdiv(ho, 8) * d->N, t32 = (long long)cdiv(wo, 32) * cdiv(ho, 8) * d->N;
     const double e16 = (double)M / (double)(t16 * 128), e32 = (double)M / (double)(t32 * 256);
     // the 256-pixel patch halves the weight staging per MFMA; it needs >= 2 workgroups per CU in flight to pay
-    const bool big = halo_on != 2 && e32 >= 0.9 * e16 && t32 * (d->Cout_pad / bn) >= 1024;
+    const bool big = halo_on != 2 && bn >= 64 && e32 >= 0.9 * e16 && t32 * (d->Cout_pad / bn) >= 1024;
     if ((big ? e32 : e16) < 0.8) return 0;
     if (tiles) *tiles = big ? t32 : t16;
     return big ? 2 : 1;
@@ -743,7 +745,7 @@ extern "C" int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t s
         const dim3 hgrid(a.tiles_m * a.tiles_n);
 #define HLAUNCH(BN_, TW_, BM_, WV_) hipLaunchKernelGGL((bf16_conv3x3_halo_kernel<BN_, TW_, BM_, WV_>), hgrid, dim3(WV_ * 64), 0, st, a)
         if (variant == 2) { if (bn == 128) HLAUNCH(128, 32, 256, 8); else HLAUNCH(64, 32, 256, 8); }
-        else { if (bn == 128) HLAUNCH(128, 16, 128, 4); else HLAUNCH(64, 16, 128, 4); }
+        else { if (bn == 128) HLAUNCH(128, 16, 128, 4); else if (bn == 64) HLAUNCH(64, 16, 128, 4); else HLAUNCH(32, 16, 128, 4); }
 #undef HLAUNCH
         M3D_LAUNCH_CHECK();
         return M3D_OK;

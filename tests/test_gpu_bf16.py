@@ -174,7 +174,8 @@ HALO_CASES = [
     (2, 64, 15, 31, 64, 1, True, -1, 0, 1),          # 8 x 16 patches, ragged right / bottom patches, BN 64
     (1, 128, 23, 47, 128, 1, True, -1, 0, 1),        # odd map, BN 128
     (2, 64, 12, 20, 64, 1, True, -1, 0, 0),          # 12 x 20 map: patches 47 % full -> implicit-GEMM tile
-    (3, 64, 8, 16, 27, 0, False, 18, 1, 0),          # Cout_pad 32 stays on the implicit-GEMM tile
+    (3, 64, 8, 16, 27, 0, False, 18, 1, 1),          # offset / mask conv: Cout_pad 32 (every wave takes all channels), fp32 out
+    (2, 128, 21, 45, 27, 0, False, 18, 1, 1),        # the same on a ragged map, two chunks
     (1, 256, 12, 40, 256, 1, False, -1, 0, 0),       # 12 x 40 map: patches would be 62 % full -> implicit-GEMM tile
     (2, 128, 16, 48, 192, 0, False, -1, 2, 1),       # planar fp32 output, Cout 192 (BN 64, 3 channel tiles)
     (56, 64, 22, 62, 512, 1, True, -1, 0, 2),        # 8 x 32 patches / 8 waves, ragged, 4 channel tiles
