@@ -67,26 +67,44 @@ __global__ __launch_bounds__(512) void bf16_frontend_kernel(const FrontArgs a)
     {
         const float *im = static_cast<const float *>(a.img) + (size_t)n * 3 * H * W;
         const unsigned char *frame = static_cast<const unsigned char *>(a.img) + (size_t)n * a.img_h * a.img_w * 3;
-        for (int i = tid; i < FE_IMH * FE_IMS; i += 512) {
+        // all loads of the thread are issued before the first conversion: the workgroup is alone on its CU (129 KB of LDS), so
+        // a load -> convert -> store loop would pay one memory round trip per iteration with nothing to hide it
+        constexpr int NI = (FE_IMH * FE_IMS + 511) / 512;
+        float v[NI][3];
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int i = tid + it * 512;
             const int r = i / FE_IMS, q = i - r * FE_IMS;
             const int h = YI + r, w = XI + q;
-            float v[3] = {0.f, 0.f, 0.f};
-            if (q < FE_IMW && h >= 0 && h < H && w >= 0 && w < W) {
+            v[it][0] = v[it][1] = v[it][2] = 0.f;
+            if (i < FE_IMH * FE_IMS && q < FE_IMW && h >= 0 && h < H && w >= 0 && w < W) {
                 if (a.is_u8) {
+                    if (h < a.img_h && w < a.img_w) {
+                        const unsigned char *px = frame + ((size_t)h * a.img_w + w) * 3;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {             // plane c of the RGB tensor = BGR channel 2 - c of the frame
-                        const int cb = 2 - c;
-                        float x = (h < a.img_h && w < a.img_w) ? (float)frame[((size_t)h * a.img_w + w) * 3 + cb] : 0.f;
-                        x = x / 255.0f;
-                        x = x - a.mean[cb];
-                        v[c] = x / a.stds[cb];
+                        for (int c = 0; c < 3; ++c) v[it][c] = (float)px[2 - c];   // plane c of the RGB tensor = BGR channel 2 - c
                     }
                 } else {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) v[c] = im[((size_t)c * H + h) * W + w];
+                    for (int c = 0; c < 3; ++c) v[it][c] = im[((size_t)c * H + h) * W + w];
                 }
             }
-            *reinterpret_cast<u32x2 *>(imt + (size_t)i * 8) = u32x2{fpack(v[0], v[1]), fpack(v[2], 0.f)};
+        }
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int i = tid + it * 512;
+            const int r = i / FE_IMS, q = i - r * FE_IMS;
+            const int h = YI + r, w = XI + q;
+            if (a.is_u8 && i < FE_IMH * FE_IMS && q < FE_IMW && h >= 0 && h < H && w >= 0 && w < W) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int cb = 2 - c;
+                    float x = v[it][c] / 255.0f;
+                    x = x - a.mean[cb];
+                    v[it][c] = x / a.stds[cb];
+                }
+            }
+            if (i < FE_IMH * FE_IMS) *reinterpret_cast<u32x2 *>(imt + (size_t)i * 8) = u32x2{fpack(v[it][0], v[it][1]), fpack(v[it][2], 0.f)};
         }
     }
     __syncthreads();
