@@ -12,12 +12,21 @@
 //   and i + 2 in flight under the MFMAs of chunk i (two register sets: an L2 round trip is longer than one chunk of MFMAs).  16-byte LDS chunks are XOR-swizzled by the row so that staging writes and fragment
 //   reads are bank-conflict free.  Output: planar fp32 out[img][c][HW] (what m3d_anchor_select / m3d_align_offsets /
 //   m3d_bundle_outputs consume).
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+#ifdef BF16_TRACE
+static long long *g_head_trace = nullptr;
+extern "C" void m3d_bf16_head_set_trace(void *buf) { g_head_trace = (long long *)buf; }
+#define HTRACE() do { if (trp && tid == 0 && tri < 32) trp[tri++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define HTRACE()
+#endif
 
 struct HeadArgs {
     const void *in;                 // bf16 [M][in_cs]
@@ -26,6 +35,9 @@ struct HeadArgs {
     float *out;                     // planar: out + g*out_goff + img*out_img_stride + c*HW + p
     long long out_goff, out_img_stride;
     int in_cs, M, HW, Cout, Cout_pad, tiles_m;
+#ifdef BF16_TRACE
+    long long *trace;
+#endif
 };
 
 __device__ __forceinline__ unsigned hpack(float lo, float hi)
@@ -42,21 +54,22 @@ __device__ __forceinline__ int wst_off(int r, int c) { return r * 128 + ((c ^ ((
 __global__ __launch_bounds__(512) void bf16_head_mlp_kernel(const HeadArgs a)
 {
     constexpr int CIN = 128, HID = 256;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[65536 + 2 * 32768];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[65536 + 2 * 32768 + 1152 * 4];
     unsigned char *act = lds, *wst = lds + 65536;
+    float *aff = reinterpret_cast<float *>(lds + 65536 + 2 * 32768);      // s1 t1 s2 t2 [256 each], s3 t3 [64 each] of this head
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef BF16_TRACE
+    long long *trp = a.trace ? a.trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr;
+    int tri = 0;
+#endif
+    HTRACE();
     // layers 1, 2: wave = 64 px x 64 ch (2 x 2 tiles); layer 3 (64 channels): wave = 32 px x 32 ch
     const int wm = (wave >> 2) * 64, wn = (wave & 3) * 64;
     const int wm3 = (wave >> 1) * 32, wn3 = (wave & 1) * 32;
     const int l31 = lane & 31, lh = lane >> 5;
-    int tile = blockIdx.x;
-    {
-        const int nt = a.tiles_m, q = nt >> 3, r = nt & 7, xcd = tile & 7, idx = tile >> 3;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int m0 = tile * 128, g = blockIdx.y;
+    const int g = blockIdx.y;
     const __bf16 *w1 = (const __bf16 *)a.w1 + (size_t)g * HID * CIN;
     const __bf16 *w2 = (const __bf16 *)a.w2 + (size_t)g * HID * HID;
     const __bf16 *w3 = (const __bf16 *)a.w3 + (size_t)g * a.Cout_pad * HID;
@@ -81,23 +94,32 @@ __global__ __launch_bounds__(512) void bf16_head_mlp_kernel(const HeadArgs a)
     };
 #define IC(n) std::integral_constant<int, n>{}
 
-    // ---- stage the input tile [128 px][128 ch] (256-byte rows); first two weight chunks on their way -------------------------
-    {
-        const int c16 = tid & 15, r0 = tid >> 4;         // 16 pieces per row, 32 rows per pass
-        u32x4 v[4];
+    // ---- affine parameters of the head -> LDS once (read from global memory inside write_hidden they cost a memory round trip
+    // per layer with the whole CU waiting: the workgroup is alone on its CU) ---------------------------------------------------
+    if (tid < HID) {
+        aff[tid] = a.s1[g * HID + tid]; aff[HID + tid] = a.t1[g * HID + tid];
+        aff[2 * HID + tid] = a.s2[g * HID + tid]; aff[3 * HID + tid] = a.t2[g * HID + tid];
+    }
+    if (tid < 64) {
+        aff[4 * HID + tid] = tid < a.Cout ? a.s3[g * a.Cout + tid] : 0.f;
+        aff[4 * HID + 64 + tid] = tid < a.Cout ? a.t3[g * a.Cout + tid] : 0.f;
+    }
+    // The workgroup walks over pixel tiles (grid.x ~ CUs / heads): the next tile's input and the first two weight chunks are
+    // fetched while the current tile computes (in-kernel trace of the one-tile-per-workgroup form: 4400 of 28000 cycles waiting
+    // for the input tile, 5100 in the 4-byte output stores, 2 x 3400 in the hidden-tile writes).
+    const int c16 = tid & 15, r0 = tid >> 4;             // input staging: 16 pieces per row, 32 rows per pass
+    u32x4 vin[4];
+    auto load_input = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const int m = m0 + p * 32 + r0;
-            v[p] = u32x4{0u, 0u, 0u, 0u};
-            if (m < a.M) v[p] = *reinterpret_cast<const u32x4 *>((const __bf16 *)a.in + (size_t)m * a.in_cs + c16 * 8);
+            const int m = tile * 128 + p * 32 + r0;
+            vin[p] = u32x4{0u, 0u, 0u, 0u};
+            if (tile < a.tiles_m && m < a.M) vin[p] = *reinterpret_cast<const u32x4 *>((const __bf16 *)a.in + (size_t)m * a.in_cs + c16 * 8);
         }
-        load_chunk(IC(0), IC(0));
-        load_chunk(IC(1), IC(1));
-#pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4 *>(act + act_off(p * 32 + r0, c16, 256)) = v[p];
-        store_chunk(IC(0), IC(0), IC(0));
-    }
-    __syncthreads();
+    };
+    load_input(blockIdx.x);
+    load_chunk(IC(0), IC(0));
+    load_chunk(IC(1), IC(1));
 
     // ---- fragment addresses, hoisted: every term that depends on the lane is computed ONCE (a VALU instruction issued next
     // to a SIMD's MFMA stream costs it ~12 cycles on this part); what varies inside the loops is an immediate offset --------
@@ -150,11 +172,14 @@ __global__ __launch_bounds__(512) void bf16_head_mlp_kernel(const HeadArgs a)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 s4 = *reinterpret_cast<const f32x4 *>(sc + cb + 8 * q), t4 = *reinterpret_cast<const f32x4 *>(sh + cb + 8 * q);
-                    float v[4];
+                    // packed fp32 (v_pk_fma_f32 / v_pk_mul_f32): the hidden-tile writes are VALU-bound (3300 cycles per layer)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = leaky(acc[j][i][4 * q + e] * s4[e] + t4[e]);
-                    pk[q][0] = hpack(v[0], v[1]);
-                    pk[q][1] = hpack(v[2], v[3]);
+                    for (int e = 0; e < 4; e += 2) {
+                        const f32x2 x = {acc[j][i][4 * q + e], acc[j][i][4 * q + e + 1]};
+                        const f32x2 r = x * f32x2{s4[e], s4[e + 1]} + f32x2{t4[e], t4[e + 1]};
+                        const f32x2 l = r * M3D_LEAKY_SLOPE;
+                        pk[q][e >> 1] = hpack(fmaxf(r[0], l[0]), fmaxf(r[1], l[1]));
+                    }
                 }
 #pragma unroll
                 for (int q = 0; q < 4; q += 2)
@@ -173,40 +198,57 @@ __global__ __launch_bounds__(512) void bf16_head_mlp_kernel(const HeadArgs a)
         }
     };
 
-    const float *s1 = a.s1 + g * HID, *t1 = a.t1 + g * HID, *s2 = a.s2 + g * HID, *t2 = a.t2 + g * HID;
-    // step i: [load chunk i+2 -> register set i&1]  MFMAs of chunk i (LDS buffer i&1)  [store chunk i+1 -> buffer (i+1)&1]  barrier
+    const float *s1 = aff, *t1 = aff + HID, *s2 = aff + 2 * HID, *t2 = aff + 3 * HID, *s3 = aff + 4 * HID, *t3p = aff + 4 * HID + 64;
+    for (int tile = blockIdx.x; tile < a.tiles_m; tile += gridDim.x) {
+    const int m0 = tile * 128;
+    // ---- stage the input tile [128 px][128 ch] (256-byte rows) and weight chunk 0; the next tile's input goes in flight --------
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4 *>(act + act_off(p * 32 + r0, c16, 256)) = vin[p];
+    store_chunk(IC(0), IC(0), IC(0));
+    load_input(tile + gridDim.x);
+    __syncthreads();
+    HTRACE();
+    // step i: [load chunk i+2 -> register set i&1]  [store chunk i+1 -> buffer (i+1)&1: free since the barrier of step i-1]
+    // MFMAs of chunk i (LDS buffer i&1)  barrier -- the staging writes (13 LDS cycles per ds_write_b128) run under the MFMAs
     // ---- layer 1: K = 128 (chunks 0, 1) ------------------------------------------------------------------------------------
     zero_acc();
     load_chunk(IC(2), IC(0));
-    mma_chunk(IC(0), IC(0), IC(256));
     store_chunk(IC(1), IC(1), IC(1));
+    mma_chunk(IC(0), IC(0), IC(256));
     __syncthreads();
+    HTRACE();
     load_chunk(IC(3), IC(1));
-    mma_chunk(IC(1), IC(1), IC(256));
     store_chunk(IC(2), IC(0), IC(0));
+    mma_chunk(IC(1), IC(1), IC(256));
     __syncthreads();                                      // every wave is done reading the input tile
     write_hidden(s1, t1);
     __syncthreads();
+    HTRACE();
     // ---- layer 2: K = 256 (chunks 2..5), hidden tile read from and written back to the same LDS region ----------------------
     zero_acc();
     load_chunk(IC(4), IC(0));
-    mma_chunk(IC(0), IC(0), IC(512));
     store_chunk(IC(3), IC(1), IC(1));
+    mma_chunk(IC(0), IC(0), IC(512));
     __syncthreads();
+    HTRACE();
     load_chunk(IC(5), IC(1));
-    mma_chunk(IC(1), IC(1), IC(512));
     store_chunk(IC(4), IC(0), IC(0));
+    mma_chunk(IC(1), IC(1), IC(512));
     __syncthreads();
+    HTRACE();
     load_chunk(IC(6), IC(0));
-    mma_chunk(IC(0), IC(2), IC(512));
     store_chunk(IC(5), IC(1), IC(1));
+    mma_chunk(IC(0), IC(2), IC(512));
     __syncthreads();
+    HTRACE();
     load_chunk(IC(7), IC(1));
-    mma_chunk(IC(1), IC(3), IC(512));
     store_chunk(IC(6), IC(0), IC(0));
+    mma_chunk(IC(1), IC(3), IC(512));
     __syncthreads();
+    HTRACE();
     write_hidden(s2, t2);
     __syncthreads();
+    HTRACE();
     // ---- layer 3: K = 256 (chunks 6..9), 64 output channels: wave = 32 px x 32 ch ---------------------------------------------
     f32x16 o;
 #pragma unroll
@@ -223,32 +265,57 @@ __global__ __launch_bounds__(512) void bf16_head_mlp_kernel(const HeadArgs a)
         }
     };
     load_chunk(IC(8), IC(0));
-    mma3(IC(0), IC(0));
     store_chunk(IC(7), IC(1), IC(1));
+    mma3(IC(0), IC(0));
     __syncthreads();
+    HTRACE();
     load_chunk(IC(9), IC(1));
-    mma3(IC(1), IC(1));
     store_chunk(IC(8), IC(0), IC(0));
+    mma3(IC(1), IC(1));
     __syncthreads();
-    mma3(IC(0), IC(2));
+    HTRACE();
     store_chunk(IC(9), IC(1), IC(1));
+    load_chunk(IC(0), IC(0));                             // both register sets are free: the next tile's first two chunks
+    load_chunk(IC(1), IC(1));
+    mma3(IC(0), IC(2));
     __syncthreads();
+    HTRACE();
     mma3(IC(1), IC(3));
-#undef IC
-    // ---- output: lane = pixel, channels wn3 + 8q + 4*lh + e; planar fp32 --------------------------------------------------------
-    const float *s3 = a.s3 + g * a.Cout, *t3p = a.t3 + g * a.Cout;
-    const int m = m0 + wm3 + l31;
-    if (m < a.M) {
-        const int img = m / a.HW, p = m - img * a.HW;
-        float *op = a.out + g * a.out_goff + (size_t)img * a.out_img_stride + p;
+    HTRACE();
+    // ---- output: accumulators (lane = pixel, channels wn3 + 8q + 4*lh + e) -> LDS [64 ch][128 px] fp32 -> planar fp32 rows,
+    // 16 bytes per lane when the tile lies inside one image (4-byte stores straight from the accumulators: 5100 cycles) --------
+    __syncthreads();                                      // every wave is done with the hidden tile
+    HTRACE();
+    float *ot = reinterpret_cast<float *>(act);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = wn3 + 8 * q + 4 * lh + e;
-                if (c < a.Cout) op[(size_t)c * a.HW] = o[4 * q + e] * s3[c] + t3p[c];
+        for (int e = 0; e < 4; ++e) ot[(wn3 + 8 * q + 4 * lh + e) * 128 + wm3 + l31] = o[4 * q + e];
+    __syncthreads();
+    if (a.HW % 128 == 0) {
+        const int img = m0 / a.HW, p0 = m0 - img * a.HW;
+        float *ob = a.out + g * a.out_goff + (size_t)img * a.out_img_stride + p0;
+        for (int i = tid; i < a.Cout * 32; i += 512) {
+            const int c = i >> 5, p4 = (i & 31) * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(ot + c * 128 + p4);
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = v[e] * s3[c] + t3p[c];
+            *reinterpret_cast<f32x4 *>(ob + (size_t)c * a.HW + p4) = r;
+        }
+    } else {
+        for (int i = tid; i < a.Cout * 128; i += 512) {
+            const int c = i >> 7, m = m0 + (i & 127);
+            if (m < a.M) {
+                const int img = m / a.HW, pp = m - img * a.HW;
+                a.out[g * a.out_goff + (size_t)img * a.out_img_stride + (size_t)c * a.HW + pp] = ot[i] * s3[c] + t3p[c];
             }
+        }
     }
+    __syncthreads();                                      // the next tile's input overwrites the region
+    HTRACE();
+    }
+#undef IC
 }
 
 extern "C" int m3d_head_mlp_bf16_forward(const m3d_head_bf16_desc *d, m3d_stream_t stream)
@@ -262,7 +329,18 @@ extern "C" int m3d_head_mlp_bf16_forward(const m3d_head_bf16_desc *d, m3d_stream
     a.in = d->in; a.w1 = d->w1; a.w2 = d->w2; a.w3 = d->w3; a.s1 = d->s1; a.t1 = d->t1; a.s2 = d->s2; a.t2 = d->t2;
     a.s3 = d->s3; a.t3 = d->t3; a.out = d->out; a.out_goff = d->out_group_off; a.out_img_stride = d->out_img_stride;
     a.in_cs = d->in_cs; a.M = (int)d->M; a.HW = d->HW; a.Cout = d->Cout; a.Cout_pad = d->Cout_pad; a.tiles_m = cdiv(d->M, 128);
-    hipLaunchKernelGGL(bf16_head_mlp_kernel, dim3(a.tiles_m, d->groups), dim3(512), 0, (hipStream_t)stream, a);
+#ifdef BF16_TRACE
+    a.trace = g_head_trace;
+#endif
+    // one workgroup per CU (132 KB of LDS): the CUs are split between the heads of the launch and every workgroup walks tiles
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    }
+    const int nb = std::max(1, std::min(a.tiles_m, ncu / d->groups));
+    hipLaunchKernelGGL(bf16_head_mlp_kernel, dim3(nb, d->groups), dim3(512), 0, (hipStream_t)stream, a);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
 }
