@@ -85,6 +85,8 @@ def cpu_baseline(sd, budget_s=10.0):
 def kernel_symbol(label):
     """engine label -> demangled kernel name as rocprofv3 prints it."""
     import re
+    if label.startswith("bf16_anab"):
+        return "bf16_anab_attend_kernel(AnabArgs)"
     if label.startswith("bf16_halo"):
         bn, tw = re.findall(r"\d+", label.split("<", 1)[1])[:2]
         return "void bf16_conv3x3_halo_kernel<%s, %s, %d, %d>(Bf16Args)" % (bn, tw, 8 * int(tw), 4 if tw == "16" else 8)
@@ -235,7 +237,7 @@ def main():
         a[1] += flops
         a[2] += 1
     # MFMA-bound kernel families (everything else is a small HBM/latency-bound helper)
-    igemm = {k: v for k, v in per_kind.items() if k.startswith(("igemm", "wino", "head_mlp", "conv_wave", "bf16_conv", "bf16_halo"))}
+    igemm = {k: v for k, v in per_kind.items() if k.startswith(("igemm", "wino", "head_mlp", "conv_wave", "bf16_conv", "bf16_halo", "bf16_anab"))}
     dominant = max(igemm, key=lambda k: igemm[k][0])
     gpu_ms_all = sum(v[0] for v in per_kind.values())
     breakdown = {k: round(v[0], 3) for k, v in sorted(per_kind.items(), key=lambda kv: -kv[1][0])}

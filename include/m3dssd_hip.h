@@ -211,6 +211,14 @@ int m3d_frontend_bf16_forward(const void *img, int is_u8, int img_h, int img_w, 
                               const void *w_stem, const float *s_stem, const float *t_stem, const void *w_l0, const float *s_l0,
                               const float *t_l0, const void *w_l1, const float *s_l1, const float *t_l1, void *out, int out_cs,
                               int N, int H, int W, m3d_stream_t stream);
+/* ANAB attention of the bf16 path in one launch (model/module/attention.py:207-211 + the BatchNorm / LeakyReLU after the block):
+ * out[p] = act((softmax_k(q[p] . khat[k]) @ vhat + res[p]) * scale + shift) per image, replacing the logits GEMM / row softmax /
+ * P.V GEMM sequence (m3d_conv_bf16_forward with per-image weights, m3d_softmax_rows_bf16).  q bf16 [B*HW][q_cs] (channels
+ * [Ck, Ck_pad) zero), khat bf16 [B][keys_pad][Ck_pad], vhatT bf16 [B][Cv][keys_pad] (rows >= keys ignored), res bf16 [B*HW][res_cs]
+ * or NULL, scale / shift fp32 [Cv] or NULL, out bf16 [B*HW][out_cs].  Built for Ck_pad = 192, Cv = 128; HW % 128 == 0. */
+int m3d_anab_attend_bf16(const void *q, int q_cs, const void *khat, const void *vhatT, int B, int HW, int Ck_pad, int keys,
+                         int keys_pad, int Cv, const void *res, int res_cs, const float *scale, const float *shift, int act,
+                         void *out, int out_cs, m3d_stream_t stream);
 int m3d_maxpool2x2_bf16(const void *in, int in_cs, void *out, int out_cs, int N, int H, int W, int C, m3d_stream_t stream);
 int m3d_upsample2x_add_bf16(const void *in, int in_cs, const float *wgt /*[4][4][C] fp32*/, const void *skip, int skip_cs,
                             void *out, int out_cs, int N, int H, int W, int C, m3d_stream_t stream);

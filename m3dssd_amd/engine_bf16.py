@@ -25,6 +25,7 @@ from ._hip import ConvBf16Desc, HeadBf16Desc
 from .engine import BN_EPS, PSP_SIZES, Engine, _Plan, _rup, _Stream
 
 BF16 = torch.bfloat16
+FUSED_ANAB = os.environ.get("M3D_BF16_FUSED_ANAB", "1") != "0"
 FUSED_HEADS = os.environ.get("M3D_BF16_FUSED_HEADS", "1") != "0"
 FUSED_FRONT = os.environ.get("M3D_BF16_FUSED_FRONT", "1") != "0"
 
@@ -528,6 +529,15 @@ class EngineBF16(Engine):
             khat.data_ptr(), khat16.data_ptr(), khat.numel(), st)))
         self._op(plan, "anab.vhat_bf16", "convert", lambda st: _hip.check(L.m3d_f32_to_bf16(
             vhatT.data_ptr(), vhat16.data_ptr(), vhatT.numel(), st)))
+        if FUSED_ANAB and ck_pad == 192 and cv == 128:
+            # logits + softmax + P.V in one launch: the fp32 logits / bf16 probabilities (1.1 GB at bs = 64) never reach HBM
+            sc, sh = P["anab.bn.scale"], P["anab.bn.shift"]
+            plan.keep += [sc, sh]
+            self._op(plan, "anab.attend", "bf16_anab", lambda st: _hip.check(L.m3d_anab_attend_bf16(
+                q.ptr, q.cs, khat16.data_ptr(), vhat16.data_ptr(), B, HW, ck_pad, n_bins, keys_pad, cv, x.ptr, x.cs,
+                sc.data_ptr(), sh.data_ptr(), 1, out.ptr, out.cs, st)))
+            plan.ops[-1] = plan.ops[-1][:2] + (2.0 * B * HW * n_bins * (ck + cv),) + plan.ops[-1][3:]
+            return
         logits = self._buf16(plan, B, fh, fw, n_bins, keys_pad, dtype=torch.float32)
         self._conv16(plan, "anab.logits", q, logits, wgt=khat16, kpad=ck_pad, cout=n_bins, cout_pad=keys_pad, out_mode=1,
                      wgt_img_stride=keys_pad * ck_pad, cin=ck_pad, flops_cin=ck)

@@ -350,6 +350,44 @@ def test_fused_head_mlp_bf16_matches_torch_chain(G, n, h, w, cout):
         assert e < 4e-3 * (1.0 + ref.abs().max().item()), (gi, e)      # a hidden value may round to the neighbouring bf16
 
 
+@pytest.mark.parametrize("B,h,w,keys", [(2, 8, 16, 337), (1, 16, 40, 337), (3, 8, 32, 85)])
+def test_anab_attend_bf16_matches_torch(B, h, w, keys):
+    """m3d_anab_attend_bf16 (logits + softmax + P.V + residual + affine + LeakyReLU in one launch, attention.py:207-211) against
+    torch fp32 on the bf16-rounded operands.  The kernel rounds exp(S - max) to bf16 and divides by the row sum in fp32."""
+    from m3dssd_amd import _hip
+    L, dev = _hip.lib(), _dev()
+    g = torch.Generator().manual_seed(B * 100 + keys)
+    HW, ck, ckp, cv = h * w, 168, 192, 128
+    kp = (keys + 63) // 64 * 64
+    q = torch.zeros(B * HW, ckp)
+    q[:, :ck] = _r(torch.randn(B * HW, ck, generator=g) * 0.5)
+    khat = torch.zeros(B, kp, ckp)
+    khat[:, :keys, :ck] = _r(torch.randn(B, keys, ck, generator=g) * 0.3)
+    vhat = torch.zeros(B, cv, kp)
+    vhat[:, :, :keys] = _r(torch.randn(B, cv, keys, generator=g))
+    vhat[:, :, keys:] = 7.0                                  # rows past `keys` must be ignored
+    res = _r(torch.randn(B * HW, cv, generator=g))
+    scale, shift = torch.rand(cv, generator=g) + 0.5, torch.randn(cv, generator=g) * 0.1
+    S = torch.einsum("bpc,bkc->bpk", q.view(B, HW, ckp), khat)[:, :, :keys]
+    Pm = torch.softmax(S, dim=-1)
+    ref = torch.einsum("bpk,bck->bpc", Pm, vhat[:, :, :keys]).reshape(B * HW, cv)
+    ref = F.leaky_relu((ref + res) * scale + shift, 0.01)
+    dq, dk, dv, dr = (t.to(BF16).contiguous().to(dev) for t in (q, khat, vhat, res))
+    dsc, dsh = scale.to(dev), shift.to(dev)
+    out = torch.full((B * HW, cv + 8), 512.0, device=dev, dtype=BF16)
+    _hip.check(L.m3d_anab_attend_bf16(dq.data_ptr(), ckp, dk.data_ptr(), dv.data_ptr(), B, HW, ckp, keys, kp, cv, dr.data_ptr(), cv,
+                                      dsc.data_ptr(), dsh.data_ptr(), 1, out.data_ptr(), cv + 8, _st()))
+    torch.cuda.synchronize()
+    assert (out[:, cv:].float() == 512.0).all()
+    got = out[:, :cv].float().cpu()
+    sc = ref.abs().max().item()
+    bad = (got - ref).abs() > 2.0 ** -7 * ref.abs() + 2e-3 * sc
+    assert not bad.any(), ((got - ref).abs().max().item(), sc, int(bad.sum()))
+    # argument validation
+    assert L.m3d_anab_attend_bf16(dq.data_ptr(), ckp, dk.data_ptr(), dv.data_ptr(), B, HW + 1, ckp, keys, kp, cv, None, 0, None, None, 0,
+                                  out.data_ptr(), cv + 8, _st()) == -1
+
+
 @pytest.mark.parametrize("shape", [(2, 128, 16, 40, 128, 3, 1), (1, 256, 8, 20, 128, 3, 1), (1, 512, 6, 10, 256, 3, 1),
                                    (2, 128, 16, 40, 128, 1, 0), (1, 64, 9, 13, 64, 3, 1)])
 def test_dcn_bf16_matches_oracle(shape):
