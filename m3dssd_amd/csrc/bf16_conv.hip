@@ -33,7 +33,7 @@ extern "C" void m3d_bf16_conv_set_trace(void *buf) { g_bf16_trace = (long long *
 #endif
 
 template <int BN, bool DEFORM>      // two workgroups per CU (LDS allows it): the gather of one overlaps the MFMA section of the other
-__global__ __launch_bounds__(256) void bf16_conv_kernel(const Bf16Args a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void bf16_conv_kernel(const Bf16Args a)
 {
     constexpr int BM = 128, BK = 64;
     constexpr int WN = BN >= 64 ? 2 : 1;          // waves along the channel dim
