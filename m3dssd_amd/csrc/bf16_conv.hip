@@ -67,6 +67,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
     if (a.wgt_img_stride) wgt += (long long)(m0 / a.HoWo) * a.wgt_img_stride;
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(inp, a.in_bytes);
     const __amdgpu_buffer_rsrc_t rwgt = make_rsrc(wgt, a.wgt_bytes);
+    float ssc = 1.f, ssh = 0.f;              // epilogue scale / shift of channel n0 + tid, fetched now, used after the K loop
+    if (tid < BN && n0 + tid < a.Cout) {
+        if (a.scale) ssc = a.scale[grp * a.ss_goff + n0 + tid];
+        if (a.shift) ssh = a.shift[grp * a.ss_goff + n0 + tid];
+    }
 
     // ---- staging map: thread = (row within a 32-row pass, 16-byte chunk of the 128-byte K line) ----------------------
     const int chunk = tid & 7, rsub = tid >> 3;
@@ -328,7 +333,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
         const int m = m0 + wm + i * 32 + l31;
         mpix[i] = m < a.M ? m : -1;
     }
-    conv_epilogue<TN, TM>(a, acc, mpix, n0, wn, lh, grp);
+    // affine parameters of the tile's channels -> LDS (the staging area is free: the loop ended on a barrier), then the bf16
+    // output tile through LDS into 128-byte row segments
+    float *ssl = reinterpret_cast<float *>(lds + sizeof(lds) - 2 * BN * 4);
+    if (tid < BN) { ssl[tid] = ssc; ssl[BN + tid] = ssh; }
+    __syncthreads();
+    BTRACE();
+    if (a.out_mode == 0) {
+        int lrow[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) lrow[i] = wm + i * 32 + l31;
+        if (a.sigmoid_from < 0) conv_epilogue_fast<TN, TM>(a, acc, mpix, lrow, n0, wn, lh, ssl, BN, lds);
+        else conv_epilogue<TN, TM>(a, acc, mpix, n0, wn, lh, grp, ssl, BN, lds, lrow);
+        BTRACE();
+        __syncthreads();
+        BTRACE();
+        store_otile<BN, BM, 256>(a, lds, n0, grp, tid, [&](int row) { return m0 + row < a.M ? m0 + row : -1; });
+    } else {
+        conv_epilogue<TN, TM>(a, acc, mpix, n0, wn, lh, grp, ssl, BN);
+    }
+    BTRACE();
 }
 
 // =====================================================================================================================
@@ -382,6 +406,11 @@ void bf16_conv3x3_halo_kernel(const Bf16Args a)
 
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
     const __amdgpu_buffer_rsrc_t rwgt = make_rsrc(a.wgt, a.wgt_bytes);
+    float ssc = 1.f, ssh = 0.f;              // epilogue scale / shift of channel n0 + tid, fetched now, used after the K loop
+    if (tid < BN && n0 + tid < a.Cout) {
+        if (a.scale) ssc = a.scale[n0 + tid];
+        if (a.shift) ssh = a.shift[n0 + tid];
+    }
 
     // ---- halo staging map: piece q = tid + NT*p -> halo pixel (tid >> 3) + RPP*p, 16-byte chunk tid & 7 ------------------
     const int chunk = tid & 7, rsub = tid >> 3;
@@ -492,7 +521,23 @@ void bf16_conv3x3_halo_kernel(const Bf16Args a)
         const int y = y0 + p / TW, x = x0 + p % TW;
         mpix[i] = (y < a.Ho && x < a.Wo) ? (img * a.Ho + y) * a.Wo + x : -1;
     }
-    conv_epilogue<TN, TM>(a, acc, mpix, n0, wn, lh, 0);
+    float *ssl = reinterpret_cast<float *>(lds + sizeof(lds) - 2 * BN * 4);      // the staging areas are free: the loop ended on a barrier
+    if (tid < BN) { ssl[tid] = ssc; ssl[BN + tid] = ssh; }
+    __syncthreads();
+    if (a.out_mode == 0) {
+        int lrow[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) lrow[i] = wm + i * 32 + lpos;
+        if (a.sigmoid_from < 0) conv_epilogue_fast<TN, TM>(a, acc, mpix, lrow, n0, wn, lh, ssl, BN, lds);
+        else conv_epilogue<TN, TM>(a, acc, mpix, n0, wn, lh, 0, ssl, BN, lds, lrow);
+        __syncthreads();
+        store_otile<BN, BM, NT>(a, lds, n0, 0, tid, [&](int row) {
+            const int y = y0 + row / TW, x = x0 + row % TW;
+            return (y < a.Ho && x < a.Wo) ? (img * a.Ho + y) * a.Wo + x : -1;
+        });
+    } else {
+        conv_epilogue<TN, TM>(a, acc, mpix, n0, wn, lh, 0, ssl, BN);
+    }
 }
 
 static int ilog2_exact(int v)

@@ -69,6 +69,13 @@ print("per K-step medians (ticks of the 100 MHz? s_memtime counter = shader cycl
       % (int(np.median(issue)), int(np.median(mfma)), int(np.median(store)),
          (" | barrier %d" % int(np.median(nxt - s[:, :, 3]))) if nxt is not None else ""))
 print("K-step period median %d" % int(np.median(np.diff(top, axis=1))))
+if 5 + 4 * n < 160 and (t[:, 5 + 4 * n] != 0).all():
+    b = 1 + 4 * n
+    print("epilogue phases: affine -> LDS + barrier %d | accumulators -> LDS tile %d | barrier %d | tile -> global stores issued %d"
+          % tuple(int(np.median(t[:, b + k + 1] - t[:, b + k])) for k in range(4)))
+elif 2 + 4 * n < 160 and (t[:, 2 + 4 * n] != 0).all():
+    print("epilogue (accumulators -> affine / activation -> stores issued): median %d ticks; workgroup start -> end median %d"
+          % (int(np.median(t[:, 2 + 4 * n] - t[:, 1 + 4 * n])), int(np.median(t[:, 2 + 4 * n] - t[:, 0]))))
 if len(sys.argv) > 8:       # per-K-step medians
     for kk in range(n):
         print("step %2d: issue %5d mfma %5d store %5d%s" % (kk, int(np.median(issue[:, kk])), int(np.median(mfma[:, kk])),
