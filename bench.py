@@ -89,7 +89,8 @@ def kernel_symbol(label):
         return "bf16_anab_attend_kernel(AnabArgs)"
     if label.startswith("bf16_halo"):
         bn, tw = re.findall(r"\d+", label.split("<", 1)[1])[:2]
-        return "void bf16_conv3x3_halo_kernel<%s, %s, %d, %d>(Bf16Args)" % (bn, tw, 8 * int(tw), 4 if tw == "16" else 8)
+        return "void bf16_conv3x3_halo_kernel<%s, %s, %d, %d, %d>(Bf16Args)" % (bn, tw, 8 * int(tw), 4 if tw == "16" else 8,
+                                                                                32 if (bn == "128" and tw == "16") else 64)
     if label.startswith("bf16_conv"):
         return "void bf16_conv_kernel<%s, %s>(Bf16Args)" % (re.findall(r"\d+", label.split("<", 1)[1])[0],
                                                             "true" if "deform" in label else "false")

@@ -26,8 +26,11 @@
 static long long *g_bf16_trace = nullptr;
 extern "C" void m3d_bf16_conv_set_trace(void *buf) { g_bf16_trace = (long long *)buf; }
 #define BTRACE_INIT() long long *trp = a.trace ? a.trace + (size_t)blockIdx.x * 160 : nullptr; int tri = 0
-#define BTRACE() do { if (trp && tid == 0 && tri < 160) trp[tri++] = __builtin_readcyclecounter(); } while (0)
+#define BTRACE() do { if (trp && tid == 0 && tri < 158) trp[tri++] = __builtin_readcyclecounter(); } while (0)
+// wall-clock pair (100 MHz s_memrealtime next to s_memtime) in slots 156..159: the shader clock the workgroup actually ran at
+#define BTRACE_REAL(k) do { if (trp && tid == 0) { trp[156 + 2 * (k)] = __builtin_readcyclecounter(); trp[157 + 2 * (k)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
+#define BTRACE_REAL(k)
 #define BTRACE_INIT()
 #define BTRACE()
 #endif
@@ -50,6 +53,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
     const int wm = (wave / WN) * (TM * 32), wn = (wave % WN) * (TN * 32);
     BTRACE_INIT();
     BTRACE();
+    BTRACE_REAL(0);
 
     // XCD-aware tile mapping (consecutive workgroup ids round-robin over the 8 XCDs)
     const int ntiles = a.tiles_m * a.tiles_n;
@@ -326,6 +330,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
         __syncthreads();
     }
     BTRACE();
+    BTRACE_REAL(1);
 
     int mpix[TM];
 #pragma unroll
@@ -372,26 +377,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
 // {4-11, 16-19, 28-31} (+32); each group is given 16 CONSECUTIVE pixels of one patch row, so every fragment read is
 // conflict-free (the identity map puts 8 + 8 pixels of two rows in a group: 2-way conflicts on every read).
 #define HT_PS 144                        // bytes per halo pixel (128 + 16 pad)
-template <int BN, int TW, int BM, int WAVES>     // LDS allows 2 workgroups per CU (3 for the small tile): hold the register file to that
+// WK = channels of a weight K-step: 64, or 32 (two half-steps per tap: half the weight staging buffers, so that the 8 x 16 tile
+// fits three workgroups per CU -- at two, the issue / staging / barrier phases of a K-step (800 cycles) are not covered by the
+// other workgroup's MFMA section (740), tools/bf16_conv_trace.py).
+template <int BN, int TW, int BM, int WAVES, int WK = 64>   // LDS allows 2-3 workgroups per CU: hold the register file to that
 __global__ __launch_bounds__(WAVES * 64)
-__attribute__((amdgpu_waves_per_eu(WAVES / 2, WAVES / 2 + (BN * BM <= 64 * 128) + (BN * BM <= 32 * 128))))
+__attribute__((amdgpu_waves_per_eu(WK == 32 ? 3 : WAVES / 2, (WK == 32 ? 3 : WAVES / 2 + (BN * BM <= 64 * 128) + (BN * BM <= 32 * 128)))))
 void bf16_conv3x3_halo_kernel(const Bf16Args a)
 {
+    constexpr int WKB = WK * 2;                        // bytes per weight row per step
+    constexpr int NH = 64 / WK;                        // weight half-steps per (tap, 64-channel chunk)
     constexpr int TH = BM / TW, HW = TW + 2, HPIX = (TH + 2) * HW;
     constexpr int NT = WAVES * 64, RPP = NT / 8;       // threads; pixels (or weight rows) staged per pass
     constexpr int WN = BN >= 64 ? 2 : 1, WM = WAVES / WN;   // BN 32 (offset / mask convs: HBM-bound): every wave takes all channels
     constexpr int TN = BN / (32 * WN), TM = BM / (32 * WM);
-    constexpr int PB = BN * 8 / NT;                    // weight pieces (16 B) per thread per K-step
+    constexpr int PB = BN * (WKB / 16) / NT;           // weight pieces (16 B) per thread per K-step
     static_assert(PB >= 1 && TM >= 1 && TN >= 1, "tile shape");
     constexpr int HP = (HPIX * 8 + NT - 1) / NT;       // halo pieces per thread per chunk
     constexpr int HBYTES = HPIX * HT_PS;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[HBYTES + 2 * BN * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[HBYTES + 2 * BN * WKB];
     unsigned char *Hs = lds, *Ws = lds + HBYTES;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (wave / WN) * (TM * 32), wn = (wave % WN) * (TN * 32);
     const int l31 = lane & 31, lh = lane >> 5;
+    BTRACE_INIT();
+    BTRACE();
+    BTRACE_REAL(0);
     const int ntiles = a.tiles_m * a.tiles_n;
     int tile = blockIdx.x;
     {
@@ -419,9 +432,13 @@ void bf16_conv3x3_halo_kernel(const Bf16Args a)
     const int hy0 = rsub / HW, hx0 = rsub - hy0 * HW;
     const unsigned hbase = ((unsigned)((img * a.H + y0 - 1) * a.W + x0 - 1) * (unsigned)a.in_cs + (unsigned)chunk * 8u) * 2u;
     const int hdst0 = rsub * HT_PS + chunk * 16;                                        // + p * RPP * HT_PS
-    const unsigned woff0 = ((unsigned)(n0 + rsub) * (unsigned)(a.KT * 64) + (unsigned)chunk * 8u) * 2u;
-    const unsigned wrow_step = (unsigned)RPP * (unsigned)(a.KT * 64) * 2u;             // bytes between passes (scalar)
-    const int wdst0 = rsub * 128 + ((chunk ^ ((rsub >> 1) & 7)) << 4);                  // + p * RPP * 128 (RPP % 16 == 0)
+    // weight staging map: WK 64: thread = (row tid >> 3, piece tid & 7) of 128-byte rows, piece XOR (row >> 1) & 7;
+    //                     WK 32: thread = (row tid >> 2, piece tid & 3) of  64-byte rows, piece XOR (row >> 2) & 3
+    constexpr int WPR = WKB / 16, WRPP = NT / WPR;                                       // pieces per row, rows per pass
+    const int wchunk = tid % WPR, wrsub = tid / WPR;
+    const unsigned woff0 = ((unsigned)(n0 + wrsub) * (unsigned)(a.KT * 64) + (unsigned)wchunk * 8u) * 2u;
+    const unsigned wrow_step = (unsigned)WRPP * (unsigned)(a.KT * 64) * 2u;            // bytes between passes (scalar)
+    const int wdst0 = wrsub * WKB + ((wchunk ^ (WK == 64 ? (wrsub >> 1) & 7 : (wrsub >> 2) & 3)) << 4);   // + p * WRPP * WKB
     u32x4 rh[HP], rw[PB];
     const int NC = a.Cin >> 6;                                  // 64-channel chunks
     auto load_halo = [&](int c) __attribute__((always_inline)) {
@@ -443,14 +460,14 @@ void bf16_conv3x3_halo_kernel(const Bf16Args a)
             if ((p + 1) * RPP <= HPIX || rsub + RPP * p < HPIX)
                 *reinterpret_cast<u32x4 *>(Hs + hdst0 + p * RPP * HT_PS) = rh[p];
     };
-    auto load_w = [&](int c, int tap) __attribute__((always_inline)) {
-        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(tap * a.Cin + c * 64) * 2u;
+    auto load_w = [&](int c, int tap, int half) __attribute__((always_inline)) {
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(tap * a.Cin + c * 64 + half * WK) * 2u;
 #pragma unroll
         for (int p = 0; p < PB; ++p) rw[p] = buf_load_u32x4(rwgt, woff0, so + (unsigned)p * wrow_step);
     };
     auto store_w = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int p = 0; p < PB; ++p) *reinterpret_cast<u32x4 *>(Ws + buf * BN * 128 + wdst0 + p * RPP * 128) = rw[p];
+        for (int p = 0; p < PB; ++p) *reinterpret_cast<u32x4 *>(Ws + buf * BN * WKB + wdst0 + p * WRPP * WKB) = rw[p];
     };
 
     f32x16 acc[TN][TM];
@@ -470,7 +487,6 @@ void bf16_conv3x3_halo_kernel(const Bf16Args a)
     else if (l31 < 20) lpos = 24 + (l31 - 16);
     else if (l31 < 28) lpos = 8 + (l31 - 20);
     else lpos = 28 + (l31 - 28);
-    const int sw = (l31 >> 1) & 7;
     int pbase[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -479,41 +495,54 @@ void bf16_conv3x3_halo_kernel(const Bf16Args a)
     }
 
     load_halo(0);
-    load_w(0, 0);
+    load_w(0, 0, 0);
     store_halo();
     store_w(0);
     __syncthreads();
-    int t = 0;                                                  // step index = c * 9 + tap; weight buffer t & 1
+    const int swk = WK == 64 ? (l31 >> 1) & 7 : (l31 >> 2) & 3;     // swizzle term of this lane's weight rows
+    int t = 0;                                                  // step index; weight buffer t & 1
     for (int c = 0; c < NC; ++c) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap, ++t) {
-            const bool last = (c == NC - 1) && tap == 8;
-            if (!last) load_w(tap == 8 ? c + 1 : c, tap == 8 ? 0 : tap + 1);
-            if (tap == 6 && c + 1 < NC) load_halo(c + 1);       // the next chunk's patch travels under the last taps of this one
-            const unsigned char *Wb = Ws + (t & 1) * BN * 128 + (wn + l31) * 128;
-            const int toff = ((tap / 3) * HW + (tap % 3)) * HT_PS;          // compile-time per unrolled tap
+        for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int co = ((2 * s + lh) ^ sw) << 4;
-                bf16x8 fw[TN], fp[TM];
+            for (int half = 0; half < NH; ++half, ++t) {
+                const bool last = (c == NC - 1) && tap == 8 && half == NH - 1;
+                BTRACE();
+                if (!last) {
+                    if (half + 1 < NH) load_w(c, tap, half + 1);
+                    else load_w(tap == 8 ? c + 1 : c, tap == 8 ? 0 : tap + 1, 0);
+                }
+                if (tap == 6 && half == 0 && c + 1 < NC) load_halo(c + 1);   // the next chunk's patch travels under the last taps of this one
+                BTRACE();
+                const unsigned char *Wb = Ws + (t & 1) * BN * WKB + (wn + l31) * WKB;
+                const int toff = ((tap / 3) * HW + (tap % 3)) * HT_PS + half * WKB;  // compile-time per unrolled step
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fw[j] = *reinterpret_cast<const bf16x8 *>(Wb + j * 32 * 128 + co);
+                for (int s = 0; s < WK / 16; ++s) {
+                    const int co = ((2 * s + lh) ^ swk) << 4;
+                    bf16x8 fw[TN], fp[TM];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fp[i] = *reinterpret_cast<const bf16x8 *>(Hs + pbase[i] + toff + s * 32);
+                    for (int j = 0; j < TN; ++j) fw[j] = *reinterpret_cast<const bf16x8 *>(Wb + j * 32 * WKB + co);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                    for (int i = 0; i < TM; ++i) fp[i] = *reinterpret_cast<const bf16x8 *>(Hs + pbase[i] + toff + s * 32);
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fp[i], acc[j][i], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fp[i], acc[j][i], 0, 0, 0);
+                }
+                BTRACE();
+                if (!last) store_w((t + 1) & 1);
+                if (tap == 8 && half == NH - 1 && c + 1 < NC) {
+                    __syncthreads();                            // every wave is done reading the patch
+                    store_halo();
+                }
+                BTRACE();
+                __syncthreads();
             }
-            if (!last) store_w((t + 1) & 1);
-            if (tap == 8 && c + 1 < NC) {
-                __syncthreads();                                // every wave is done reading the patch
-                store_halo();
-            }
-            __syncthreads();
         }
     }
+    BTRACE();
+    BTRACE_REAL(1);
     int mpix[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -572,7 +601,9 @@ static int conv_bf16_variant(const m3d_conv_bf16_desc *d, long long *tiles)
     const long long t16 = (long long)cdiv(wo, 16) * cdiv(ho, 8) * d->N, t32 = (long long)cdiv(wo, 32) * cdiv(ho, 8) * d->N;
     const double e16 = (double)M / (double)(t16 * 128), e32 = (double)M / (double)(t32 * 256);
     // the 256-pixel patch halves the weight staging per MFMA; it needs >= 2 workgroups per CU in flight to pay
-    const bool big = halo_on != 2 && bn >= 64 && e32 >= 0.9 * e16 && t32 * (d->Cout_pad / bn) >= 1024;
+    // 128-channel tiles: the 8 x 16 patch with 32-channel weight half-steps runs three workgroups per CU and beats the 8 x 32 /
+    // 8-wave tile (128 -> 128 @ 48x160: 904 vs 792 TFLOP/s); 64-channel tiles: 8 x 32 / 8 waves (708 vs 668)
+    const bool big = halo_on != 2 && bn == 64 && e32 >= 0.9 * e16 && t32 * (d->Cout_pad / bn) >= 1024;
     if ((big ? e32 : e16) < 0.8) return 0;
     if (tiles) *tiles = big ? t32 : t16;
     return big ? 2 : 1;
@@ -629,9 +660,13 @@ extern "C" int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t s
     if (variant) {
         a.tiles_m = (int)htiles;
         const dim3 hgrid(a.tiles_m * a.tiles_n);
-#define HLAUNCH(BN_, TW_, BM_, WV_) hipLaunchKernelGGL((bf16_conv3x3_halo_kernel<BN_, TW_, BM_, WV_>), hgrid, dim3(WV_ * 64), 0, st, a)
-        if (variant == 2) { if (bn == 128) HLAUNCH(128, 32, 256, 8); else HLAUNCH(64, 32, 256, 8); }
-        else { if (bn == 128) HLAUNCH(128, 16, 128, 4); else if (bn == 64) HLAUNCH(64, 16, 128, 4); else HLAUNCH(32, 16, 128, 4); }
+#define HLAUNCH(BN_, TW_, BM_, WV_, WK_) hipLaunchKernelGGL((bf16_conv3x3_halo_kernel<BN_, TW_, BM_, WV_, WK_>), hgrid, dim3(WV_ * 64), 0, st, a)
+        static int wk32 = -1;                 // M3D_BF16_HALO_WK=64: 64-channel weight steps for the 8 x 16 tile too (A/B)
+        if (wk32 < 0) { const char *e = getenv("M3D_BF16_HALO_WK"); wk32 = (e && atoi(e) == 64) ? 0 : 1; }
+        if (variant == 2) HLAUNCH(64, 32, 256, 8, 64);
+        else if (bn == 128) { if (wk32) HLAUNCH(128, 16, 128, 4, 32); else HLAUNCH(128, 16, 128, 4, 64); }
+        else if (bn == 64) HLAUNCH(64, 16, 128, 4, 64);
+        else HLAUNCH(32, 16, 128, 4, 64);
 #undef HLAUNCH
         M3D_LAUNCH_CHECK();
         return M3D_OK;

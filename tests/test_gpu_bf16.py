@@ -178,9 +178,10 @@ HALO_CASES = [
     (2, 128, 21, 45, 27, 0, False, 18, 1, 1),        # the same on a ragged map, two chunks
     (1, 256, 12, 40, 256, 1, False, -1, 0, 0),       # 12 x 40 map: patches would be 62 % full -> implicit-GEMM tile
     (2, 128, 16, 48, 192, 0, False, -1, 2, 1),       # planar fp32 output, Cout 192 (BN 64, 3 channel tiles)
-    (56, 64, 22, 62, 512, 1, True, -1, 0, 2),        # 8 x 32 patches / 8 waves, ragged, 4 channel tiles
+    (56, 64, 22, 62, 512, 1, True, -1, 0, 1),        # 128-channel tiles: 8 x 16 patches, 32-channel weight half-steps, ragged, 4 channel tiles
     (128, 64, 24, 96, 64, 1, False, -1, 1, 2),       # 8 x 32 patches, BN 64, fp32 NHWC output
-    (128, 128, 16, 64, 256, 1, True, -1, 0, 2),      # two 64-channel chunks: the patch buffer is refilled mid-loop
+    (256, 128, 16, 64, 64, 1, True, -1, 0, 2),       # 8 x 32 patches, two 64-channel chunks: the patch buffer is refilled mid-loop
+    (16, 256, 16, 32, 256, 1, True, -1, 0, 1),       # four chunks with half-steps, two channel tiles
 ]
 
 

@@ -37,7 +37,8 @@ if deform >= 0:
                     torch.zeros(B * H * W, 32 - 3 * k * k, device=dev)], 1).contiguous()
     d.dcn_offmask, d.dcn_om_cs = om.data_ptr(), 32
 bn = 128 if wp.shape[0] % 128 == 0 else (64 if wp.shape[0] % 64 == 0 else 32)
-grid = (B * H * W + 127) // 128 * (wp.shape[0] // bn)
+grid = (B * H * W + 127) // 128 * (wp.shape[0] // bn)          # upper bound: the halo-tile kernels launch fewer, larger workgroups
+L.m3d_conv_bf16_variant.argtypes = [ctypes.POINTER(_hip.ConvBf16Desc)]
 trace = torch.zeros(grid * 160, dtype=torch.int64, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
@@ -52,11 +53,23 @@ torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
 KT = kpad // 64
 t = trace.cpu().numpy().reshape(grid, 160)
+variant = L.m3d_conv_bf16_variant(ctypes.byref(d))
+if variant:
+    grid = ((H + 7) // 8) * ((W + 16 * variant - 1) // (16 * variant)) * B * (wp.shape[0] // bn)
+    t = t[:grid]
+    print("halo-tile kernel, 8 x %d patches" % (16 * variant))
 fl = 2.0 * B * H * W * cout * k * k * cin
 n = min(KT, 38)
 dur = t[:, 1 + 4 * n] - t[:, 0] if 1 + 4 * n < 160 else t[:, 1 + 4 * (n - 1)] - t[:, 0]
 print("grid %d workgroups, KT %d, launch %.4f ms (%.1f TFLOP/s); workgroup (first %d K-steps) ticks: min %d median %d max %d"
       % (grid, KT, ms, fl / ms / 1e9, n, dur.min(), int(np.median(dur)), dur.max()))
+if (t[:, 159] != 0).all():
+    cyc, real = t[:, 158] - t[:, 156], t[:, 159] - t[:, 157]
+    ok = real > 0
+    print("shader clock seen by the workgroups (s_memtime / s_memrealtime at 100 MHz): median %.2f GHz (p10 %.2f, p90 %.2f)"
+          % tuple(np.percentile(cyc[ok] / real[ok] * 0.1, [50, 10, 90])))
+    span = (t[:, 159].max() - t[:, 157].min()) / 100.0
+    print("first workgroup start -> last K loop end: %.1f us of the %.1f us launch" % (span, ms * 1000))
 s = t[:, 1:1 + 4 * n].reshape(grid, n, 4)
 prolog = t[:, 1] - t[:, 0]
 top = s[:, :, 0]
