@@ -119,7 +119,7 @@ __device__ __forceinline__ void conv_epilogue(const Bf16Args &a, f32x16 (&acc)[T
                 // LeakyReLU without a branch (slope 1 = identity); the per-element sigmoid test only in launches that have one.
                 // Written per element with both tests inside, this compiled to ~1500 branches per kernel and the epilogue took
                 // as long as the K loop of a 1x1 layer (11000 of 30000 cycles, tools/bf16_conv_trace.py).
-                if (!has_sig) {
+                if (!has_sig || c0 + 3 < a.sigmoid_from) {      // groups below the first sigmoid channel never evaluate an exponential
                     x = __builtin_elementwise_max(x, x * slope);
                 } else {
 #pragma unroll
