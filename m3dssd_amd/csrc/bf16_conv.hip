@@ -16,6 +16,8 @@
 //   are adjacent (they re-read the same pixels from that XCD's L2).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 #include "bf16_tile.h"
@@ -439,7 +441,7 @@ void bf16_conv3x3_halo_kernel(const Bf16Args a)
     const unsigned woff0 = ((unsigned)(n0 + wrsub) * (unsigned)(a.KT * 64) + (unsigned)wchunk * 8u) * 2u;
     const unsigned wrow_step = (unsigned)WRPP * (unsigned)(a.KT * 64) * 2u;            // bytes between passes (scalar)
     const int wdst0 = wrsub * WKB + ((wchunk ^ (WK == 64 ? (wrsub >> 1) & 7 : (wrsub >> 2) & 3)) << 4);   // + p * WRPP * WKB
-    u32x4 rh[HP], rw[PB];
+    u32x4 rh[HP], rw[3][PB];                                    // weights: three register sets, loads run two K-steps ahead
     const int NC = a.Cin >> 6;                                  // 64-channel chunks
     auto load_halo = [&](int c) __attribute__((always_inline)) {
         const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(c) * 128u;
@@ -460,14 +462,21 @@ void bf16_conv3x3_halo_kernel(const Bf16Args a)
             if ((p + 1) * RPP <= HPIX || rsub + RPP * p < HPIX)
                 *reinterpret_cast<u32x4 *>(Hs + hdst0 + p * RPP * HT_PS) = rh[p];
     };
-    auto load_w = [&](int c, int tap, int half) __attribute__((always_inline)) {
-        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(tap * a.Cin + c * 64 + half * WK) * 2u;
+    // weights of K-step u (= tap * NH + half) of chunk c -> register set R (compile-time: the steps of a chunk are unrolled and
+    // their number is a multiple of 3)
+    constexpr int SPC = 9 * NH;                                 // K-steps per 64-channel chunk
+    auto load_w = [&](int c, int u, auto rtag) __attribute__((always_inline)) {
+        constexpr int R = decltype(rtag)::value;
+        if (u >= SPC) { u -= SPC; ++c; }
+        if (c >= NC) return;
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((u / NH) * a.Cin + c * 64 + (u % NH) * WK) * 2u;
 #pragma unroll
-        for (int p = 0; p < PB; ++p) rw[p] = buf_load_u32x4(rwgt, woff0, so + (unsigned)p * wrow_step);
+        for (int p = 0; p < PB; ++p) rw[R][p] = buf_load_u32x4(rwgt, woff0, so + (unsigned)p * wrow_step);
     };
-    auto store_w = [&](int buf) __attribute__((always_inline)) {
+    auto store_w = [&](int buf, auto rtag) __attribute__((always_inline)) {
+        constexpr int R = decltype(rtag)::value;
 #pragma unroll
-        for (int p = 0; p < PB; ++p) *reinterpret_cast<u32x4 *>(Ws + buf * BN * WKB + wdst0 + p * WRPP * WKB) = rw[p];
+        for (int p = 0; p < PB; ++p) *reinterpret_cast<u32x4 *>(Ws + buf * BN * WKB + wdst0 + p * WRPP * WKB) = rw[R][p];
     };
 
     f32x16 acc[TN][TM];
@@ -494,53 +503,57 @@ void bf16_conv3x3_halo_kernel(const Bf16Args a)
         pbase[i] = ((p / TW) * HW + (p % TW)) * HT_PS + lh * 16;
     }
 
+#define RT(n) std::integral_constant<int, (n) % 3>{}
     load_halo(0);
-    load_w(0, 0, 0);
+    load_w(0, 0, RT(0));
+    load_w(0, 1, RT(1));
     store_halo();
-    store_w(0);
+    store_w(0, RT(0));
     __syncthreads();
     const int swk = WK == 64 ? (l31 >> 1) & 7 : (l31 >> 2) & 3;     // swizzle term of this lane's weight rows
     int t = 0;                                                  // step index; weight buffer t & 1
     for (int c = 0; c < NC; ++c) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int u = 0; u < SPC; ++u, ++t) {
+            constexpr int dummy = 0; (void)dummy;
+            const int tap = u / NH, half = u % NH;
+            const bool last = (c == NC - 1) && u == SPC - 1;
+            BTRACE();
+            // step t: loads of step t + 2 go out, step t + 1's weights (fetched one step ago) are staged under this step's
+            // MFMAs: a fetch issued and consumed inside ONE step (256-512 MFMA cycles) waits out most of its memory round trip
+            if (u % 3 == 0) load_w(c, u + 2, RT(2)); else if (u % 3 == 1) load_w(c, u + 2, RT(0)); else load_w(c, u + 2, RT(1));
+            if (tap == 6 && half == 0 && c + 1 < NC) load_halo(c + 1);   // the next chunk's patch travels under the last taps of this one
+            __builtin_amdgcn_sched_barrier(0);
+            BTRACE();
+            const unsigned char *Wb = Ws + (t & 1) * BN * WKB + (wn + l31) * WKB;
+            const int toff = ((tap / 3) * HW + (tap % 3)) * HT_PS + half * WKB;  // compile-time per unrolled step
 #pragma unroll
-            for (int half = 0; half < NH; ++half, ++t) {
-                const bool last = (c == NC - 1) && tap == 8 && half == NH - 1;
-                BTRACE();
-                if (!last) {
-                    if (half + 1 < NH) load_w(c, tap, half + 1);
-                    else load_w(tap == 8 ? c + 1 : c, tap == 8 ? 0 : tap + 1, 0);
-                }
-                if (tap == 6 && half == 0 && c + 1 < NC) load_halo(c + 1);   // the next chunk's patch travels under the last taps of this one
-                BTRACE();
-                const unsigned char *Wb = Ws + (t & 1) * BN * WKB + (wn + l31) * WKB;
-                const int toff = ((tap / 3) * HW + (tap % 3)) * HT_PS + half * WKB;  // compile-time per unrolled step
+            for (int s = 0; s < WK / 16; ++s) {
+                const int co = ((2 * s + lh) ^ swk) << 4;
+                bf16x8 fw[TN], fp[TM];
 #pragma unroll
-                for (int s = 0; s < WK / 16; ++s) {
-                    const int co = ((2 * s + lh) ^ swk) << 4;
-                    bf16x8 fw[TN], fp[TM];
+                for (int j = 0; j < TN; ++j) fw[j] = *reinterpret_cast<const bf16x8 *>(Wb + j * 32 * WKB + co);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) fw[j] = *reinterpret_cast<const bf16x8 *>(Wb + j * 32 * WKB + co);
+                for (int i = 0; i < TM; ++i) fp[i] = *reinterpret_cast<const bf16x8 *>(Hs + pbase[i] + toff + s * 32);
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) fp[i] = *reinterpret_cast<const bf16x8 *>(Hs + pbase[i] + toff + s * 32);
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-                            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fp[i], acc[j][i], 0, 0, 0);
-                }
-                BTRACE();
-                if (!last) store_w((t + 1) & 1);
-                if (tap == 8 && half == NH - 1 && c + 1 < NC) {
-                    __syncthreads();                            // every wave is done reading the patch
-                    store_halo();
-                }
-                BTRACE();
-                __syncthreads();
+                    for (int i = 0; i < TM; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fp[i], acc[j][i], 0, 0, 0);
             }
+            BTRACE();
+            if (!last) {
+                if (u % 3 == 0) store_w((t + 1) & 1, RT(1)); else if (u % 3 == 1) store_w((t + 1) & 1, RT(2)); else store_w((t + 1) & 1, RT(0));
+            }
+            if (u == SPC - 1 && c + 1 < NC) {
+                __syncthreads();                                // every wave is done reading the patch
+                store_halo();
+            }
+            BTRACE();
+            __syncthreads();
         }
     }
+#undef RT
     BTRACE();
     BTRACE_REAL(1);
     int mpix[TM];
