@@ -3,8 +3,10 @@
 // the image once and writes only the 32-channel half-resolution map.  Unfused these three layers move 16-channel
 // full-resolution tensors through HBM four times (at bs = 64: 4 GB) and, at 16 channels, cannot feed a 128-wide GEMM tile.
 //
-//   Workgroup (512 threads, 8 waves) = one 8 x 32 tile of level1 outputs.  Working backwards it needs 17 x 65 level0 pixels,
-//   19 x 67 stem pixels and a 25 x 73 image patch: all three live in LDS (bf16; pixel stride 48 bytes for the 16-channel
+//   Workgroup (256 threads, 4 waves) = one 8 x 16 tile of level1 outputs.  Working backwards it needs 17 x 33 level0 pixels,
+//   19 x 35 stem pixels and a 25 x 41 image patch: all three live in LDS (68 KB: TWO workgroups per CU, so that the load phase
+//   of one runs under the compute phases of the other -- the 8 x 32 tile of the first version filled the CU alone and ran
+//   1.35 ms against 1.25; bf16; pixel stride 48 bytes for the 16-channel
 //   tiles so that 16 consecutive pixels hit 16 different 16-byte bank groups).  Each stage is an implicit GEMM on
 //   v_mfma_f32_16x16x32_bf16 with rows = output channels (A operand = weights, held in registers for the whole stage) and
 //   columns = 16 consecutive pixels of the flattened region (B operand gathered from the LDS tile):
@@ -21,14 +23,16 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 #define FE_T1H 8
-#define FE_T1W 32
+#define FE_T1W 16
 #define FE_L0H (2 * FE_T1H + 1)     // 17
 #define FE_L0W (2 * FE_T1W + 1)     // 65
 #define FE_S0H (FE_L0H + 2)         // 19
 #define FE_S0W (FE_L0W + 2)         // 67
 #define FE_IMH (FE_S0H + 6)         // 25
 #define FE_IMW (FE_S0W + 6)         // 73
-#define FE_IMS 76                   // image tile row stride in pixels (8 bytes each): room for the 8-wide tap window
+#define FE_IMS ((FE_IMW + 3 + 3) / 4 * 4)   // image tile row stride in pixels (8 bytes each): room for the 8-wide tap window
+#define FE_NT 256                   // threads per workgroup
+#define FE_NW (FE_NT / 64)
 #define FE_PS 48                    // bytes per pixel of the 16-channel LDS tiles
 
 struct FrontArgs {
@@ -47,7 +51,7 @@ __device__ __forceinline__ unsigned fpack(float lo, float hi)
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
-__global__ __launch_bounds__(512) void bf16_frontend_kernel(const FrontArgs a)
+__global__ __launch_bounds__(FE_NT) void bf16_frontend_kernel(const FrontArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[FE_IMH * FE_IMS * 8 + FE_S0H * FE_S0W * FE_PS + FE_L0H * FE_L0W * FE_PS + 64];
     unsigned char *imt = lds;                                   // [25][76][4 bf16]
@@ -69,11 +73,11 @@ __global__ __launch_bounds__(512) void bf16_frontend_kernel(const FrontArgs a)
         const unsigned char *frame = static_cast<const unsigned char *>(a.img) + (size_t)n * a.img_h * a.img_w * 3;
         // all loads of the thread are issued before the first conversion: the workgroup is alone on its CU (129 KB of LDS), so
         // a load -> convert -> store loop would pay one memory round trip per iteration with nothing to hide it
-        constexpr int NI = (FE_IMH * FE_IMS + 511) / 512;
+        constexpr int NI = (FE_IMH * FE_IMS + FE_NT - 1) / FE_NT;
         float v[NI][3];
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
-            const int i = tid + it * 512;
+            const int i = tid + it * FE_NT;
             const int r = i / FE_IMS, q = i - r * FE_IMS;
             const int h = YI + r, w = XI + q;
             v[it][0] = v[it][1] = v[it][2] = 0.f;
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(512) void bf16_frontend_kernel(const FrontArgs a)
         }
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
-            const int i = tid + it * 512;
+            const int i = tid + it * FE_NT;
             const int r = i / FE_IMS, q = i - r * FE_IMS;
             const int h = YI + r, w = XI + q;
             if (a.is_u8 && i < FE_IMH * FE_IMS && q < FE_IMW && h >= 0 && h < H && w >= 0 && w < W) {
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(512) void bf16_frontend_kernel(const FrontArgs a)
         for (int i = 0; i < 7; ++i) wf[i] = *reinterpret_cast<const bf16x8 *>((const __bf16 *)a.w_stem + l15 * 224 + i * 32 + kg * 8);
         const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.s_stem + 4 * kg), sh = *reinterpret_cast<const f32x4 *>(a.t_stem + 4 * kg);
         constexpr int NP = FE_S0H * FE_S0W, NG = (NP + 15) / 16;
-        for (int g = wave; g < NG; g += 8) {
+        for (int g = wave; g < NG; g += FE_NW) {
             const int p = g * 16 + l15;
             const int pc = p < NP ? p : NP - 1;
             const int ry = pc / FE_S0W, rx = pc - ry * FE_S0W;
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(512) void bf16_frontend_kernel(const FrontArgs a)
             tap = tap > 8 ? 8 : tap;
             toff[t] = ((tap / 3) * FE_S0W + (tap % 3)) * FE_PS + (kg & 1) * 16;
         }
-        for (int g = wave; g < NG; g += 8) {
+        for (int g = wave; g < NG; g += FE_NW) {
             const int p = g * 16 + l15;
             const int pc = p < NP ? p : NP - 1;
             const int ry = pc / FE_L0W, rx = pc - ry * FE_L0W;
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(512) void bf16_frontend_kernel(const FrontArgs a)
             toff[t] = ((tap / 3) * FE_L0W + (tap % 3)) * FE_PS + (kg & 1) * 16;
         }
         const int Ho = H / 2, Wo = W / 2;
-        for (int g = wave; g < (FE_T1H * FE_T1W) / 16; g += 8) {
+        for (int g = wave; g < (FE_T1H * FE_T1W) / 16; g += FE_NW) {
             const int p = g * 16 + l15;
             const int oy = p / FE_T1W, ox = p - oy * FE_T1W;
             const unsigned char *src = l0t + ((size_t)(2 * oy) * FE_L0W + 2 * ox) * FE_PS;
@@ -240,7 +244,7 @@ extern "C" int m3d_frontend_bf16_forward(const void *img, int is_u8, int img_h, 
         a.img_h = img_h; a.img_w = img_w;
     }
     a.tiles_x = cdiv(W / 2, FE_T1W); a.tiles_y = cdiv(H / 2, FE_T1H);
-    hipLaunchKernelGGL(bf16_frontend_kernel, dim3(a.tiles_x, a.tiles_y, N), dim3(512), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(bf16_frontend_kernel, dim3(a.tiles_x, a.tiles_y, N), dim3(FE_NT), 0, (hipStream_t)stream, a);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
 }
