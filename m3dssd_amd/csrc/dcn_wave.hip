@@ -19,6 +19,8 @@
 // A step covers the 32 channels (one 128-byte line) of one tap: 4 k-groups x 16 MFMAs.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 struct ConvWaveArgs {
@@ -29,6 +31,7 @@ struct ConvWaveArgs {
     int kh, kw, stride, pad, dil;
     int M, KG, tiles_n;
     int act, res_mode, sigmoid_from;
+    int vec_out;                   // out / res / scale / shift views allow 16-byte accesses: epilogue through the LDS transpose
     long long w_img_stride;        // floats between the per-image weight sets (0: shared weights)
     unsigned in_bytes, out_bytes, res_bytes, w_bytes;
     // split-K across waves (layers with too few 32 x 128 tiles): grid = splits x tiles, split s covers steps
@@ -53,8 +56,8 @@ extern "C" void m3d_conv_wave_set_trace(void *buf) { g_conv_trace = (long long *
 #endif
 
 // NT = column tiles of 32 output channels per wave: 4 (128 channels) or, for 64-channel layers, 2
-template <bool DEFORM, int NT>
-__global__ __launch_bounds__(64) void conv_wave_kernel(const ConvWaveArgs a)
+template <bool DEFORM, int NT>      // register bound: 3 waves per SIMD for the plain kernel, 2 for the deformable one (as its K loop needs)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFORM ? 2 : 3))) void conv_wave_kernel(const ConvWaveArgs a)
 {
     __shared__ __attribute__((aligned(16))) float tileA[32 * 32];     // [pixel][8 slots of 4 channels], swizzled
     __shared__ __attribute__((aligned(16))) float tapst[32 * 8];      // [pixel][4 corner offsets (as bits), 4 weights]
@@ -281,6 +284,86 @@ __global__ __launch_bounds__(64) void conv_wave_kernel(const ConvWaveArgs a)
         }
         return;
     }
+    if (a.vec_out) {
+        // 16-byte epilogue: every 32 x 32 accumulator tile (lane = channel) is turned through the wave's LDS tile so that a lane
+        // owns 4 consecutive channels of a pixel: 16 float4 stores (and residual loads) per wave instead of 64 4-byte ones --
+        // the 4-byte form took ~10000 cycles per wave, up to a fifth of the wave on the 1x1 layers (tools/conv_wave_trace.py).
+        const float slope = a.act == 1 ? M3D_LEAKY_SLOPE : 1.f;
+        const int pr = lane >> 3, c4 = lane & 7;                     // read map: pixel pr + 8q of the tile, channels 4*c4 .. +3
+        unsigned oq[4], rq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = m0 + pr + 8 * q;
+            oq[q] = m < a.M ? (unsigned)m * (unsigned)a.out_cs * 4u : M3D_BUF_OOB;
+            rq[q] = m < a.M ? (unsigned)m * (unsigned)a.res_cs * 4u : M3D_BUF_OOB;
+        }
+        // affine parameters of all channel tiles in ONE round trip, before the first store (fetched per tile, after stores they
+        // may alias, they cost a memory round trip each: 4 x ~2000 cycles); residuals per tile (16 registers: the plain kernel
+        // keeps its three waves per SIMD)
+        f32x4 scv[NT], shv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c = n0 + nt * 32 + 4 * c4;
+            scv[nt] = f32x4{1.f, 1.f, 1.f, 1.f};
+            shv[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c + 3 < a.Cout) {
+                if (a.scale) scv[nt] = *reinterpret_cast<const f32x4 *>(a.scale + c);
+                if (a.shift) shv[nt] = *reinterpret_cast<const f32x4 *>(a.shift + c);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < a.Cout) {
+                        if (a.scale) scv[nt][e] = a.scale[c + e];
+                        if (a.shift) shv[nt][e] = a.shift[c + e];
+                    }
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c = n0 + nt * 32 + 4 * c4;
+            f32x4 rv[4];
+            if (a.res) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (c + 3 < a.Cout) {
+                        rv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, rq[q] + (unsigned)c * 4u, 0, 0));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            rv[q][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                rres, c + e < a.Cout ? rq[q] + (unsigned)(c + e) * 4u : M3D_BUF_OOB, 0, 0));
+                    }
+                }
+            }
+            // accumulator element r of lane (channel l31, half h) is pixel (r & 3) + 8 * (r >> 2) + 4 * h of the tile
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tileA[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[nt][r];
+            const bool tile_sig = a.sigmoid_from >= 0 && n0 + nt * 32 + 31 >= a.sigmoid_from;      // wave-uniform
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = *reinterpret_cast<const f32x4 *>(&tileA[(pr + 8 * q) * 32 + 4 * c4]);   // the wave's own writes: in order
+                if (a.res) v = a.res_mode ? (v + rv[q]) * scv[nt] + shv[nt] : v * scv[nt] + shv[nt] + rv[q];
+                else v = v * scv[nt] + shv[nt];
+                if (tile_sig) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = c + e >= a.sigmoid_from ? sigmoidf_(v[e]) : fmaxf(v[e], v[e] * slope);
+                } else {
+                    v = __builtin_elementwise_max(v, v * slope);
+                }
+                if (c + 3 < a.Cout) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, oq[q] + (unsigned)c * 4u, 0, 0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rout,
+                                                              c + e < a.Cout ? oq[q] + (unsigned)(c + e) * 4u : M3D_BUF_OOB, 0, 0);
+                }
+            }
+        }
+        TRACE();
+        return;
+    }
+    // 4-byte form (views that do not allow 16-byte accesses)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = n0 + nt * 32 + l31;
@@ -393,6 +476,11 @@ extern "C" int m3d_conv_wave_forward(const m3d_conv_desc *d, m3d_stream_t stream
     const int cw = d->Cout_pad % 128 == 0 ? 128 : 64;
     a.M = (int)M; a.KG = d->kh * d->kw * d->Cin / 8; a.tiles_n = d->Cout_pad / cw;
     a.act = d->act; a.res_mode = d->res_mode; a.sigmoid_from = d->sigmoid_from; a.w_img_stride = d->wgt_img_stride;
+    static int vec_epi = -1;       // M3D_WAVE_VEC_EPILOGUE=0: 4-byte stores straight from the accumulators (A/B)
+    if (vec_epi < 0) { const char *e = getenv("M3D_WAVE_VEC_EPILOGUE"); vec_epi = e ? atoi(e) : 1; }
+    a.vec_out = vec_epi && d->out_cs % 4 == 0 && ((uintptr_t)d->out & 15) == 0 &&
+                (!d->res || (d->res_cs % 4 == 0 && ((uintptr_t)d->res & 15) == 0)) &&
+                (!d->scale || ((uintptr_t)d->scale & 15) == 0) && (!d->shift || ((uintptr_t)d->shift & 15) == 0);
     a.in_bytes = (unsigned)((long long)d->N * d->H * d->W * d->in_cs * 4);
     a.out_bytes = (unsigned)(M * d->out_cs * 4);
     a.res_bytes = (unsigned)(M * d->res_cs * 4);
