@@ -72,21 +72,35 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpBatch batch)
     // two register sets used alternately (k loops unrolled by two, every layer starts on an even stream position).
     // The prefetch is UNCONDITIONAL (stream position clamped at the end): with a conditional load or a set-to-set copy
     // hipcc emits s_waitcnt vmcnt(0) for the loads just issued, serialising the memory latency into every k-tile.
+    // The loads are asm with HAND-COUNTED waits (as in wino_conv.hip): hipcc's own accounting of this loop-carried prefetch
+    // put `s_waitcnt vmcnt(0)` in front of the MFMAs of every second hidden-layer tile and of every output-layer tile -- i.e.
+    // behind the loads issued a few instructions earlier: one exposed memory round trip per tile.  Every call issues exactly 8
+    // loads (the 64-channel output layer re-reads its row tile for the second slot), so "the previous set has landed" is
+    // always vmcnt(8).
     f32x4 fbA[2][4], fbB[2][4];
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lane16 = (unsigned)lane * 16u;
     auto load_frags = [&](int t_req, f32x4 (&dst)[2][4]) {
         const int t = min(t_req, n_tiles - 1);
         const float *w;
         int kgroups, kt, j0, nj;
-        if (HAS_L1 && t < kt1) { w = a.w[0]; kgroups = a.Cin / 8; kt = t; j0 = wave * 2; nj = 2; }
-        else if (t < kt1 + kt2) { w = a.w[1]; kgroups = MLP_H / 8; kt = t - kt1; j0 = wave * 2; nj = 2; }
-        else { w = a.w[2]; kgroups = MLP_H / 8; kt = t - kt1 - kt2; j0 = (N3 == 64) ? (wave & 1) : wave * 2; nj = TNo; }
+        if (HAS_L1 && t < kt1) { w = a.w[0]; kgroups = a.Cin / 8; kt = t; j0 = swave * 2; nj = 2; }
+        else if (t < kt1 + kt2) { w = a.w[1]; kgroups = MLP_H / 8; kt = t - kt1; j0 = swave * 2; nj = 2; }
+        else { w = a.w[2]; kgroups = MLP_H / 8; kt = t - kt1 - kt2; j0 = (N3 == 64) ? (swave & 1) : swave * 2; nj = TNo; }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
+            // wave-uniform base in SGPRs, lane term in one VGPR, k-group as the immediate offset: no per-load VALU
+            const float *base = w + (size_t)((j0 + min(j, nj - 1)) * kgroups + kt * 4) * 256;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                if (j < nj && !(a.ablate & 1))
-                    dst[j][g] = *reinterpret_cast<const f32x4 *>(
-                        w + ((size_t)((j0 + j) * kgroups + kt * 4 + g) * 64 + lane) * 4);
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst[j][g]) : "v"(lane16), "s"(base), "n"(g * 1024));
+        }
+    };
+    // the set `fb` (issued one tile ago) has landed when at most the 8 loads issued after it are outstanding
+    auto wait_frags = [&](f32x4 (&fb)[2][4]) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(8)"
+                     : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]),
+                       "+v"(fb[1][3]));
     };
 
     load_frags(0, fbA);
@@ -141,22 +155,26 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpBatch batch)
         // KT is even (Cin and 256 are multiples of 64); the first pair is peeled for the zero-C start
         load_frags(t + 1, fbB);
         __builtin_amdgcn_sched_barrier(0);            // keep the prefetch ahead of the MFMAs
+        wait_frags(fbA);
         tile(0, fbA, std::true_type{});
         TRACE();
         ++t;
         load_frags(t + 1, fbA);
         __builtin_amdgcn_sched_barrier(0);
+        wait_frags(fbB);
         tile(1, fbB, std::false_type{});
         TRACE();
         ++t;
         for (int kt = 2; kt < KT; kt += 2) {
             load_frags(t + 1, fbB);
             __builtin_amdgcn_sched_barrier(0);
+            wait_frags(fbA);
             tile(kt, fbA, std::false_type{});
             TRACE();
             ++t;
             load_frags(t + 1, fbA);
             __builtin_amdgcn_sched_barrier(0);
+            wait_frags(fbB);
             tile(kt + 1, fbB, std::false_type{});
             TRACE();
             ++t;
@@ -236,10 +254,12 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpBatch batch)
         for (int kt = 0; kt < kt3; kt += 2) {
             load_frags(t + 1, fbB);
             __builtin_amdgcn_sched_barrier(0);
+            wait_frags(fbA);
             tile(kt, fbA);
             ++t;
             load_frags(t + 1, fbA);
             __builtin_amdgcn_sched_barrier(0);
+            wait_frags(fbB);
             tile(kt + 1, fbB);
             ++t;
         }
