@@ -152,6 +152,13 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpBatch batch)
                                                                              (FIRST && g == 0 && s == 0) ? zero16 : acc[i][j], 0, 0, 0);
             }
         };
+        // this lane's affine parameters: requested before the k loop, used after it (latency off the layer boundary)
+        float sj[2], bj[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            sj[j] = a.scale[layer][wn + j * 32 + l31];
+            bj[j] = a.shift[layer][wn + j * 32 + l31];
+        }
         // KT is even (Cin and 256 are multiples of 64); the first pair is peeled for the zero-C start
         load_frags(t + 1, fbB);
         __builtin_amdgcn_sched_barrier(0);            // keep the prefetch ahead of the MFMAs
@@ -180,13 +187,12 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpBatch batch)
             ++t;
         }
         // affine + LeakyReLU in registers, then overwrite the activation tile in place
-        const float *sc = a.scale[layer], *sh = a.shift[layer];
         __syncthreads();                              // every wave has finished reading the old tile
         TRACE();
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int co = wn + j * 32 + l31;
-            const float s = sc[co], b = sh[co];
+            const float s = sj[j], b = bj[j];
             const f32x2 s2 = {s, s}, b2 = {b, b}, k2 = {M3D_LEAKY_SLOPE, M3D_LEAKY_SLOPE};
 #pragma unroll
             for (int i = 0; i < 2; ++i)
