@@ -425,3 +425,43 @@ def test_rccl_single_rank_collective_runs():
     res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"),
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert res.returncode == 0 and "RCCL_OK" in res.stdout, res.stdout[-2000:]
+
+
+@pytest.mark.gpu
+def test_dcn_wave_fp32_run_to_run_identical_at_large_grids():
+    """The fp32 deformable wave kernel shares one sampling state per pixel through LDS, like the first bf16 version whose
+    predicates went wrong in lanes 48-63 about once per thousand workgroups.  15360 waves, 3 launches on the
+    same operands, bit-identical outputs."""
+    import ctypes
+
+    import torch
+
+    from m3dssd_amd import _hip
+    from m3dssd_amd.engine import pack_frag
+    dev = torch.device("cuda:0")
+    L = _hip.lib()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for cin, cout, h, w, b, k in [(128, 128, 48, 160, 64, 3), (128, 128, 48, 160, 32, 1)]:
+        g = torch.Generator().manual_seed(cin + k)
+        x = torch.randn(b * h * w * cin, generator=g).to(dev)
+        wf = pack_frag(torch.randn(cout, k * k * cin, generator=g) / (k * k * cin) ** 0.5, cout, dev)
+        kk = k * k
+        om = torch.cat([torch.randn(b * h * w, 2 * kk, generator=g) * 2.0, torch.rand(b * h * w, kk, generator=g),
+                        torch.zeros(b * h * w, 28 - 3 * kk)], 1).contiguous().to(dev)
+        outs = []
+        for _ in range(3):
+            out = torch.zeros(b * h * w * cout, device=dev)
+            d = _hip.ConvDesc()
+            d.inp, d.in_cs, d.N, d.H, d.W, d.Cin = x.data_ptr(), cin, b, h, w, cin
+            d.wgt, d.Cout, d.Cout_pad = wf.data_ptr(), cout, cout
+            d.kh = d.kw = k
+            d.stride, d.pad, d.dil, d.Ho, d.Wo = 1, k // 2, 1, h, w
+            d.out, d.out_cs, d.act, d.sigmoid_from = out.data_ptr(), cout, 1, -1
+            d.dcn_offmask, d.dcn_om_cs = om.data_ptr(), 28
+            _hip.check(L.m3d_conv_wave_forward(ctypes.byref(d), st))
+            torch.cuda.synchronize()
+            outs.append(out)
+        assert torch.isfinite(outs[0]).all()
+        for o in outs[1:]:
+            assert torch.equal(outs[0], o), (cin, k, int((outs[0] != o).sum()))
+
