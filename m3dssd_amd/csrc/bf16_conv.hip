@@ -186,10 +186,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
                 const float w_im = (float)w0 + dw;
                 // h_im > -1 && w_im > -1 && h_im < H && w_im < W as ONE comparison (the signs of the sums / differences are
                 // exact), and each corner's two-sided test as one sign test.  Not a style choice: with one state per lane the
-                // four-compare form compiles to back-to-back v_cmp -> s_and_b64 chains, and on the MI355X that form gave lanes
-                // 48-63 of a wave the wrong predicate about once per thousand workgroups (run-to-run different outputs,
-                // tools/dcn_determinism.py; a check build showed the received state wrong in exactly those lanes while the
-                // prefetched offsets were right).  tests/test_gpu_bf16.py::test_dcn_bf16_run_to_run_identical guards it.
+                // four-compare form gave lanes 48-63 of a wave the wrong state about once per thousand workgroups on the MI355X
+                // (run-to-run different outputs, tools/dcn_determinism.py; a check build showed the received state wrong in
+                // exactly those lanes while the prefetched offsets were right; root cause not identified -- an isolated
+                // reproducer, tools/ubench/vcmp_sand_hazard.hip, is clean).  tests/test_gpu_bf16.py::
+                // test_dcn_bf16_run_to_run_identical guards it.
                 if (fminf(fminf(h_im, w_im) + 1.f, -fmaxf(h_im - (float)a.H, w_im - (float)a.W)) > 0.f) {
                     const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
                     const float lh = h_im - (float)hl, lw = w_im - (float)wl;
