@@ -343,6 +343,10 @@ int m3d_anab_pool_finish(const float *partial, const int *bin_slots, const float
 long long m3d_anab_pool_nested_scratch_bytes(int B, int C);
 int m3d_anab_pool_nested(const float *kv, int kv_cs, const float *s, int s_cs, int B, int H, int W, int Ck, int Cv,
                          float *scratch, float *khat, int keys_pad, int ck_pad, float *vhatT, int frag, m3d_stream_t stream);
+/* The same with the K|V map stored as bf16 (bf16 engine: the K|V conv writes bf16 NHWC, the 4 gate channels come from a separate
+ * fp32 conv); fp32 sums, same outputs up to the rounding of the features. */
+int m3d_anab_pool_nested_bf16(const void *kv, int kv_cs, const float *s, int s_cs, int B, int H, int W, int Ck, int Cv,
+                              float *scratch, float *khat, int keys_pad, int ck_pad, float *vhatT, int frag, m3d_stream_t stream);
 /* In-place softmax over the first `valid` columns of each row; columns [valid, cs) are zeroed. */
 int m3d_softmax_rows(float *x, int rows, int valid, int cs, m3d_stream_t stream);
 

@@ -280,7 +280,10 @@ extern "C" int m3d_anab_pool_finish(const float *partial, const int *bin_slots, 
 // bin (H/16 x W/16 pixels), one thread per channel, four gated sums per thread (one per scale) -> fine[B][256][4][C];
 // the finish kernel adds the fine partials of each coarse bin in row-major order (deterministic) and scatters into the
 // two GEMM operand layouts like anab_pool_finish_kernel.
-__global__ void anab_pool_nested_kernel(const float *__restrict__ kv, int kv_cs, const float *__restrict__ s, int s_cs,
+// T = element type of the K|V map: float, or __bf16 for the bf16 engine (same fp32 sums over bf16-rounded features: the pooled
+// keys / values are rounded to bf16 again before they become GEMM operands).
+template <typename T>
+__global__ void anab_pool_nested_kernel(const T *__restrict__ kv, int kv_cs, const float *__restrict__ s, int s_cs,
                                         float *__restrict__ fine, int H, int W, int C)
 {
     const int fb = blockIdx.x, b = blockIdx.y;
@@ -292,7 +295,7 @@ __global__ void anab_pool_nested_kernel(const float *__restrict__ kv, int kv_cs,
             const size_t prow = (size_t)(b * H + h) * W + w0;
 #pragma unroll 5
             for (int w = 0; w < bw; ++w) {
-                const float x = kv[(prow + w) * kv_cs + c];
+                const float x = (float)kv[(prow + w) * kv_cs + c];
                 const float *g = s + (prow + w) * s_cs;
                 a0 = fmaf(x, g[0], a0);
                 a1 = fmaf(x, g[1], a1);
@@ -348,9 +351,9 @@ __global__ void anab_pool_nested_finish_kernel(const float *__restrict__ fine, i
 
 extern "C" long long m3d_anab_pool_nested_scratch_bytes(int B, int C) { return (long long)B * 256 * 4 * C * 4; }
 
-extern "C" int m3d_anab_pool_nested(const float *kv, int kv_cs, const float *s, int s_cs, int B, int H, int W, int Ck, int Cv,
-                                    float *scratch, float *khat, int keys_pad, int ck_pad, float *vhatT, int frag,
-                                    m3d_stream_t stream)
+template <typename T>
+static int anab_pool_nested_launch(const T *kv, int kv_cs, const float *s, int s_cs, int B, int H, int W, int Ck, int Cv,
+                                   float *scratch, float *khat, int keys_pad, int ck_pad, float *vhatT, int frag, m3d_stream_t stream)
 {
     M3D_REQUIRE(!frag || (keys_pad % 32 == 0 && ck_pad % 8 == 0 && Cv % 32 == 0), "anab_pool_nested: fragment layout needs "
                 "keys_pad %% 32 == 0, ck_pad %% 8 == 0, Cv %% 32 == 0");
@@ -359,13 +362,28 @@ extern "C" int m3d_anab_pool_nested(const float *kv, int kv_cs, const float *s, 
     M3D_REQUIRE(keys_pad >= 337 && ck_pad >= Ck && s_cs >= 4, "anab_pool_nested: bad operand layout");
     const int C = Ck + Cv;
     const int threads = C <= 1024 ? ((C + 63) / 64) * 64 : 256;
-    hipLaunchKernelGGL(anab_pool_nested_kernel, dim3(256, B), dim3(threads), 0, (hipStream_t)stream, kv, kv_cs, s, s_cs, scratch,
+    hipLaunchKernelGGL(anab_pool_nested_kernel<T>, dim3(256, B), dim3(threads), 0, (hipStream_t)stream, kv, kv_cs, s, s_cs, scratch,
                        H, W, C);
     M3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(anab_pool_nested_finish_kernel, dim3(337, B), dim3(256), 0, (hipStream_t)stream, scratch, H, W, Ck, Cv,
                        khat, keys_pad, ck_pad, vhatT, frag);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
+}
+
+extern "C" int m3d_anab_pool_nested(const float *kv, int kv_cs, const float *s, int s_cs, int B, int H, int W, int Ck, int Cv,
+                                    float *scratch, float *khat, int keys_pad, int ck_pad, float *vhatT, int frag,
+                                    m3d_stream_t stream)
+{
+    return anab_pool_nested_launch<float>(kv, kv_cs, s, s_cs, B, H, W, Ck, Cv, scratch, khat, keys_pad, ck_pad, vhatT, frag, stream);
+}
+
+extern "C" int m3d_anab_pool_nested_bf16(const void *kv, int kv_cs, const float *s, int s_cs, int B, int H, int W, int Ck, int Cv,
+                                         float *scratch, float *khat, int keys_pad, int ck_pad, float *vhatT, int frag,
+                                         m3d_stream_t stream)
+{
+    return anab_pool_nested_launch<__bf16>(static_cast<const __bf16 *>(kv), kv_cs, s, s_cs, B, H, W, Ck, Cv, scratch, khat, keys_pad,
+                                           ck_pad, vhatT, frag, stream);
 }
 
 // ---------------------------------------------------------------------------------------
