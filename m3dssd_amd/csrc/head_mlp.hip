@@ -269,6 +269,14 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpBatch batch)
             tile(kt + 1, fbB);
             ++t;
         }
+        // The clamped prefetch past the last tile is still in flight into fbA / fbB, and the compiler does not track the asm loads:
+        // it must land before the register allocator's next tenants of those registers are written.  (A four-set, three-tiles-
+        // ahead pipeline for this layer read garbage for exactly this reason until the hidden layers' last prefetch was drained
+        // first; once correct it was 1 % slower than this loop and was not kept.)
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(fbA[0][0]), "+v"(fbA[0][1]), "+v"(fbA[0][2]), "+v"(fbA[0][3]), "+v"(fbA[1][0]), "+v"(fbA[1][1]),
+                       "+v"(fbA[1][2]), "+v"(fbA[1][3]), "+v"(fbB[0][0]), "+v"(fbB[0][1]), "+v"(fbB[0][2]), "+v"(fbB[0][3]),
+                       "+v"(fbB[1][0]), "+v"(fbB[1][1]), "+v"(fbB[1][2]), "+v"(fbB[1][3]));
         TRACE();
         // planar store out[n][co][pix]: the channel term rides in the SGPR offset of a buffer store, a lane whose pixel or
         // channel does not exist gets the out-of-range offset
