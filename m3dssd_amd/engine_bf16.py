@@ -22,7 +22,7 @@ import torch
 
 from . import _hip
 from ._hip import ConvBf16Desc, HeadBf16Desc
-from .engine import BN_EPS, PSP_SIZES, Engine, _Plan, _rup, _Stream
+from .engine import BN_EPS, PSP_SIZES, Engine, _Plan, _rup
 
 BF16 = torch.bfloat16
 FUSED_ANAB = os.environ.get("M3D_BF16_FUSED_ANAB", "1") != "0"
