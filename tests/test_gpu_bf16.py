@@ -585,6 +585,58 @@ def test_bf16_network_matches_fp32_oracle_within_stated_tolerance(crop, B, pad):
         assert ((o_mask - torch.gather(fg, 1, ind))[diff].abs() < BF16_PROB_TOL).all()
 
 
+def test_anab_pool_nested_bf16_matches_fp32_kernel():
+    """m3d_anab_pool_nested_bf16 (K|V map stored as bf16) against m3d_anab_pool_nested on the widened values: same sums."""
+    from m3dssd_amd import _hip
+    L, dev = _hip.lib(), _dev()
+    B, H, W, ck, cv = 2, 16, 32, 168, 128
+    g = torch.Generator().manual_seed(5)
+    kv = _r(torch.randn(B * H * W, ck + cv, generator=g))
+    sg = torch.rand(B * H * W, 4, generator=g)
+    kp, ckp = 384, 192
+    outs = []
+    for use16 in (False, True):
+        khat = torch.zeros(B * kp * ckp, device=dev)
+        vhat = torch.zeros(B * cv * kp, device=dev)
+        scratch = torch.empty(L.m3d_anab_pool_nested_scratch_bytes(B, ck + cv) // 4, device=dev)
+        d_s = sg.to(dev).contiguous()
+        if use16:
+            d_kv = kv.to(BF16).to(dev).contiguous()
+            _hip.check(L.m3d_anab_pool_nested_bf16(d_kv.data_ptr(), ck + cv, d_s.data_ptr(), 4, B, H, W, ck, cv, scratch.data_ptr(),
+                                                   khat.data_ptr(), kp, ckp, vhat.data_ptr(), 0, _st()))
+        else:
+            d_kv = kv.to(dev).contiguous()
+            _hip.check(L.m3d_anab_pool_nested(d_kv.data_ptr(), ck + cv, d_s.data_ptr(), 4, B, H, W, ck, cv, scratch.data_ptr(),
+                                              khat.data_ptr(), kp, ckp, vhat.data_ptr(), 0, _st()))
+        torch.cuda.synchronize()
+        outs.append((khat.cpu(), vhat.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][0].abs().max() > 0
+
+
+def test_bf16_engine_alternative_paths_agree(monkeypatch):
+    """The A/B forms of the bf16 engine (three-launch attention, fp32 K|V map) compute the same network: head outputs agree with
+    the default plan within the rounding differences of the attention block (bf16 probabilities / features)."""
+    from m3dssd_amd import engine_bf16
+    crop, B = (128, 320), 2
+    x = synth.synth_frames(B, crop, 99).to(_dev())
+    ref = None
+    for fused, kv16 in [(True, True), (False, True), (True, False), (False, False)]:
+        monkeypatch.setattr(engine_bf16, "FUSED_ANAB", fused)
+        monkeypatch.setattr(engine_bf16, "KV_BF16", kv16)
+        net, _ = _net(crop, B, "bf16")
+        with torch.no_grad():
+            out = [t.float().cpu() for t in net(x)[:4]]
+        kinds = {op[1] for op in net.engine().plan_for(B, *crop).ops}
+        assert ("bf16_anab" in kinds) == fused
+        if ref is None:
+            ref = out
+            continue
+        for name, a, b in zip(("cls", "prob", "bbox_2d", "bbox_3d"), ref, out):
+            d = (a - b).abs()
+            assert float(d.max()) <= 0.25 and float((d ** 2).mean().sqrt()) <= 5e-3, (fused, kv16, name, float(d.max()))
+
+
 def test_bf16_batch64_full_size_properties():
     """BASELINE.json configs[2] at its own size: 64 frames of 1280x384.  Size-independent properties: finite outputs, run-to-run
     bit determinism, image i of the batch == the same image in a batch of 2 (bf16 kernels are batch-invariant: same tiles,
