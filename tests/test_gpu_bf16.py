@@ -638,7 +638,11 @@ def test_bf16_engine_alternative_paths_agree(monkeypatch):
             continue
         for name, a, b in zip(("cls", "prob", "bbox_2d", "bbox_3d"), ref, out):
             d = (a - b).abs()
-            assert float(d.max()) <= 0.5 and float((d ** 2).mean().sqrt()) <= 0.02, (fused, kv16, heads, front, name, float(d.max()))   # different bf16 rounding points, same network (stated tolerance vs the oracle: rms 0.03)
+            # different bf16 rounding points, same network: the stated bf16 tolerances (rms / 99.9 % -- doubled, both sides carry the
+            # error -- / max; a flipped discrete
+            # decision -- top-1 anchor, hard mask -- moves a few entries by more than the rounding noise)
+            assert float((d ** 2).mean().sqrt()) <= BF16_BBOX_RMS_TOL and float(torch.quantile(d.flatten()[:2000000], 0.999)) <= 2 * BF16_BBOX_P999_TOL \
+                and float(d.max()) <= BF16_BBOX_MAX_TOL, (fused, kv16, heads, front, name, float(d.max()))
 
 
 def test_bf16_batch64_full_size_properties():
