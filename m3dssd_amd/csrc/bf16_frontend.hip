@@ -33,7 +33,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define FE_IMS ((FE_IMW + 3 + 3) / 4 * 4)   // image tile row stride in pixels (8 bytes each): room for the 8-wide tap window
 #define FE_NT 256                   // threads per workgroup
 #define FE_NW (FE_NT / 64)
-#define FE_PS 48                    // bytes per pixel of the 16-channel LDS tiles
+#define FE_PS 48                    // bytes per pixel of the level0 tile (read with pixel stride 2 by level1: 16 lanes x 16 B cover the 64 banks once)
+#define FE_PS0 32                   // bytes per pixel of the stem tile (read with pixel stride 1 by level0: dense rows are the conflict-free ones;
+                                    // at 48 the two 16-byte halves of neighbouring pixels collide 2-way: SQ_LDS_BANK_CONFLICT 136 M cycles per launch)
 
 struct FrontArgs {
     const void *img;                // fp32 [N][3][H][W] or uint8 [N][img_h][img_w][3] (BGR)
@@ -53,10 +55,10 @@ __device__ __forceinline__ unsigned fpack(float lo, float hi)
 
 __global__ __launch_bounds__(FE_NT) void bf16_frontend_kernel(const FrontArgs a)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[FE_IMH * FE_IMS * 8 + FE_S0H * FE_S0W * FE_PS + FE_L0H * FE_L0W * FE_PS + 64];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FE_IMH * FE_IMS * 8 + FE_S0H * FE_S0W * FE_PS0 + FE_L0H * FE_L0W * FE_PS + 64];
     unsigned char *imt = lds;                                   // [25][76][4 bf16]
     unsigned char *s0t = lds + FE_IMH * FE_IMS * 8;              // [19*67][48 B]
-    unsigned char *l0t = s0t + FE_S0H * FE_S0W * FE_PS;          // [17*65][48 B]  (+64: the k-padding read of the last pixel)
+    unsigned char *l0t = s0t + FE_S0H * FE_S0W * FE_PS0;          // [17*65][48 B]  (+64: the k-padding read of the last pixel)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kg = lane >> 4;
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(FE_NT) void bf16_frontend_kernel(const FrontArgs a)
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = inside ? leaky(acc[e] * sc[e] + sh[e]) : 0.f;
-            if (p < NP) *reinterpret_cast<u32x2 *>(s0t + (size_t)p * FE_PS + kg * 8) = u32x2{fpack(v[0], v[1]), fpack(v[2], v[3])};
+            if (p < NP) *reinterpret_cast<u32x2 *>(s0t + (size_t)p * FE_PS0 + kg * 8) = u32x2{fpack(v[0], v[1]), fpack(v[2], v[3])};
         }
     }
     __syncthreads();
@@ -158,13 +160,13 @@ __global__ __launch_bounds__(FE_NT) void bf16_frontend_kernel(const FrontArgs a)
         for (int t = 0; t < 5; ++t) {
             int tap = 2 * t + (kg >> 1);
             tap = tap > 8 ? 8 : tap;
-            toff[t] = ((tap / 3) * FE_S0W + (tap % 3)) * FE_PS + (kg & 1) * 16;
+            toff[t] = ((tap / 3) * FE_S0W + (tap % 3)) * FE_PS0 + (kg & 1) * 16;
         }
         for (int g = wave; g < NG; g += FE_NW) {
             const int p = g * 16 + l15;
             const int pc = p < NP ? p : NP - 1;
             const int ry = pc / FE_L0W, rx = pc - ry * FE_L0W;
-            const unsigned char *src = s0t + ((size_t)ry * FE_S0W + rx) * FE_PS;
+            const unsigned char *src = s0t + ((size_t)ry * FE_S0W + rx) * FE_PS0;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 5; ++t)
