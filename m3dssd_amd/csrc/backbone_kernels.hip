@@ -397,20 +397,23 @@ __global__ __launch_bounds__(256) void conv3x3_c16_mfma_kernel(const float *__re
                 for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct)
-                        acc[rr][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rr][ct][t], b[t], acc[rr][ct], 0, 0, 0);
+                        // operands swapped (A = weights, B = pixels): D[cout][pixel], so a lane ends up with 4 consecutive
+                        // channels of ONE pixel and the epilogue stores 16 bytes per lane, 1 KB contiguous per instruction
+                        acc[rr][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[t], a[rr][ct][t], acc[rr][ct], 0, 0, 0);
         }
-    // ---- epilogue: lane = cout li, registers = pixels 4*lq + r of the 16-pixel tile -------------------------------------
-    const float sc = scale[li], sh = shift[li];
+    // ---- epilogue: lane = pixel li of the 16-pixel tile, registers = couts 4*lq + r -------------------------------------------
+    const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + 4 * lq), sh = *reinterpret_cast<const f32x4 *>(shift + 4 * lq);
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int h = h0 + 2 * wave + rr;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < 4; ++ct) {
+            const int w = w0 + ct * 16 + li;
+            f32x4 v = acc[rr][ct] * sc + sh;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int w = w0 + ct * 16 + 4 * lq + r;
-                if (h < H && w < W) out[((size_t)(n * H + h) * W + w) * out_cs + li] = leaky(acc[rr][ct][r] * sc + sh);
-            }
+            for (int e = 0; e < 4; ++e) v[e] = leaky(v[e]);
+            if (h < H && w < W) *reinterpret_cast<f32x4 *>(out + ((size_t)(n * H + h) * W + w) * out_cs + 4 * lq) = v;
+        }
     }
 }
 
@@ -419,6 +422,8 @@ extern "C" int m3d_conv3x3_c16(const float *in, int in_cs, const float *wgt, con
 {
     M3D_REQUIRE(in && wgt && scale && shift && out && in_cs % 4 == 0 && out_cs % 4 == 0 && in_cs >= 16 && out_cs >= 16,
                 "conv3x3_c16: bad arguments");
+    M3D_REQUIRE((((uintptr_t)in | (uintptr_t)out | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0,
+                "conv3x3_c16: in / out / scale / shift must be 16-byte aligned (float4 accesses)");
     static int valu = -1;                        // tuning knob (experiments only): M3D_L0_VALU=1 selects the VALU kernel
     if (valu < 0) { const char *e = getenv("M3D_L0_VALU"); valu = e ? atoi(e) : 0; }
     const long long in_bytes = (long long)N * H * W * in_cs * 4;
