@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
     const int sp = chunk & 3;                                       // piece this lane produces the state of
     const int spix = m0 + sp * 32 + rsub;
     const bool sprod = DEFORM && spix < a.M;
+    const int sinv = sign_smear(a.M - 1 - spix);                    // all ones: no such pixel, the state is "nothing"
     int sh0 = 0, sw0 = 0, sbase = 0;                                // that pixel's tap-(0, 0) input position / image base
     if (sprod) {
         const int n = spix / a.HoWo, rem = spix - n * a.HoWo;
@@ -179,43 +180,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
         } else {
             // sampling state of a pixel for a tap (dcn_v2_im2col_cuda.cu:18-47,150-178): corner weights (mask folded in) and
             // corner pixel offsets inside the image
-            auto sample = [&](int h0, int w0, float dh, float dw, float mk, float (&w)[4], int (&o)[4]) __attribute__((always_inline)) {
-                float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
-                int o1 = 0, o2 = 0, o3 = 0, o4 = 0;
-                const float h_im = (float)h0 + dh;
-                const float w_im = (float)w0 + dw;
-                // h_im > -1 && w_im > -1 && h_im < H && w_im < W as ONE comparison (the signs of the sums / differences are
-                // exact), and each corner's two-sided test as one sign test.  Not a style choice: with one state per lane the
-                // four-compare form gave lanes 48-63 of a wave the wrong state about once per thousand workgroups on the MI355X
-                // (run-to-run different outputs, tools/dcn_determinism.py; a check build showed the received state wrong in
-                // exactly those lanes while the prefetched offsets were right; root cause not identified -- an isolated
-                // reproducer, tools/ubench/vcmp_sand_hazard.hip, is clean).  tests/test_gpu_bf16.py::
-                // test_dcn_bf16_run_to_run_identical guards it.
-                if (fminf(fminf(h_im, w_im) + 1.f, -fmaxf(h_im - (float)a.H, w_im - (float)a.W)) > 0.f) {
-                    const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
-                    const float lh = h_im - (float)hl, lw = w_im - (float)wl;
-                    const float uh = 1.f - lh, uw = 1.f - lw;
-                    const int hr = a.H - 2 - hl, wr = a.W - 2 - wl;          // >= 0: the high corner row / column is inside
-                    if ((hl | wl) >= 0) { w1 = uh * uw; o1 = hl * a.W + wl; }
-                    if ((hl | wr) >= 0) { w2 = uh * lw; o2 = hl * a.W + wl + 1; }
-                    if ((hr | wl) >= 0) { w3 = lh * uw; o3 = (hl + 1) * a.W + wl; }
-                    if ((hr | wr) >= 0) { w4 = lh * lw; o4 = (hl + 1) * a.W + wl + 1; }
+            auto sample = [&](int h0, int w0, float dh, float dw, float mk, int off, float (&w)[4], int (&o)[4]) __attribute__((always_inline)) {
+                int drop[4];
+                dcn_corners((float)h0 + dh, (float)w0 + dw, a.H, a.W, off, w, o, drop);     // no SGPR lane masks: common.h
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    w[q] *= mk;
+                    o[q] &= ~drop[q];                                                       // dropped corner: pixel 0, weight 0
                 }
-                w[0] = w1 * mk; w[1] = w2 * mk; w[2] = w3 * mk; w[3] = w4 * mk;
-                o[0] = o1; o[1] = o2; o[2] = o3; o[3] = o4;
             };
             if (fresh && uni) {
                 samp_tap = tap;
                 {
                     float w[4] = {0.f, 0.f, 0.f, 0.f};
                     int o[4] = {0, 0, 0, 0};
-                    if (sprod) sample(sh0 + ti, sw0 + tj, omn[0], omn[1], omn[2], w, o);
+                    sample(sh0 + ti, sw0 + tj, omn[0], omn[1], omn[2], sinv, w, o);
                     u32x4 sw_, so_;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        sw_[q] = __float_as_uint(w[q]);
-                        so_[q] = (unsigned)(sbase + o[q]) * (unsigned)a.in_cs * 2u;
-                    }
+                    for (int q = 0; q < 4; ++q) sw_[q] = __float_as_uint(w[q]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) so_[q] = (unsigned)(sbase + o[q]) * (unsigned)a.in_cs * 2u;
                     fetch_om(tap + 1);
                     const unsigned lane_c = (unsigned)chunk * 16u;
                     const int src0 = (lane & ~7) * 4;
@@ -236,7 +220,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
                     int o[4] = {0, 0, 0, 0};
                     if (rvalid[p] && kvalid) {
                         const float *omp = a.om + (size_t)(m0 + p * 32 + rsub) * a.om_cs;
-                        sample(hi0[p] + ti, wi0[p] + tj, omp[2 * tap], omp[2 * tap + 1], omp[2 * KK + tap], w, o);
+                        sample(hi0[p] + ti, wi0[p] + tj, omp[2 * tap], omp[2 * tap + 1], omp[2 * KK + tap], 0, w, o);
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {

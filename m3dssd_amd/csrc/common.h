@@ -11,6 +11,50 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// ---- DCNv2 sampling state without lane masks in SGPRs --------------------------------------------------------------
+// dcn_v2_im2col_cuda.cu:18-47,150-178: a sample at (h_im, w_im) is taken iff h_im > -1, w_im > -1, h_im < H, w_im < W, and each
+// of its four corners contributes iff it lies inside the image.  Written the obvious way (compares, &&, ?:) hipcc builds the
+// decisions as v_cmp -> s_and_b64 -> v_cndmask chains on 64-bit lane masks held in SGPRs; in the deformable kernels -- 255
+// VGPRs, two waves per SIMD, MFMA / LDS / gather traffic around the sampling code -- about one (pixel, tap) state in 10^5..10^6
+// then came out with ONE corner dropped (weight 0, offset 0) in lanes 48-63 of a wave: run-to-run different outputs
+// (tools/dcn_determinism.py resolves the difference into per-corner contributions: coefficient -1.00 on one corner, residual
+// at bf16 rounding level).  Which corner / tap and how often changed with every recompile (0 of 800 launches for one build, 100 %
+// of the launches for another), one workgroup per CU never showed it, a 24-bit multiply or a branch-free form moved it but did
+// not remove it, and two isolated reproducers (tools/ubench/vcmp_sand_hazard.hip, vmul_divergent.hip) are clean: the
+// observation is consistent with bits 48-63 of a VALU-written SGPR mask being read stale, the root cause is not established.
+// What removes it in every build tried (4 variants x 4 shapes x 300 launches): no lane mask at all.  Every decision is a sign
+// bit smeared over the register by an arithmetic shift the optimiser cannot see through (`x & ~(y >> 31)` written in C++ is
+// turned back into v_cmp + v_cndmask), applied with AND / OR.
+__device__ __forceinline__ int sign_smear(int x)         // x < 0 ? ~0 : 0, as one opaque v_ashrrev_i32
+{
+    int m;
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m) : "v"(x));
+    return m;
+}
+// Corner weights (uh*uw, uh*lw, lh*uw, lh*lw -- zero for a dropped corner), corner pixel offsets inside the image plane
+// (hl*W + wl, ... -- valid only where kept) and the drop masks (all ones: corner not sampled).  `drop_all`: all ones forces the
+// whole sample off (a lane without a pixel).
+__device__ __forceinline__ void dcn_corners(float h_im, float w_im, int H, int W, int drop_all, float (&w)[4], int (&o)[4],
+                                            int (&drop)[4])
+{
+    const float tin = fminf(fminf(h_im, w_im) + 1.f, -fmaxf(h_im - (float)H, w_im - (float)W));     // > 0: inside
+    const int xin = (int)__float_as_uint(tin);
+    const int out = sign_smear((xin - 1) | xin) | drop_all;                                          // tin <= 0 (or -0.0)
+    const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
+    const float lh = h_im - (float)hl, lw = w_im - (float)wl;
+    const float uh = 1.f - lh, uw = 1.f - lw;
+    const int hr = H - 2 - hl, wr = W - 2 - wl;                       // >= 0: the high corner row / column is inside
+    drop[0] = sign_smear(hl | wl) | out;
+    drop[1] = sign_smear(hl | wr) | out;
+    drop[2] = sign_smear(hr | wl) | out;
+    drop[3] = sign_smear(hr | wr) | out;
+    const int row0 = __mul24(hl, W) + wl, row1 = row0 + W;
+    o[0] = row0; o[1] = row0 + 1; o[2] = row1; o[3] = row1 + 1;
+    const float wf[4] = {uh * uw, uh * lw, lh * uw, lh * lw};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = __uint_as_float(__float_as_uint(wf[q]) & ~(unsigned)drop[q]);
+}
+
 // ---- raw buffer access (gfx950) -------------------------------------------------------------------------------
 // A buffer resource makes the address of a load  base(SGPR x4) + voffset(VGPR, 32 bit) + soffset(SGPR): no per-load
 // 64-bit VALU address arithmetic, and a lane whose voffset is >= num_records reads 0.0f -- out-of-image taps cost no

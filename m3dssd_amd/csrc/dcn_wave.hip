@@ -91,6 +91,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFORM ? 2 :
     // ---- the pixel this lane owns in the MFMA map (DEFORM: it computes that pixel's sampling state) ----------------
     int o_pix = 0, o_hi0 = 0, o_wi0 = 0;
     bool o_valid = false;
+    int o_inv = -1;                                    // all ones: this lane owns no pixel (its sampling state is "nothing")
     const float *o_om = a.om;
     // ---- the 4 pixels this lane gathers for (plain mode keeps their coordinates) --------------------------------------
     int g_pix[4], g_hi0[4], g_wi0[4];
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFORM ? 2 :
     {
         const int m = m0 + l31;
         o_valid = m < a.M;
+        o_inv = sign_smear(a.M - 1 - m);
         const int mm = o_valid ? m : 0;
         const int n = mm / a.HoWo, rem = mm - n * a.HoWo;
         const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
@@ -134,26 +136,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFORM ? 2 :
     auto setup_tap = [&](int tap) {
         const int ti = tap / a.kw, tj = tap - ti * a.kw;
         if constexpr (DEFORM) {
-            float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
-            int o1 = -1, o2 = -1, o3 = -1, o4 = -1;
             const float mk = raw[2];
             const float h_im = (float)(o_hi0 + ti * a.dil) + raw[0];
             const float w_im = (float)(o_wi0 + tj * a.dil) + raw[1];
-            if (o_valid && h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
-                const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
-                const int hh = hl + 1, wh = wl + 1;
-                const float lh = h_im - (float)hl, lw = w_im - (float)wl;
-                const float uh = 1.f - lh, uw = 1.f - lw;
-                if (hl >= 0 && wl >= 0) { w1 = uh * uw; o1 = hl * a.W + wl; }
-                if (hl >= 0 && wh <= a.W - 1) { w2 = uh * lw; o2 = hl * a.W + wh; }
-                if (hh <= a.H - 1 && wl >= 0) { w3 = lh * uw; o3 = hh * a.W + wl; }
-                if (hh <= a.H - 1 && wh <= a.W - 1) { w4 = lh * lw; o4 = hh * a.W + wh; }
-            }
-            const int o[4] = {o1, o2, o3, o4};
+            float wq[4];
+            int oq[4], drop[4];
+            dcn_corners(h_im, w_im, a.H, a.W, o_inv, wq, oq, drop);      // no SGPR lane masks in here: see common.h
+            const float w1 = wq[0], w2 = wq[1], w3 = wq[2], w4 = wq[3];
             u32x4 ob;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                ob[q] = o[q] >= 0 ? (unsigned)(o_pix + o[q]) * (unsigned)a.in_cs * 4u : M3D_BUF_OOB;
+            for (int q = 0; q < 4; ++q) {
+                const unsigned off = (unsigned)(o_pix + oq[q]) * (unsigned)a.in_cs * 4u;
+                ob[q] = (off & ~(unsigned)drop[q]) | (M3D_BUF_OOB & (unsigned)drop[q]);     // dropped corner: the load reads 0
+            }
             if (h == 0) {
                 *reinterpret_cast<u32x4 *>(&tapst[l31 * 8]) = ob;
                 *reinterpret_cast<f32x4 *>(&tapst[l31 * 8 + 4]) = f32x4{w1 * mk, w2 * mk, w3 * mk, w4 * mk};

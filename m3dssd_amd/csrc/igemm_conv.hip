@@ -183,25 +183,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
                 const int KK = a.kh * a.kw;
 #pragma unroll
                 for (int p = 0; p < PA; ++p) {
-                    float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f, mk = 0.f;
-                    int o1 = 0, o2 = 0, o3 = 0, o4 = 0;
-                    if (rvalid[p]) {
-                        const float *omp = a.om + (size_t)(m0 + p * RPP + rsub) * a.om_cs;
-                        const float dh = omp[2 * tap], dw = omp[2 * tap + 1];
-                        mk = omp[2 * KK + tap];
-                        const float h_im = (float)(hi0[p] + ti * a.dil) + dh;
-                        const float w_im = (float)(wi0[p] + tj * a.dil) + dw;
-                        if (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
-                            const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
-                            const int hh = hl + 1, wh = wl + 1;
-                            const float lh = h_im - (float)hl, lw = w_im - (float)wl;
-                            const float uh = 1.f - lh, uw = 1.f - lw;
-                            if (hl >= 0 && wl >= 0) { w1 = uh * uw; o1 = hl * a.W + wl; }
-                            if (hl >= 0 && wh <= a.W - 1) { w2 = uh * lw; o2 = hl * a.W + wh; }
-                            if (hh <= a.H - 1 && wl >= 0) { w3 = lh * uw; o3 = hh * a.W + wl; }
-                            if (hh <= a.H - 1 && wh <= a.W - 1) { w4 = lh * lw; o4 = hh * a.W + wh; }
-                        }
-                    }
+                    // rows past M read row M - 1 and are switched off through `drop_all`; no lane mask in an SGPR (common.h)
+                    const int row = m0 + p * RPP + rsub;
+                    const float *omp = a.om + (size_t)min(row, a.M - 1) * a.om_cs;
+                    const float dh = omp[2 * tap], dw = omp[2 * tap + 1], mk = omp[2 * KK + tap];
+                    float wq[4];
+                    int oq[4], drop[4];
+                    dcn_corners((float)(hi0[p] + ti * a.dil) + dh, (float)(wi0[p] + tj * a.dil) + dw, a.H, a.W,
+                                sign_smear(a.M - 1 - row), wq, oq, drop);
+                    const float w1 = wq[0], w2 = wq[1], w3 = wq[2], w4 = wq[3];
+                    const int o1 = oq[0] & ~drop[0], o2 = oq[1] & ~drop[1], o3 = oq[2] & ~drop[2], o4 = oq[3] & ~drop[3];
                     // the modulation mask is folded into the corner weights once per tap (dcn_v2_im2col_cuda.cu:174)
                     bw[p][0] = w1 * mk; bw[p][1] = w2 * mk; bw[p][2] = w3 * mk; bw[p][3] = w4 * mk;
                     doff[p][0] = ((unsigned)(pix_base[p] + o1) * (unsigned)a.in_cs + (unsigned)csub) * 4u;

@@ -208,9 +208,11 @@ def test_conv_bf16_halo_tile_matches_torch(case):
 
 
 def test_dcn_bf16_run_to_run_identical():
-    """Deformable mode at full-size grids (3840 workgroups): 4 launches on the same operands must agree bit for bit.  The
-    sampling state is traded between lanes (ds_bpermute) and built from predicates; a first version of that code produced wrong
-    predicates in lanes 48-63 of a wave about once per thousand workgroups -- a rate only a large grid shows."""
+    """Deformable mode at full-size grids (3840 workgroups, two waves per SIMD): 24 launches on the same operands must agree bit
+    for bit.  Sampling code written with compares (v_cmp -> s_and_b64 -> v_cndmask on SGPR lane masks) dropped one corner in
+    lanes 48-63 of a wave once per 10^5..10^6 (pixel, tap) states, at a rate that changed with every recompile (0 of 800
+    launches for one build, every launch for another): csrc/common.h `dcn_corners` keeps every decision in VGPR sign masks.
+    tools/dcn_determinism.py is the long form of this test (300 launches, per-corner analysis of a difference)."""
     from m3dssd_amd import _hip
     from m3dssd_amd.engine_bf16 import pack_conv_bf16
     L, dev = _hip.lib(), _dev()
@@ -222,7 +224,7 @@ def test_dcn_bf16_run_to_run_identical():
         om = torch.cat([torch.randn(b * h * w, 2 * kk, generator=g) * 2.0, torch.rand(b * h * w, kk, generator=g),
                         torch.zeros(b * h * w, 32 - 3 * kk)], 1).contiguous().to(dev)
         outs = []
-        for _ in range(4):
+        for _ in range(24):
             out = torch.zeros(b * h * w, cout, device=dev, dtype=BF16)
             d = _hip.ConvBf16Desc()
             d.inp, d.in_cs, d.N, d.H, d.W, d.Cin = x.data_ptr(), cin, b, h, w, cin

@@ -429,9 +429,10 @@ def test_rccl_single_rank_collective_runs():
 
 @pytest.mark.gpu
 def test_dcn_wave_fp32_run_to_run_identical_at_large_grids():
-    """The fp32 deformable wave kernel shares one sampling state per pixel through LDS, like the first bf16 version whose
-    predicates went wrong in lanes 48-63 about once per thousand workgroups.  15360 waves, 3 launches on the
-    same operands, bit-identical outputs."""
+    """Run-to-run identity of the fp32 deformable wave kernel at a full-size grid (15360 waves, two per SIMD): the bf16 kernel's
+    sampling code, written with compares, dropped a corner in lanes 48-63 of a wave once per 10^5..10^6 states (DESIGN.md
+    section 3); all three deformable kernels now build the state through `dcn_corners` (csrc/common.h, no SGPR lane masks).
+    12 launches on the same operands, bit-identical outputs."""
     import ctypes
 
     import torch
@@ -449,7 +450,7 @@ def test_dcn_wave_fp32_run_to_run_identical_at_large_grids():
         om = torch.cat([torch.randn(b * h * w, 2 * kk, generator=g) * 2.0, torch.rand(b * h * w, kk, generator=g),
                         torch.zeros(b * h * w, 28 - 3 * kk)], 1).contiguous().to(dev)
         outs = []
-        for _ in range(3):
+        for _ in range(12):
             out = torch.zeros(b * h * w * cout, device=dev)
             d = _hip.ConvDesc()
             d.inp, d.in_cs, d.N, d.H, d.W, d.Cin = x.data_ptr(), cin, b, h, w, cin

@@ -1,5 +1,5 @@
-// Attempt to reproduce, in isolation, the wrong-predicate event seen in the first bf16 DCNv2 state-sharing code (DESIGN.md
-// section 3): a four-compare range test compiled to back-to-back v_cmp -> s_and_b64 chains gave lanes 48-63 of a wave the wrong
+// Attempt to reproduce, in isolation, the wrong-predicate event seen in the bf16 DCNv2 sampling code (the
+// kernels now avoid SGPR lane masks there altogether, csrc/common.h dcn_corners): a four-compare range test compiled to back-to-back v_cmp -> s_and_b64 chains gave lanes 48-63 of a wave the wrong
 // predicate about once per thousand workgroups.  Every wave evaluates the test in that form (A) and in the single-compare form
 // (B) on the same operands, `iters` times with fresh operands, while the other waves of the workgroup stream MFMAs / LDS
 // traffic; any lane where A != B is counted.
