@@ -402,6 +402,14 @@ void _nms(int *keep_out, int *num_out, const float *boxes_host, int boxes_num, i
  * ------------------------------------------------------------------------------------------ */
 int m3d_refine_3d(const float *aboxes, const int *counts, int B, int K, const double *p2, const double *p2_inv,
                   double score_thresh, int hill_climbing, double step_r_init, double r_lim, double *out, m3d_stream_t stream);
+/* The same with the two per-image steps im_detect_3d / test_kitti_3d apply between NMS and the loop folded in, so that the call can
+ * sit in a captured graph right behind m3d_select_post: scale [B] fp32 (device, or NULL) -- x1 y1 x2 y2 x3d y3d are divided by
+ * scale[b] in float32 first (lib/rpn_util.py:1528-1531, `aboxes[:, 0:4] /= scale_factor`); clip_wh [B][2] fp32 = (imW, imH)
+ * (device, or NULL; an entry <= 0 disables it) -- the 2-D box is then clipped to [0, imW - 1] x [0, imH - 1] (:1533-1538).  The
+ * rows themselves are not modified.  K may include the count row of a m3d_select_post block (it lies past counts[b]). */
+int m3d_refine_3d_ex(const float *aboxes, const int *counts, int B, int K, const double *p2, const double *p2_inv,
+                     const float *scale, const float *clip_wh, double score_thresh, int hill_climbing, double step_r_init,
+                     double r_lim, double *out, m3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * KITTI AP evaluator natives (lib/eval/eval.py, lib/eval/rotate_iou.py of the reference, which compiles them

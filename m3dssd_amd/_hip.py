@@ -115,6 +115,7 @@ SIGNATURES = {
     "m3d_nhwc_to_nchw": (c_int, [P, c_int, P] + [c_int] * 4 + [P]),
     "m3d_stem_conv7x7": (c_int, [P, P, P, P, P] + [c_int] * 4 + [P]),
     "m3d_refine_3d": (c_int, [P, P, c_int, c_int, P, P, ctypes.c_double, c_int, ctypes.c_double, ctypes.c_double, P, P]),
+    "m3d_refine_3d_ex": (c_int, [P, P, c_int, c_int, P, P, P, P, ctypes.c_double, c_int, ctypes.c_double, ctypes.c_double, P, P]),
     "m3d_preprocess_u8": (c_int, [P, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), P, c_int,
                                   c_int, P]),
     "m3d_stem_conv7x7_u8": (c_int, [P, c_int, c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), P, P, P, P,

@@ -20,6 +20,8 @@ struct RefineArgs {
     const double *p2;        // [B][16] row-major 4x4 projection matrices
     const double *p2_inv;    // [B][16] their inverses (np.linalg.inv on the host, as the reference computes them)
     double *out;             // [B][K][16]: valid, cls, alpha, x1, y1, x2, y2, h3d, w3d, l3d, x3d, y3d, z3d, ry3d, score, 0
+    const float *scale;      // [B] or null: rows are divided back to the original image scale first (lib/rpn_util.py:1528-1531)
+    const float *clip_wh;    // [B][2] = (imW, imH) or null: then the 2-D box is clipped to the image (:1533-1538); <= 0: not clipped
     int B, K, hill_climbing;
     double score_thresh, step_r_init, r_lim, step_z_init, z_lim, min_ol_dif;
 };
@@ -85,7 +87,16 @@ __global__ void refine3d_kernel(const RefineArgs a)
         return;
     }
     const double *p2 = a.p2 + (size_t)b * 16, *pi = a.p2_inv + (size_t)b * 16;
-    const float x1f = r[0], y1f = r[1], x2f = r[2], y2f = r[3], x3f = r[6], y3f = r[7];
+    float x1f = r[0], y1f = r[1], x2f = r[2], y2f = r[3], x3f = r[6], y3f = r[7];
+    if (a.scale) {                                     // np.float32 divisions, as `aboxes[:, 0:4] /= scale_factor` does them
+        const float sf = a.scale[b];
+        x1f /= sf; y1f /= sf; x2f /= sf; y2f /= sf; x3f /= sf; y3f /= sf;
+    }
+    if (a.clip_wh) {
+        const float cw = a.clip_wh[2 * b], ch = a.clip_wh[2 * b + 1];
+        if (cw > 0.f) { x1f = fminf(fmaxf(x1f, 0.f), cw - 1.f); x2f = fminf(fmaxf(x2f, 0.f), cw - 1.f); }
+        if (ch > 0.f) { y1f = fminf(fmaxf(y1f, 0.f), ch - 1.f); y2f = fminf(fmaxf(y2f, 0.f), ch - 1.f); }
+    }
     const double x1 = x1f, y1 = y1f, x2 = x2f, y2 = y2f;
     double z3d = r[8];
     bool z_f32 = true;                                                         // z3d is still the row's np.float32
@@ -138,17 +149,26 @@ __global__ void refine3d_kernel(const RefineArgs a)
     o[7] = h3d; o[8] = w3d; o[9] = l3d; o[10] = X; o[11] = Y + h3d / 2; o[12] = Z; o[13] = ry; o[14] = score; o[15] = 0.0;
 }
 
-extern "C" int m3d_refine_3d(const float *aboxes, const int *counts, int B, int K, const double *p2, const double *p2_inv,
-                             double score_thresh, int hill_climbing, double step_r_init, double r_lim, double *out,
-                             m3d_stream_t stream)
+extern "C" int m3d_refine_3d_ex(const float *aboxes, const int *counts, int B, int K, const double *p2, const double *p2_inv,
+                                const float *scale, const float *clip_wh, double score_thresh, int hill_climbing,
+                                double step_r_init, double r_lim, double *out, m3d_stream_t stream)
 {
     M3D_REQUIRE(aboxes && counts && p2 && p2_inv && out && B >= 1 && K >= 1, "refine_3d: bad arguments");
     M3D_REQUIRE(step_r_init >= 0 && r_lim >= 0, "refine_3d: negative step / limit");
     RefineArgs a;
     a.aboxes = aboxes; a.counts = counts; a.p2 = p2; a.p2_inv = p2_inv; a.out = out; a.B = B; a.K = K;
+    a.scale = scale; a.clip_wh = clip_wh;
     a.hill_climbing = hill_climbing; a.score_thresh = score_thresh; a.step_r_init = step_r_init; a.r_lim = r_lim;
     a.step_z_init = 0.0; a.z_lim = 0.0; a.min_ol_dif = 0.0;                   // the values test_kitti_3d passes (:1833)
     hipLaunchKernelGGL(refine3d_kernel, dim3(cdiv(B * K, 64)), dim3(64), 0, (hipStream_t)stream, a);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
+}
+
+extern "C" int m3d_refine_3d(const float *aboxes, const int *counts, int B, int K, const double *p2, const double *p2_inv,
+                             double score_thresh, int hill_climbing, double step_r_init, double r_lim, double *out,
+                             m3d_stream_t stream)
+{
+    return m3d_refine_3d_ex(aboxes, counts, B, K, p2, p2_inv, nullptr, nullptr, score_thresh, hill_climbing, step_r_init, r_lim,
+                            out, stream);
 }

@@ -4,7 +4,8 @@ label folder.
 
 What changes on the MI355X path: the reference handles ONE image per iteration (forward, host decode / sort / NMS, a Python
 loop of <= 40 boxes x ~14 projections); here frames are grouped into batches of ``rpn_conf.batch_size`` and each batch is
-forward -> decode -> top-k -> NMS -> select (``detect_batch``) -> ``m3d_refine_3d`` on the device; the host only formats text.
+forward -> decode -> top-k -> NMS -> select -> ``m3d_refine_3d_ex`` on the device, full batches inside ONE captured hipGraph
+(forward of batch k beside the detection + refinement of batch k-1); the host only formats text.
 The result files and the printed AP tables are the reference's, byte for byte, given the same detections.
 """
 import logging
@@ -32,29 +33,67 @@ def _get(obj, key, default=None):
     return getattr(obj, key, default)
 
 
-def _flush(ims, metas, net, rpn_conf, results_path, dev):
-    x = torch.cat([im if im.dim() == 4 else im[None] for im in ims]).to(dev, torch.float32)
-    dets, counts = detect_batch(net, x, rpn_conf)
-    dets = dets.clone()
-    B = dets.shape[0]
-    scale = torch.tensor([float(_get(m, "scale_factor", 1.0) or 1.0) for m in metas], device=dev, dtype=torch.float32)
-    if bool((scale != 1.0).any()):                      # lib/rpn_util.py:1528-1531: back to the original image scale
-        dets[:, :, 0:4] /= scale[:, None, None]
-        dets[:, :, 6:8] /= scale[:, None, None]
-    if getattr(rpn_conf, "clip_boxes", False):          # :1533-1538
+def _meta_arrays(metas, rpn_conf):
+    """Per-image calibration / scale / clip size of a batch, as m3d_refine_3d_ex takes them."""
+    p2 = np.stack([np.asarray(_get(m, "p2"), dtype=np.float64).reshape(4, 4) for m in metas])
+    scale = np.asarray([float(_get(m, "scale_factor", 1.0) or 1.0) for m in metas], dtype=np.float32)   # rpn_util.py:1528-1531
+    clip = np.zeros((len(metas), 2), dtype=np.float32)
+    if getattr(rpn_conf, "clip_boxes", False):                                                           # :1533-1538
         for b, m in enumerate(metas):
             w, h = _get(m, "imW"), _get(m, "imH")
             if w is not None and h is not None:
-                dets[b, :, 0].clamp_(0, w - 1)
-                dets[b, :, 2].clamp_(0, w - 1)
-                dets[b, :, 1].clamp_(0, h - 1)
-                dets[b, :, 3].clamp_(0, h - 1)
-    p2 = np.stack([np.asarray(_get(m, "p2"), dtype=np.float64).reshape(4, 4) for m in metas])
-    ref = R.refine_detections(dets, counts, p2, hill_climbing=bool(getattr(rpn_conf, "hill_climbing", True))).cpu().numpy()
+                clip[b] = (w, h)
+    return {"p2": p2, "scale": scale, "clip_wh": clip}
+
+
+def _write(refined, metas, rpn_conf, results_path):
+    ref = refined.cpu().numpy()
     for b, m in enumerate(metas):
         with open(os.path.join(results_path, str(_get(m, "id")) + ".txt"), "w") as f:
             f.write(R.kitti_text(ref[b], rpn_conf.lbls))
-    return B
+
+
+def _flush(ims, metas, net, rpn_conf, results_path, dev):
+    """A batch outside the pipelined graph (the ragged last one, or a one-off padded size): eager launches."""
+    x = torch.cat([im if im.dim() == 4 else im[None] for im in ims]).to(dev, torch.float32)
+    dets, counts = detect_batch(net, x, rpn_conf)
+    meta = _meta_arrays(metas, rpn_conf)
+    ref = R.refine_detections(dets, counts, meta["p2"], hill_climbing=bool(getattr(rpn_conf, "hill_climbing", True)),
+                              scale=meta["scale"], clip_wh=meta["clip_wh"])
+    _write(ref, metas, rpn_conf, results_path)
+    return dets.shape[0]
+
+
+class _Pipelined:
+    """Full batches go through one captured hipGraph per input shape (m3dssd_amd.pipeline.PipelinedDetector, refine=True):
+    forward(batch k) || decode -> top-k -> NMS -> select -> m3d_refine_3d_ex of batch k-1; the host formats the text of batch
+    k-1 while batch k runs."""
+
+    def __init__(self, net, rpn_conf, results_path, dev):
+        self.net, self.conf, self.path, self.dev = net, rpn_conf, results_path, dev
+        self.pipes = {}
+        self.open = None                      # (pipe, metas) of the batch in flight
+
+    def submit(self, ims, metas):
+        from ..pipeline import PipelinedDetector
+        x = torch.cat([im if im.dim() == 4 else im[None] for im in ims]).to(self.dev, torch.float32)
+        key = tuple(x.shape)
+        pipe = self.pipes.get(key)
+        if pipe is None:
+            pipe = self.pipes[key] = PipelinedDetector(self.net, self.conf, key[0], key[2], key[3], refine=True)
+        if self.open is not None and self.open[0] is not pipe:
+            self.drain()
+        res = pipe.step(x, meta=_meta_arrays(metas, self.conf))
+        if res is not None:
+            _write(res[2], self.open[1], self.conf, self.path)
+        self.open = (pipe, metas)
+        return len(metas)
+
+    def drain(self):
+        if self.open is not None:
+            res = self.open[0].flush()
+            _write(res[2], self.open[1], self.conf, self.path)
+            self.open = None
 
 
 def test_kitti_3d(dataset_test, net, rpn_conf, results_path, test_path, use_log=True, writer=None, phase="validation"):
@@ -65,18 +104,21 @@ def test_kitti_3d(dataset_test, net, rpn_conf, results_path, test_path, use_log=
     net.eval()
     bs = max(1, int(getattr(rpn_conf, "batch_size", 1)))
     ims, metas, n_done = [], [], 0
+    pipe = _Pipelined(net, rpn_conf, results_path, dev)
     with torch.no_grad():
         for batch in dataset_test:
             im, meta = _unpack(batch, rpn_conf)
             im = torch.as_tensor(im)
             if ims and tuple(im.shape[-2:]) != tuple(ims[0].shape[-2:]):      # a different padded size: finish the open batch
+                pipe.drain()
                 n_done += _flush(ims, metas, net, rpn_conf, results_path, dev)
                 ims, metas = [], []
             ims.append(im)
             metas.append(meta)
             if len(ims) == bs:
-                n_done += _flush(ims, metas, net, rpn_conf, results_path, dev)
+                n_done += pipe.submit(ims, metas)
                 ims, metas = [], []
+        pipe.drain()
         if ims:
             n_done += _flush(ims, metas, net, rpn_conf, results_path, dev)
     key = "datasets_{}".format(phase)

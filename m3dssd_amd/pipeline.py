@@ -10,15 +10,27 @@ the forward of the NEXT batch: one captured hipGraph per input shape whose two b
 
 so each ``step(x)`` returns the detections of the PREVIOUS batch (one batch of pipeline latency) and ``flush()``
 drains the last one.  Results are identical to ``lib.rpn_util.detect_batch`` (tests/test_gpu_parity.py).
+
+``refine=True`` appends the post-NMS 3-D refinement of ``test_kitti_3d`` (lib/rpn_util.py:1796-1847: back to the original image
+scale, clipping, alpha -> ry, hill climbing, back-projection; ``m3d_refine_3d_ex``) to branch B, reading the selected rows where
+``m3d_select_post`` left them: a replay then yields the rows of the KITTI result files of batch k-1.
 """
+import ctypes
+import math
+
+import numpy as np
 import torch
 
+from . import _hip
 from .host.detect import detect_from_outputs, select_block
+from .host.refine import p2_arrays
 
 
 class PipelinedDetector:
-    def __init__(self, net, conf, batch, height, width):
+    def __init__(self, net, conf, batch, height, width, refine=False, score_thresh=0.75, step_r_init=0.3 * math.pi, r_lim=0.01):
         self.net, self.conf = net, conf
+        self.refine = bool(refine)
+        self._rargs = (float(score_thresh), 1 if bool(getattr(conf, "hill_climbing", True)) else 0, float(step_r_init), float(r_lim))
         dev = next(net.parameters()).device
         if dev.type != "cuda":
             raise NotImplementedError("PipelinedDetector needs the module on a ROCm device")
@@ -32,11 +44,30 @@ class PipelinedDetector:
         self._outs = (n["prob"], n["bbox_2d"], n["bbox_3d"])
         self._rois = net.rois.to(dev)
         self._pending = False
+        if self.refine:
+            # calibration / scale / image size of the batch whose detections the NEXT replay refines; `_meta_next` (host) holds
+            # those of the batch submitted last
+            self._p2 = torch.zeros(batch, 16, device=dev, dtype=torch.float64)
+            self._p2_inv = torch.zeros(batch, 16, device=dev, dtype=torch.float64)
+            self._p2[:, 0::5] = 1.0
+            self._p2_inv[:, 0::5] = 1.0
+            self._scale = torch.ones(batch, device=dev, dtype=torch.float32)
+            self._clip = torch.zeros(batch, 2, device=dev, dtype=torch.float32)
+            self._meta_next = None
         self._build()
 
     def _detect(self):
         prob, b2, b3 = self._outs
-        return select_block(*detect_from_outputs(self.eng, self.plan, prob, b2, b3, self._rois, self.conf), self.conf)
+        block, counts = select_block(*detect_from_outputs(self.eng, self.plan, prob, b2, b3, self._rois, self.conf), self.conf)
+        if not self.refine:
+            return block, counts, None
+        B, K1, _ = block.shape                          # K1 = kept rows + the count row (past counts[b]: refined to zeros)
+        out = torch.empty(B, K1, 16, device=self.dev, dtype=torch.float64)
+        st = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        _hip.check(_hip.lib().m3d_refine_3d_ex(block.data_ptr(), counts.data_ptr(), B, K1, self._p2.data_ptr(),
+                                               self._p2_inv.data_ptr(), self._scale.data_ptr(), self._clip.data_ptr(),
+                                               *self._rargs, out.data_ptr(), st))
+        return block, counts, out
 
     def _forward(self, start, end):
         self.plan.named["input_ptr"][0] = self.input.data_ptr()
@@ -53,33 +84,60 @@ class PipelinedDetector:
             with torch.cuda.graph(self.graph, stream=cap):
                 side.wait_stream(cap)                    # fork
                 with torch.cuda.stream(side):
-                    self._block, self._counts = self._detect()      # batch k-1
+                    self._block, self._counts, self._refined = self._detect()      # batch k-1
                 self._forward(0, self.n_fwd)             # batch k, everything but the bundling
                 cap.wait_stream(side)                    # join: outputs may now be overwritten
                 self._forward(self.n_fwd, None)
             # tail graph for flush(): detect only
             self.tail = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.tail, stream=cap):
-                self._tblock, self._tcounts = self._detect()
+                self._tblock, self._tcounts, self._trefined = self._detect()
         torch.cuda.current_stream(self.dev).wait_stream(cap)
 
-    def step(self, x=None, as_block=False):
+    def _upload_meta(self):
+        """Calibration of the batch submitted LAST -> the device buffers the refinement of the next replay reads."""
+        m = self._meta_next
+        if m is None:
+            return
+        B = self.input.shape[0]
+        p2, p2_inv = p2_arrays(m["p2"], B)
+        self._p2.copy_(torch.from_numpy(p2.reshape(B, 16)))
+        self._p2_inv.copy_(torch.from_numpy(p2_inv.reshape(B, 16)))
+        scale = m.get("scale")
+        self._scale.copy_(torch.from_numpy(np.ones(B, np.float32) if scale is None else np.asarray(scale, np.float32).reshape(B)))
+        clip = m.get("clip_wh")
+        self._clip.copy_(torch.from_numpy(np.zeros((B, 2), np.float32) if clip is None
+                                          else np.asarray(clip, np.float32).reshape(B, 2)))
+
+    def step(self, x=None, as_block=False, meta=None):
         """Submit batch k (copied into ``self.input`` unless x is None = already written there); returns
         (dets, counts) of batch k-1, or None for the first call.  Returned tensors are overwritten by the next step.
-        as_block: return the [B, nms_topN_post + 1, 14] gather block (m3dssd_amd.dist.gather_block) instead of dets."""
+        as_block: return the [B, nms_topN_post + 1, 14] gather block (m3dssd_amd.dist.gather_block) instead of dets.
+        refine mode: meta = {"p2": [B, 4, 4] (or [4, 4]), "scale": [B] or None, "clip_wh": [B, 2] or None} of batch k; the
+        return value gains a third element, the refined rows [B, nms_topN_post, 16] (float64) of batch k-1."""
         if x is not None:
             self.input.copy_(x)
         had = self._pending
+        if self.refine:
+            if meta is None:
+                raise RuntimeError("PipelinedDetector(refine=True).step needs the batch's meta (p2, scale, clip_wh)")
+            self._upload_meta()                      # of batch k-1: what this replay's refinement reads
+            self._meta_next = meta
         self.graph.replay()
         self._pending = True
         if not had:
             return None
-        return (self._block if as_block else self._block[:, :-1], self._counts)
+        res = (self._block if as_block else self._block[:, :-1], self._counts)
+        return res + (self._refined[:, :-1],) if self.refine else res
 
     def flush(self, as_block=False):
         """Detections of the last submitted batch."""
         if not self._pending:
             return None
+        if self.refine:
+            self._upload_meta()
+            self._meta_next = None
         self.tail.replay()
         self._pending = False
-        return (self._tblock if as_block else self._tblock[:, :-1], self._tcounts)
+        res = (self._tblock if as_block else self._tblock[:, :-1], self._tcounts)
+        return res + (self._trefined[:, :-1],) if self.refine else res

@@ -946,6 +946,30 @@ def test_pipelined_detector_matches_detect_batch():
     assert len(got) == 3
     for (gd, gc), (rd, rc) in zip(got, ref):
         assert torch.equal(gc, rc) and torch.equal(gd, rd)
+    # refine mode: the post-NMS refinement of test_kitti_3d inside the same captured graph, with the calibration / scale / clip
+    # size of batch k-1 while batch k is in flight == the eager call on detect_batch's rows, bit for bit
+    from m3dssd_amd.host import refine as HR
+    p2 = np.array([[721.5377, 0.0, 609.5593, 44.85728], [0.0, 721.5377, 172.854, 0.2163791], [0.0, 0.0, 1.0, 0.002745884],
+                   [0.0, 0.0, 0.0, 1.0]])
+    metas = [{"p2": np.stack([p2, p2 * np.array([[1.0 + 0.01 * i], [1.0], [1.0], [1.0]])]),
+              "scale": np.array([1.0, 0.9 - 0.1 * i], np.float32), "clip_wh": np.array([[0, 0], [300, 100 + i]], np.float32)}
+             for i in range(3)]
+    pipe = PipelinedDetector(net, conf, 2, 128, 320, refine=True)
+    with pytest.raises(RuntimeError):
+        pipe.step(xs[0])                                   # refine mode needs the batch's meta
+    outs = []
+    for x, m in zip(xs, metas):
+        r = pipe.step(x, meta=m)
+        if r is not None:
+            outs.append(tuple(t.clone() for t in r))
+    outs.append(tuple(t.clone() for t in pipe.flush()))
+    assert len(outs) == 3
+    for (gd, gc, gr), (rd, rc), m in zip(outs, ref, metas):
+        assert torch.equal(gc, rc) and torch.equal(gd, rd)
+        want = HR.refine_detections(rd, rc, m["p2"], hill_climbing=bool(getattr(conf, "hill_climbing", True)), scale=m["scale"],
+                                    clip_wh=m["clip_wh"])
+        assert gr.shape == want.shape and torch.equal(gr, want)
+        assert float(gr[:, :, 0].sum()) > 0                # some rows were refined
 
 
 # ------------------------------------------------------------------------------------ test-time input path (8f row 4)

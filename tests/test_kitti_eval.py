@@ -193,6 +193,27 @@ def test_test_kitti_3d_writes_results_and_evaluates(tmp_path):
         ref = R.refine_detections(dets.clone(), counts, np.stack([p2] * (hi - lo))).cpu().numpy()
         for b in range(hi - lo):
             assert open(res_dir / ("%06d.txt" % (lo + b))).read() == R.kitti_text(ref[b], conf.lbls)
+    # scale_factor != 1 and clip_boxes (lib/rpn_util.py:1528-1538): applied inside m3d_refine_3d_ex (full batches: in the captured
+    # graph) == the reference's float32 array operations followed by the plain refinement
+    conf.clip_boxes = True
+    scales = [0.8 + 0.05 * i for i in range(7)]
+    dataset2 = [(frames[i:i + 1], Conf(id="%06d" % i, p2=p2, scale_factor=scales[i], imW=300, imH=110)) for i in range(7)]
+    res2 = tmp_path / "results2" / "data"
+    test_kitti_3d(dataset2, net, conf, str(res2), str(tmp_path), use_log=False, phase="train")
+    n_clipped = 0
+    for lo, hi in ((0, 3), (3, 6), (6, 7)):
+        dets, counts = detect_batch(net, frames[lo:hi].to(dev), conf)
+        d = dets.clone()
+        sc = torch.tensor(scales[lo:hi], device=dev, dtype=torch.float32)
+        d[:, :, 0:4] /= sc[:, None, None]
+        d[:, :, 6:8] /= sc[:, None, None]
+        n_clipped += int((d[:, :, 2] > 299).sum()) + int((d[:, :, 3] > 109).sum())
+        d[:, :, 0].clamp_(0, 299); d[:, :, 2].clamp_(0, 299); d[:, :, 1].clamp_(0, 109); d[:, :, 3].clamp_(0, 109)
+        ref = R.refine_detections(d, counts, np.stack([p2] * (hi - lo))).cpu().numpy()
+        for b in range(hi - lo):
+            assert open(res2 / ("%06d.txt" % (lo + b))).read() == R.kitti_text(ref[b], conf.lbls), (lo, b)
+    assert n_clipped > 0                                             # the clip really acted on some box
+    conf.clip_boxes = False
     ab = im_detect_3d(frames[6], net, conf)                          # and the reference-style single-image entry (same batch of 1)
     assert np.array_equal(ab[:conf.nms_topN_post], detect_batch(net, frames[6:7].to(dev), conf)[0][0, :len(ab)].cpu().numpy())
     n_lines = 0
