@@ -53,7 +53,22 @@ __device__ __forceinline__ unsigned fpack(float lo, float hi)
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
-__global__ __launch_bounds__(FE_NT) void bf16_frontend_kernel(const FrontArgs a)
+// Epilogue of one MFMA column group: 4 channels of a pixel -> folded BatchNorm + LeakyReLU on the packed-fp32 pipe (2 v_pk_fma +
+// 2 v_pk_mul + 4 v_max instead of 12 scalar ops), two bf16 pairs, zeroed through `msk` (0 / ~0) where the pixel lies outside
+// the image.  The kernel is VALU-bound (SQ_INSTS_VALU 320 M per launch, MFMA 17 % busy): instructions here are time.
+__device__ __forceinline__ u32x2 fe_epilogue(const f32x4 acc, const f32x2 sc01, const f32x2 sc23, const f32x2 sh01, const f32x2 sh23,
+                                             unsigned msk)
+{
+    const f32x2 sl = {M3D_LEAKY_SLOPE, M3D_LEAKY_SLOPE};
+    const f32x2 y01 = __builtin_elementwise_fma(f32x2{acc[0], acc[1]}, sc01, sh01);
+    const f32x2 y23 = __builtin_elementwise_fma(f32x2{acc[2], acc[3]}, sc23, sh23);
+    const f32x2 z01 = y01 * sl, z23 = y23 * sl;
+    return u32x2{fpack(fmaxf(y01[0], z01[0]), fmaxf(y01[1], z01[1])) & msk, fpack(fmaxf(y23[0], z23[0]), fmaxf(y23[1], z23[1])) & msk};
+}
+
+// amdgpu_waves_per_eu(2): two workgroups per CU is what the LDS tiles allow anyway, and with at most 256 registers per wave hipcc
+// keeps the MFMA accumulators in VGPRs (no v_accvgpr_read before every epilogue).
+__global__ __launch_bounds__(FE_NT) __attribute__((amdgpu_waves_per_eu(2))) void bf16_frontend_kernel(const FrontArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[FE_IMH * FE_IMS * 8 + FE_S0H * FE_S0W * FE_PS0 + FE_L0H * FE_L0W * FE_PS + 64];
     unsigned char *imt = lds;                                   // [25][76][4 bf16]
@@ -121,11 +136,14 @@ __global__ __launch_bounds__(FE_NT) void bf16_frontend_kernel(const FrontArgs a)
 #pragma unroll
         for (int i = 0; i < 7; ++i) wf[i] = *reinterpret_cast<const bf16x8 *>((const __bf16 *)a.w_stem + l15 * 224 + i * 32 + kg * 8);
         const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.s_stem + 4 * kg), sh = *reinterpret_cast<const f32x4 *>(a.t_stem + 4 * kg);
+        const f32x2 sc01 = {sc[0], sc[1]}, sc23 = {sc[2], sc[3]}, sh01 = {sh[0], sh[1]}, sh23 = {sh[2], sh[3]};
         constexpr int NP = FE_S0H * FE_S0W, NG = (NP + 15) / 16;
+        // pixel p = g*16 + l15 of the flattened region, g = wave, wave + 4, ...: (row, column) advance by 64 pixels per iteration
+        // without a division (the groups past NP read one tile row further -- still inside `lds` -- and are not stored)
+        constexpr int QS = (16 * FE_NW) / FE_S0W, RS = (16 * FE_NW) % FE_S0W;
+        int p = wave * 16 + l15;
+        int ry = p / FE_S0W, rx = p - ry * FE_S0W;
         for (int g = wave; g < NG; g += FE_NW) {
-            const int p = g * 16 + l15;
-            const int pc = p < NP ? p : NP - 1;
-            const int ry = pc / FE_S0W, rx = pc - ry * FE_S0W;
             // tap row i, taps j = 2*kg, 2*kg + 1 of pixel (ry, rx): image tile pixels (ry + i, rx + 2*kg + {0, 1})
             const unsigned char *src = imt + ((size_t)ry * FE_IMS + rx + 2 * kg) * 8;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -137,11 +155,11 @@ __global__ __launch_bounds__(FE_NT) void bf16_frontend_kernel(const FrontArgs a)
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
             }
             const int h = YS + ry, w = XS + rx;
-            const bool inside = h >= 0 && h < H && w >= 0 && w < W;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = inside ? leaky(acc[e] * sc[e] + sh[e]) : 0.f;
-            if (p < NP) *reinterpret_cast<u32x2 *>(s0t + (size_t)p * FE_PS0 + kg * 8) = u32x2{fpack(v[0], v[1]), fpack(v[2], v[3])};
+            const unsigned msk = ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) ? ~0u : 0u;
+            if (p < NP) *reinterpret_cast<u32x2 *>(s0t + (size_t)p * FE_PS0 + kg * 8) = fe_epilogue(acc, sc01, sc23, sh01, sh23, msk);
+            p += 16 * FE_NW;
+            rx += RS; ry += QS;
+            if (rx >= FE_S0W) { rx -= FE_S0W; ry += 1; }
         }
     }
     __syncthreads();
@@ -152,6 +170,7 @@ __global__ __launch_bounds__(FE_NT) void bf16_frontend_kernel(const FrontArgs a)
 #pragma unroll
         for (int t = 0; t < 5; ++t) wf[t] = *reinterpret_cast<const bf16x8 *>((const __bf16 *)a.w_l0 + l15 * 160 + t * 32 + kg * 8);
         const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.s_l0 + 4 * kg), sh = *reinterpret_cast<const f32x4 *>(a.t_l0 + 4 * kg);
+        const f32x2 sc01 = {sc[0], sc[1]}, sc23 = {sc[2], sc[3]}, sh01 = {sh[0], sh[1]}, sh23 = {sh[2], sh[3]};
         constexpr int NP = FE_L0H * FE_L0W, NG = (NP + 15) / 16;
         // k-group kg of K-step t reads tap 2t + (kg >> 1), channel half kg & 1; tap 9 (t = 4, kg >= 2) has zero weights: it
         // re-reads tap 8 so that the operand stays finite
@@ -162,21 +181,21 @@ __global__ __launch_bounds__(FE_NT) void bf16_frontend_kernel(const FrontArgs a)
             tap = tap > 8 ? 8 : tap;
             toff[t] = ((tap / 3) * FE_S0W + (tap % 3)) * FE_PS0 + (kg & 1) * 16;
         }
+        constexpr int QL = (16 * FE_NW) / FE_L0W, RL = (16 * FE_NW) % FE_L0W;
+        int p = wave * 16 + l15;
+        int ry = p / FE_L0W, rx = p - ry * FE_L0W;
         for (int g = wave; g < NG; g += FE_NW) {
-            const int p = g * 16 + l15;
-            const int pc = p < NP ? p : NP - 1;
-            const int ry = pc / FE_L0W, rx = pc - ry * FE_L0W;
             const unsigned char *src = s0t + ((size_t)ry * FE_S0W + rx) * FE_PS0;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 5; ++t)
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], *reinterpret_cast<const bf16x8 *>(src + toff[t]), acc, 0, 0, 0);
             const int h = Y0 + ry, w = X0 + rx;
-            const bool inside = h >= 0 && h < H && w >= 0 && w < W;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = inside ? leaky(acc[e] * sc[e] + sh[e]) : 0.f;
-            if (p < NP) *reinterpret_cast<u32x2 *>(l0t + (size_t)p * FE_PS + kg * 8) = u32x2{fpack(v[0], v[1]), fpack(v[2], v[3])};
+            const unsigned msk = ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) ? ~0u : 0u;
+            if (p < NP) *reinterpret_cast<u32x2 *>(l0t + (size_t)p * FE_PS + kg * 8) = fe_epilogue(acc, sc01, sc23, sh01, sh23, msk);
+            p += 16 * FE_NW;
+            rx += RL; ry += QL;
+            if (rx >= FE_L0W) { rx -= FE_L0W; ry += 1; }
         }
     }
     __syncthreads();
@@ -216,10 +235,8 @@ __global__ __launch_bounds__(FE_NT) void bf16_frontend_kernel(const FrontArgs a)
                     const f32x4 acc = hh ? acc1 : acc0;
                     const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.s_l1 + hh * 16 + 4 * kg);
                     const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.t_l1 + hh * 16 + 4 * kg);
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = leaky(acc[e] * sc[e] + sh[e]);
-                    *reinterpret_cast<u32x2 *>(op + hh * 16 + 4 * kg) = u32x2{fpack(v[0], v[1]), fpack(v[2], v[3])};
+                    *reinterpret_cast<u32x2 *>(op + hh * 16 + 4 * kg) =
+                        fe_epilogue(acc, f32x2{sc[0], sc[1]}, f32x2{sc[2], sc[3]}, f32x2{sh[0], sh[1]}, f32x2{sh[2], sh[3]}, ~0u);
                 }
             }
         }
