@@ -38,18 +38,20 @@ __device__ __forceinline__ void dcn_corners(float h_im, float w_im, int H, int W
                                             int (&drop)[4])
 {
     const float tin = fminf(fminf(h_im, w_im) + 1.f, -fmaxf(h_im - (float)H, w_im - (float)W));     // > 0: inside
-    const int xin = (int)__float_as_uint(tin);
-    const int out = sign_smear((xin - 1) | xin) | drop_all;                                          // tin <= 0 (or -0.0)
+    const unsigned xin = __float_as_uint(tin);
+    const int out = sign_smear((int)((xin - 1u) | xin)) | drop_all;                                   // tin <= 0 (or -0.0)
+    // far outside the image the float -> int conversions saturate: the index arithmetic below is unsigned (wrap-around, no
+    // signed overflow for the optimiser to reason about); its results are masked by `out` there
     const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
     const float lh = h_im - (float)hl, lw = w_im - (float)wl;
     const float uh = 1.f - lh, uw = 1.f - lw;
-    const int hr = H - 2 - hl, wr = W - 2 - wl;                       // >= 0: the high corner row / column is inside
+    const int hr = (int)((unsigned)(H - 2) - (unsigned)hl), wr = (int)((unsigned)(W - 2) - (unsigned)wl);   // >= 0: high row / column inside
     drop[0] = sign_smear(hl | wl) | out;
     drop[1] = sign_smear(hl | wr) | out;
     drop[2] = sign_smear(hr | wl) | out;
     drop[3] = sign_smear(hr | wr) | out;
-    const int row0 = __mul24(hl, W) + wl, row1 = row0 + W;
-    o[0] = row0; o[1] = row0 + 1; o[2] = row1; o[3] = row1 + 1;
+    const unsigned row0 = (unsigned)__mul24(hl, W) + (unsigned)wl, row1 = row0 + (unsigned)W;
+    o[0] = (int)row0; o[1] = (int)(row0 + 1u); o[2] = (int)row1; o[3] = (int)(row1 + 1u);
     const float wf[4] = {uh * uw, uh * lw, lh * uw, lh * lw};
 #pragma unroll
     for (int q = 0; q < 4; ++q) w[q] = __uint_as_float(__float_as_uint(wf[q]) & ~(unsigned)drop[q]);

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFORM ? 2 :
             u32x4 ob;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const unsigned off = (unsigned)(o_pix + oq[q]) * (unsigned)a.in_cs * 4u;
+                const unsigned off = ((unsigned)o_pix + (unsigned)oq[q]) * (unsigned)a.in_cs * 4u;    // garbage where dropped: masked next
                 ob[q] = (off & ~(unsigned)drop[q]) | (M3D_BUF_OOB & (unsigned)drop[q]);     // dropped corner: the load reads 0
             }
             if (h == 0) {
