@@ -419,6 +419,44 @@ def test_dcn_bf16_matches_oracle(shape):
     assert (got32 - ref).abs().max().item() < 1e-2 * scale
 
 
+def _border_grid_offsets(h, w):
+    """1x1 deformable conv whose output pixel (i, j) samples the input at (hs[i % 8], ws[j % 8]): every combination of the
+    in / out decisions of dcn_v2_im2col_cuda.cu:129-178 -- exactly -1 (out, the gate is strict), just inside, between rows, 0,
+    the last row, past the last row (one corner row dropped), just below H, exactly H (out)."""
+    hs = [-1.0, -0.999, -0.5, 0.0, h - 1.0, h - 0.5, h - 0.001, float(h)]
+    ws = [-1.0, -0.999, -0.5, 0.0, w - 1.0, w - 0.5, w - 0.001, float(w)]
+    off = torch.zeros(1, 2, h, w)
+    for i in range(h):
+        for j in range(w):
+            off[0, 0, i, j] = hs[i % 8] - i
+            off[0, 1, i, j] = ws[j % 8] - j
+    return off
+
+
+def test_dcn_bf16_sampling_border_grid():
+    """The corner in / out decisions of the sampling code (csrc/common.h dcn_corners: sign-smear masks instead of compares) on a
+    grid of exact border positions, bf16 kernel vs oracle/dcn.py, uniform-K and general-K paths (Cin 64 / 24)."""
+    from oracle import dcn as odcn
+    for c in (64, 24):
+        h, w, co = 16, 24, 32
+        g = torch.Generator().manual_seed(5 + c)
+        x = _r(torch.randn(1, c, h, w, generator=g) + 3.0)                  # offset from zero: a dropped corner shows
+        wt = _r(torch.randn(co, c, 1, 1, generator=g) / c ** 0.5)
+        b = torch.zeros(co)
+        off = _border_grid_offsets(h, w)
+        m = torch.ones(1, 1, h, w)
+        ref = odcn.dcn_v2_forward(x, off, m, wt, b, 1, 0, 1, 1)
+        om = torch.cat([off, m, torch.zeros(1, 1, h, w)], 1).permute(0, 2, 3, 1).contiguous()
+        got32 = _run_conv(x, wt, b, None, 1, 0, 0, None, 0, -1, 1, om)
+        scale = ref.abs().max().item()
+        assert (got32 - ref).abs().max().item() < 1e-2 * scale, c
+        # rows / columns sampled exactly at -1 or at H / W contribute nothing at all
+        assert torch.equal(got32[0, :, 0::8, :], torch.zeros_like(got32[0, :, 0::8, :])) and \
+            torch.equal(got32[0, :, 7::8, :], torch.zeros_like(got32[0, :, 7::8, :])) and \
+            torch.equal(got32[0, :, :, 0::8], torch.zeros_like(got32[0, :, :, 0::8])) and \
+            torch.equal(got32[0, :, :, 7::8], torch.zeros_like(got32[0, :, :, 7::8]))
+
+
 def test_bf16_helpers_match_torch():
     from m3dssd_amd import _hip
     L = _hip.lib()

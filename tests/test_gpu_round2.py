@@ -428,6 +428,38 @@ def test_rccl_single_rank_collective_runs():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout", [(32, 128), (20, 24)])
+def test_dcn_fp32_sampling_border_grid(cin, cout):
+    """The corner in / out decisions of the DCNv2 sampling code (csrc/common.h dcn_corners) at exact border positions through
+    the drop-in op: a 1x1 deformable conv whose pixel (i, j) samples at (hs[i % 8], ws[j % 8]) with hs / ws = -1 (out: the gate
+    is strict), just inside, between rows, 0, the last row, past it (the high corners dropped), just below H, exactly H (out).
+    (32, 128) runs the wave-granular kernel, (20, 24) the LDS-tiled implicit GEMM."""
+    import torch
+
+    from m3dssd_amd.host import ops
+    from oracle import dcn as odcn
+    dev = torch.device("cuda:0")
+    h, w = 16, 24
+    g = torch.Generator().manual_seed(cin)
+    x = torch.randn(1, cin, h, w, generator=g) + 3.0
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    b = torch.zeros(cout)
+    hs = [-1.0, -0.999, -0.5, 0.0, h - 1.0, h - 0.5, h - 0.001, float(h)]
+    ws = [-1.0, -0.999, -0.5, 0.0, w - 1.0, w - 0.5, w - 0.001, float(w)]
+    off = torch.zeros(1, 2, h, w)
+    for i in range(h):
+        for j in range(w):
+            off[0, 0, i, j] = hs[i % 8] - i
+            off[0, 1, i, j] = ws[j % 8] - j
+    m = torch.ones(1, 1, h, w)
+    ref = odcn.dcn_v2_forward(x, off, m, wt, b, 1, 0, 1, 1)
+    got = ops.dcn_v2_forward(x.to(dev), off.to(dev), m.to(dev), wt.to(dev), b.to(dev), 1, 0, 1, 1).cpu()
+    assert (got - ref).abs().max().item() < 2e-4 * ref.abs().max().item()
+    for sl in (got[0, :, 0::8, :], got[0, :, 7::8, :], got[0, :, :, 0::8], got[0, :, :, 7::8]):
+        assert torch.equal(sl, torch.zeros_like(sl))                 # sampled exactly at -1 / H / W: nothing at all
+
+
+@pytest.mark.gpu
 def test_dcn_wave_fp32_run_to_run_identical_at_large_grids():
     """Run-to-run identity of the fp32 deformable wave kernel at a full-size grid (15360 waves, two per SIMD): the bf16 kernel's
     sampling code, written with compares, dropped a corner in lanes 48-63 of a wave once per 10^5..10^6 states (DESIGN.md
