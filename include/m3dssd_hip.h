@@ -377,7 +377,9 @@ int m3d_decode_rows(const long long *rows /*[B][n_rows] row ids*/, const float *
                     int n_rows, m3d_stream_t stream);
 
 /* Greedy NMS on device.  boxes_dev [B][n][box_stride>=4] sorted by descending score; mask_ws needs
- * B*n*ceil(n/64) uint64.  keep_dev [B][n] int32 (kept positions, ascending), num_keep_dev [B]. */
+ * B*n*ceil(n/64) uint64.  keep_dev [B][n] int32 (kept positions, ascending), num_keep_dev [B].
+ * n <= 4096 (the reference's _nms is unbounded; the path calls it with nms_topN_pre = 3000 rows): larger n returns
+ * M3D_E_ARG -- one wave holds the whole "removed" bit set of an image in registers, 64 lanes x 64 bits. */
 long long m3d_nms_workspace_bytes(int B, int n);
 int m3d_nms_sorted_dev(const float *boxes_dev, int B, int n, int box_stride, float thresh, void *mask_ws,
                        int *keep_dev, int *num_keep_dev, m3d_stream_t stream);
