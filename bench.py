@@ -34,6 +34,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming copy)
 CROP = (384, 1280)
 PER_GPU_BATCH = 8
+MFMA_FAMILIES = ("igemm", "wino", "head_mlp", "conv_wave", "bf16_conv", "bf16_halo", "bf16_anab")
 
 
 def _cpu_model():
@@ -119,11 +120,16 @@ def pmc_traffic(kernel_label):
     sym = kernel_symbol(kernel_label)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), reverse=True):
         try:
-            ks = json.load(open(f))["kernels"]
+            doc = json.load(open(f))
         except Exception:
             continue
-        if sym in ks:
-            return ks[sym]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+        fam = doc.get("families") or {}
+        if kernel_label in fam:          # per-FAMILY average (tools/pmc_traffic.py aligned with --dump-launches)
+            return fam[kernel_label]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT) + "#families"
+        if fam:
+            continue                     # a file with family rows that lacks this label is from another dtype / plan
+        if sym in doc.get("kernels", {}):   # older passes: per-SYMBOL average (one symbol can serve several families)
+            return doc["kernels"][sym]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT) + "#symbol-average"
     return None, None
 
 
@@ -159,7 +165,7 @@ def algorithmic_bytes(op):
     return b
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 for f32 bs=8, 60 for bf16 bs=64: ~1.2 s timed)")
@@ -168,16 +174,21 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 = BASELINE.json configs[1] (the headline metric); bf16 = configs[2] (bs=64, bf16 storage / MFMA)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs2", action="store_true",
+                    help="skip the extra configs[2] (bs=64 bf16) measurement that the default N=1 f32 run appends as 'configs2_bf16'")
+    ap.add_argument("--configs2-steps", type=int, default=60)
     ap.add_argument("--dump-layers", default=None, help="write the per-launch table of one instrumented step here")
+    ap.add_argument("--dump-launches", default=None,
+                    help="write the ordered [family label, kernel base name] list of one step's MFMA launches (for tools/pmc_traffic.py)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap decode/top-k/NMS of batch k with the forward of batch k+1")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def main():
+    args = parse_args()
     from m3dssd_amd import dist as mdist
-    from m3dssd_amd import synth
-    from m3dssd_amd.host.detect import detect_device, select_block
-    from model.M3d_inference_align import build
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher -- one process per GPU under torch.distributed.run
@@ -194,22 +205,50 @@ def main():
         os.execv(sys.executable, cmd)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
-    rank, world, local = mdist.init_from_env()
+    backend = os.environ.get("M3D_DIST_BACKEND") or "nccl"
+    if args.gpus > 1 and backend == "nccl" and torch.cuda.device_count() < args.gpus:
+        raise SystemExit("--gpus %d with the nccl (RCCL) backend needs %d visible devices, found %d "
+                         "(M3D_DIST_BACKEND=gloo lets test ranks share a device)" % (args.gpus, args.gpus, torch.cuda.device_count()))
+    rank, world, local = mdist.init_from_env(backend)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    bf16 = args.dtype == "bf16"
-    if args.steps is None:
-        args.steps = 60 if bf16 else 200
-    B = args.batch if args.batch is not None else (64 if bf16 else PER_GPU_BATCH)
 
+    out, sd = run_config(args, args.dtype, args.steps, args.batch, rank, world, dev, mdist, dump_layers=args.dump_layers)
+    if rank == 0:
+        if world > 1:
+            out["dist_backend"] = mdist.backend_name()
+        if world == 1 and args.dtype == "f32" and args.batch is None and not args.no_configs2:
+            # BASELINE.json configs[2] (bs = 64, bf16 storage + MFMA) on the same clock as the headline line: same step
+            # definition, same timed-region bracket, its own roofline objects.
+            torch.cuda.empty_cache()
+            c2, _ = run_config(args, "bf16", args.configs2_steps, None, rank, world, dev, mdist)
+            out["configs2_bf16"] = {k: c2[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config",
+                                                        "launch", "roofline", "step_roofline", "gpu_ms_by_kernel_one_step",
+                                                        "mfma_kernel_families") if k in c2}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=None):
+    """Warm up, instrument, time `steps` steps of one (dtype, batch) configuration; returns (JSON dict or None off rank 0, state dict)."""
+    from m3dssd_amd import synth
+    from m3dssd_amd.host.detect import detect_device, select_block
+    from model.M3d_inference_align import build
+    bf16 = dtype == "bf16"
+    if steps is None:
+        steps = 60 if bf16 else 200
+    B = batch if batch is not None else (64 if bf16 else PER_GPU_BATCH)
     conf = synth.synth_conf(CROP, 0, batch_size=B, device=str(dev))
     sd = synth.synth_state_dict(0)
     net = build(conf, "test")
     net.load_state_dict(sd, strict=True)
-    net = net.to(dev).set_compute_dtype(args.dtype)
+    net = net.to(dev).set_compute_dtype(dtype)
     x = synth.synth_frames(B, CROP, 1234 + rank).to(dev)          # inputs resident in HBM before the timed region
     eng = net.engine()
 
@@ -226,11 +265,15 @@ def main():
     step()
     torch.cuda.synchronize()
     eng.flush_profile()
-    if args.dump_layers and rank == 0:
-        with open(args.dump_layers, "w") as f:
+    if dump_layers and rank == 0:
+        with open(dump_layers, "w") as f:
             f.write("name,kernel,gflop,ms,tflops\n")
             for name, kind, flops, ms in eng.profile:
                 f.write("%s,\"%s\",%.3f,%.4f,%.1f\n" % (name, kind, flops / 1e9, ms, flops / 1e9 / max(ms, 1e-6)))
+    if args.dump_launches and rank == 0:
+        seq = [[kind, kernel_symbol(kind).split("(", 1)[0].split("<", 1)[0].replace("void ", "").strip()]
+               for name, kind, flops, ms in eng.profile if kind.startswith(MFMA_FAMILIES)]
+        json.dump(seq, open(args.dump_launches, "w"))
     per_kind = {}
     for name, kind, flops, ms in eng.profile:
         a = per_kind.setdefault(kind, [0.0, 0.0, 0])
@@ -238,7 +281,7 @@ def main():
         a[1] += flops
         a[2] += 1
     # MFMA-bound kernel families (everything else is a small HBM/latency-bound helper)
-    igemm = {k: v for k, v in per_kind.items() if k.startswith(("igemm", "wino", "head_mlp", "conv_wave", "bf16_conv", "bf16_halo", "bf16_anab"))}
+    igemm = {k: v for k, v in per_kind.items() if k.startswith(MFMA_FAMILIES)}
     dominant = max(igemm, key=lambda k: igemm[k][0])
     gpu_ms_all = sum(v[0] for v in per_kind.values())
     breakdown = {k: round(v[0], 3) for k, v in sorted(per_kind.items(), key=lambda kv: -kv[1][0])}
@@ -302,7 +345,7 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         timed_step()
     if flush is not None:
         flush()
@@ -343,15 +386,15 @@ def main():
                        "traffic": tr, "traffic_source": src}
 
     if rank == 0:
-        value = world * B * args.steps / dt
+        value = world * B * steps / dt
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         wino_div = 2.25 if dominant.startswith("wino") else 1.0
         out = {
             "metric": ("images/sec at 1280x384 bs=8, 1/2/4/8 MI355X; 3D-box Linf vs ref" if not bf16 else
                        "images/sec at 1280x384 bs=64 bf16 (BASELINE.json configs[2]), 1/2/4/8 MI355X"),
-            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]: full M3d_inference_align (DLA-34 + DCNv2 align + ANAB) "
                                    "forward + decode + top-3000 + NMS, bs=%d/GPU, 1280x384, %s, random-init "
                                    "synthetic weights and frames" % (2 if bf16 else 1, B, "bf16 storage + bf16 MFMA, fp32 "
@@ -384,18 +427,15 @@ def main():
         }
         if bf16:
             # whole-step figures against both roofs (in bf16 the network is HBM-bound unless fused)
-            step_s = dt / args.steps
+            step_s = dt / steps
             out["step_roofline"] = {
                 "algorithmic_tflops": round(B * 105.8e9 / step_s / 1e12, 1), "mfma_frac": round(B * 105.8e9 / step_s / 1e12 / peak_tf, 4),
                 "algorithmic_gbs_bf16": round((B * (501.8e6 + 21e6 + 5.9e6) + 41.3e6) / step_s / 1e9, 1),
                 "hbm_frac": round((B * (501.8e6 + 21e6 + 5.9e6) + 41.3e6) / step_s / 1e9 / PEAK_HBM_GBS, 4),
                 "note": "SURVEY 8d algorithmic work per image: 105.8 GFLOP; 501.8 MB bf16 activations + 21 MB outputs + 5.9 MB input, "
                         "weights 41.3 MB (bf16) per batch"}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd)
-        print(json.dumps(out))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+        return out, sd
+    return None, sd
 
 
 if __name__ == "__main__":

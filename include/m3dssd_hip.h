@@ -258,10 +258,15 @@ int m3d_head_mlp_forward_batched(const m3d_mlp_desc *d, int n, m3d_stream_t stre
  * Drop-in for dcn_v2_cuda_forward: NCHW contiguous fp32 device tensors, exactly the reference
  * argument meaning.  `workspace` replaces the reference's `ones`/`columns` scratch tensors
  * (dcn_v2_func.py:28): the caller allocates m3d_dcn_v2_workspace_bytes() bytes.
- * deformable_group must be 1 (the only value on the M3DSSD path).
+ * deformable_group = G > 1 (model/DCNv2/test.py:169-179; the M3DSSD path itself uses 1): G must divide `channels`;
+ * offset is [N, G*2*kh*kw, Ho, Wo], mask [N, G*kh*kw, Ho, Wo] (dcn_v2_im2col_cuda.cu:139-156); the workspace then comes
+ * from m3d_dcn_v2_workspace_bytes_grouped (returns -1 for an invalid G).
  * ------------------------------------------------------------------------------------------ */
 long long m3d_dcn_v2_workspace_bytes(int batch, int channels, int height, int width, int channels_out,
                                      int kernel_h, int kernel_w, int stride, int pad, int dilation);
+long long m3d_dcn_v2_workspace_bytes_grouped(int batch, int channels, int height, int width, int channels_out,
+                                             int kernel_h, int kernel_w, int stride, int pad, int dilation,
+                                             int deformable_group);
 int m3d_dcn_v2_forward(const float *input, const float *weight, const float *bias, const float *offset,
                        const float *mask, float *output, int batch, int channels, int height, int width,
                        int channels_out, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h,

@@ -3,4 +3,4 @@ from m3dssd_amd.rpn_util import (anchor_center, generate_anchors_2d, calc_output
                                  flatten_tensor)
 from m3dssd_amd.host.detect import im_detect_3d, detect_batch  # noqa: F401
 from m3dssd_amd.host.nms import gpu_nms  # noqa: F401
-from m3dssd_amd.host.test_kitti import test_kitti_3d  # noqa: F401,E402
+from m3dssd_amd.host.kitti_test import test_kitti_3d  # noqa: F401,E402

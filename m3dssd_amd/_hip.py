@@ -109,6 +109,7 @@ SIGNATURES = {
     "m3d_conv2d_tile": (c_int, [ctypes.POINTER(ConvDesc)] + [ctypes.POINTER(c_int)] * 4),
     "m3d_conv2d_splitk_plan": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int), ctypes.POINTER(c_ll)]),
     "m3d_dcn_v2_workspace_bytes": (c_ll, [c_int] * 10),
+    "m3d_dcn_v2_workspace_bytes_grouped": (c_ll, [c_int] * 11),
     "m3d_dcn_v2_forward": (c_int, [P] * 6 + [c_int] * 14 + [P, c_ll, P]),
     "m3d_pack_conv_weight": (c_int, [P, P] + [c_int] * 6 + [P]),
     "m3d_nchw_to_nhwc": (c_int, [P, P] + [c_int] * 5 + [P]),

@@ -7,8 +7,9 @@
 
 // ---------------------------------------------------------------------------------------
 // [Cout, Cin, kh, kw] -> [Cout_pad, (i*kw + j)*Cin_pad + c]   (rows >= Cout and channels >= Cin are zero)
+// (the source may be a channel slice [c0, c0 + Cin) of a [Cout, Ctot, kh, kw] tensor: one deformable group)
 __global__ void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ p, int Cout, int Cout_pad,
-                                   int Cin, int Cin_pad, int KK)
+                                   int Cin, int Cin_pad, int KK, int Ctot, int c0)
 {
     const long long total = (long long)Cout_pad * KK * Cin_pad;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -16,31 +17,40 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, float *__restric
         const int c = (int)(i % Cin_pad);
         const int tap = (int)((i / Cin_pad) % KK);
         const int co = (int)(i / ((long long)Cin_pad * KK));
-        p[i] = (co < Cout && c < Cin) ? w[((long long)co * Cin + c) * KK + tap] : 0.f;
+        p[i] = (co < Cout && c < Cin) ? w[((long long)co * Ctot + c0 + c) * KK + tap] : 0.f;
     }
+}
+
+int m3d_pack_conv_weight_slice(const float *w, int Ctot, int c0, float *packed, int Cout, int Cout_pad, int Cin, int Cin_pad,
+                               int kh, int kw, m3d_stream_t stream)
+{
+    M3D_REQUIRE(w && packed && Cout > 0 && Cout_pad >= Cout && Cin_pad >= Cin && c0 >= 0 && c0 + Cin <= Ctot,
+                "pack_conv_weight: bad arguments");
+    const long long total = (long long)Cout_pad * kh * kw * Cin_pad;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(imin(cdiv(total, 256), 4096)), dim3(256), 0, (hipStream_t)stream, w,
+                       packed, Cout, Cout_pad, Cin, Cin_pad, kh * kw, Ctot, c0);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
 }
 
 extern "C" int m3d_pack_conv_weight(const float *w, float *packed, int Cout, int Cout_pad, int Cin, int Cin_pad,
                                     int kh, int kw, m3d_stream_t stream)
 {
-    M3D_REQUIRE(w && packed && Cout > 0 && Cout_pad >= Cout && Cin_pad >= Cin, "pack_conv_weight: bad arguments");
-    const long long total = (long long)Cout_pad * kh * kw * Cin_pad;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(imin(cdiv(total, 256), 4096)), dim3(256), 0, (hipStream_t)stream, w,
-                       packed, Cout, Cout_pad, Cin, Cin_pad, kh * kw);
-    M3D_LAUNCH_CHECK();
-    return M3D_OK;
+    return m3d_pack_conv_weight_slice(w, Cin, 0, packed, Cout, Cout_pad, Cin, Cin_pad, kh, kw, stream);
 }
 
 // ---------------------------------------------------------------------------------------
 // NCHW <-> NHWC through a 32x32 LDS tile (coalesced on both sides).
-__global__ void nchw_to_nhwc_kernel(const float *__restrict__ in, float *__restrict__ out, int C, int HW, int out_cs)
+// (the source may be a channel slice [c0, c0 + C) of an image with Ctot channels)
+__global__ void nchw_to_nhwc_kernel(const float *__restrict__ in, float *__restrict__ out, int C, int HW, int out_cs, int Ctot,
+                                    int c0s)
 {
     __shared__ float t[32][33];
     const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
     for (int r = ty; r < 32; r += 8) {
         const int c = c0 + r, p = p0 + tx;
-        t[r][tx] = (c < C && p < HW) ? in[((size_t)n * C + c) * HW + p] : 0.f;
+        t[r][tx] = (c < C && p < HW) ? in[((size_t)n * Ctot + c0s + c) * HW + p] : 0.f;
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
@@ -65,15 +75,21 @@ __global__ void nhwc_to_nchw_kernel(const float *__restrict__ in, int in_cs, flo
     }
 }
 
+int m3d_nchw_to_nhwc_slice(const float *in, int Ctot, int c0, float *out, int N, int C, int H, int W, int out_cs,
+                           m3d_stream_t stream)
+{
+    M3D_REQUIRE(in && out && out_cs >= C && c0 >= 0 && c0 + C <= Ctot, "nchw_to_nhwc: bad arguments");
+    const int HW = H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), N), dim3(256), 0, (hipStream_t)stream, in,
+                       out, C, HW, out_cs, Ctot, c0);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
 extern "C" int m3d_nchw_to_nhwc(const float *in, float *out, int N, int C, int H, int W, int out_cs,
                                 m3d_stream_t stream)
 {
-    M3D_REQUIRE(in && out && out_cs >= C, "nchw_to_nhwc: bad arguments");
-    const int HW = H * W;
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), N), dim3(256), 0, (hipStream_t)stream, in,
-                       out, C, HW, out_cs);
-    M3D_LAUNCH_CHECK();
-    return M3D_OK;
+    return m3d_nchw_to_nhwc_slice(in, C, 0, out, N, C, H, W, out_cs, stream);
 }
 
 extern "C" int m3d_nhwc_to_nchw(const float *in, int in_cs, float *out, int N, int C, int H, int W,

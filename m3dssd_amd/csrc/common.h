@@ -39,7 +39,10 @@ __device__ __forceinline__ void dcn_corners(float h_im, float w_im, int H, int W
 {
     const float tin = fminf(fminf(h_im, w_im) + 1.f, -fmaxf(h_im - (float)H, w_im - (float)W));     // > 0: inside
     const unsigned xin = __float_as_uint(tin);
-    const int out = sign_smear((int)((xin - 1u) | xin)) | drop_all;                                   // tin <= 0 (or -0.0)
+    // fminf / fmaxf return the other operand for a NaN: a NaN coordinate must fail the test like the reference's compares do
+    // (`h_im > -1 && ...` is false for NaN, dcn_v2_im2col_cuda.cu:165).  x - x is +0 for finite x and NaN for NaN / inf.
+    const unsigned nonfinite = __float_as_uint((h_im - h_im) + (w_im - w_im)) & 0x7fffffffu;
+    const int out = sign_smear((int)((xin - 1u) | xin)) | sign_smear(-(int)nonfinite) | drop_all;      // tin <= 0 (or -0.0)
     // far outside the image the float -> int conversions saturate: the index arithmetic below is unsigned (wrap-around, no
     // signed overflow for the optimiser to reason about); its results are masked by `out` there
     const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
@@ -109,6 +112,10 @@ __device__ __forceinline__ f32x4 pk_add(f32x4 a, f32x4 b)
 #define M3D_LEAKY_SLOPE 0.01f
 
 void m3d_set_error(const char *fmt, ...);
+// channel-slice forms of m3d_nchw_to_nhwc / m3d_pack_conv_weight (internal: the deformable groups of m3d_dcn_v2_forward)
+int m3d_nchw_to_nhwc_slice(const float *in, int Ctot, int c0, float *out, int N, int C, int H, int W, int out_cs, m3d_stream_t stream);
+int m3d_pack_conv_weight_slice(const float *w, int Ctot, int c0, float *packed, int Cout, int Cout_pad, int Cin, int Cin_pad, int kh,
+                               int kw, m3d_stream_t stream);
 
 #define M3D_REQUIRE(cond, ...)        \
     do {                              \

@@ -18,7 +18,12 @@ ROW = 14  # x1,y1,x2,y2,score,cls,x3d,y3d,z3d,w3d,h3d,l3d,ry3d,anchor  (lib/rpn_
 
 
 def init_from_env(backend=None):
-    """Initialise torch.distributed from torchrun's environment; returns (rank, world, local_rank)."""
+    """Initialise torch.distributed from torchrun's environment; returns (rank, world, local_rank).
+
+    Backend: the argument, else $M3D_DIST_BACKEND, else "nccl" (= RCCL over xGMI) when a GPU is visible, "gloo" otherwise.
+    With nccl every rank needs its own device: LOCAL_RANK >= device_count is a launch error and is reported as one (RCCL
+    rejects or hangs on duplicate devices in one communicator); gloo (CPU tests, or two ranks sharing the one GPU of a test
+    lease) maps ranks onto the visible devices round-robin."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -26,11 +31,23 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("M3D_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend not in ("nccl", "gloo"):
+            raise ValueError("M3D_DIST_BACKEND must be 'nccl' or 'gloo' (got %r)" % (backend,))
         if backend == "nccl":
+            n_dev = torch.cuda.device_count()
+            if local >= n_dev:
+                raise RuntimeError("LOCAL_RANK %d but only %d visible GPU(s): the nccl (RCCL) backend needs one device per "
+                                   "rank (set M3D_DIST_BACKEND=gloo to share a device in tests)" % (local, n_dev))
+            torch.cuda.set_device(local)
+        elif torch.cuda.is_available():
             torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def backend_name():
+    return dist.get_backend() if dist.is_initialized() else None
 
 
 def shard_range(n_images, rank, world):

@@ -35,6 +35,8 @@ def dcn_v2_forward(inp, offset, mask, weight, bias, stride, padding, dilation=1,
     co, ck, kh, kw = weight.shape
     if ck != c:
         raise RuntimeError("Input shape and kernel channels wont match: (%d vs %d)." % (c, ck))   # dcn_v2_cuda.c:37-39
+    if deformable_groups < 1 or c % deformable_groups:
+        raise RuntimeError("dcn_v2_forward: deformable_groups (%d) must divide the input channels (%d)" % (deformable_groups, c))
     ho = (h + 2 * padding - (dilation * (kh - 1) + 1)) // stride + 1
     wo = (w + 2 * padding - (dilation * (kw - 1) + 1)) // stride + 1
     if tuple(offset.shape) != (n, deformable_groups * 2 * kh * kw, ho, wo) or \
@@ -42,7 +44,7 @@ def dcn_v2_forward(inp, offset, mask, weight, bias, stride, padding, dilation=1,
         raise RuntimeError("dcn_v2_forward: offset/mask shape does not match the output size")
     offset, mask, bias = offset.contiguous().float(), mask.contiguous().float(), bias.contiguous().float()
     out = torch.empty(n, co, ho, wo, device=inp.device, dtype=torch.float32)
-    nbytes = L.m3d_dcn_v2_workspace_bytes(n, c, h, w, co, kh, kw, stride, padding, dilation)
+    nbytes = L.m3d_dcn_v2_workspace_bytes_grouped(n, c, h, w, co, kh, kw, stride, padding, dilation, deformable_groups)
     ws = torch.empty(nbytes + 256, device=inp.device, dtype=torch.uint8)
     base = (ws.data_ptr() + 255) // 256 * 256
     with torch.cuda.device(inp.device):

@@ -3,6 +3,8 @@
 ``RPN.forward(x)`` returns exactly what the reference does in eval mode --
 ``(cls [B,N,4], prob [B,N,4], bbox_2d [B,N,4], bbox_3d [B,N,7], feat_size [2], rois [N,5])`` --
 computed by the HIP engine.  Training (phase='train') is out of scope for this path."""
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -21,6 +23,10 @@ def _head(cin, mid, cout, k0):
     return nn.Sequential(nn.Conv2d(cin, mid, k0, padding=k0 // 2), nn.BatchNorm2d(mid), nn.LeakyReLU(inplace=True),
                          nn.Conv2d(mid, mid, 1), nn.BatchNorm2d(mid), nn.LeakyReLU(inplace=True),
                          nn.Conv2d(mid, cout, 1))
+
+
+def _invalidate_after_load(module, incompatible_keys):
+    module.refresh_engine()
 
 
 class RPN(nn.Module):
@@ -65,23 +71,57 @@ class RPN(nn.Module):
         self.softmax = nn.Softmax(dim=1)
         self._conf = conf
         self._engine = None
+        self._param_sig = None
+        # a parent's load_state_dict reaches sub-modules through _load_from_state_dict only: invalidate from there
+        self.register_load_state_dict_post_hook(_invalidate_after_load)
         self.compute_dtype = str(conf.compute_dtype) if "compute_dtype" in conf else "f32"
 
     # -- engine management: parameters are folded / packed once and re-packed when they change --------------------------------
-    # Everything that replaces or moves parameters through the nn.Module API (load_state_dict, .to / .cuda / .float via _apply)
-    # marks the packed engine stale; code that writes parameter storage IN PLACE (p.data.copy_, optimiser steps) must call
-    # refresh_engine() itself -- hashing ~540 (data_ptr, _version) pairs on every forward cost 0.3 ms of host time per call.
+    # Everything that replaces or moves parameters through the nn.Module API marks the packed engine stale:
+    #   * load_state_dict on this module OR on any parent / wrapper (nn.DataParallel, DDP, a container): the parent recurses
+    #     through child._load_from_state_dict and never calls the child's load_state_dict, so the invalidation hangs on
+    #     _load_from_state_dict of every sub-module via a load_state_dict post-hook registered in __init__;
+    #   * .to / .cuda / .float (through _apply).
+    # Code that writes parameter storage IN PLACE (p.data.copy_, optimiser steps) calls refresh_engine() itself -- hashing
+    # ~540 (data_ptr, _version) pairs on every forward cost 0.3 ms of host time per call; M3D_CHECK_PARAMS=1 turns that full
+    # check on for debugging (forward then raises on a stale packing instead of using it).
     def refresh_engine(self):
         self._engine = None
+        self._param_sig = None
         return self
 
     def _apply(self, fn, *args, **kwargs):
-        self._engine = None
+        self.refresh_engine()
         return super()._apply(fn, *args, **kwargs)
 
-    def load_state_dict(self, *args, **kwargs):
-        self._engine = None
-        return super().load_state_dict(*args, **kwargs)
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        """Accepts the checkpoints the reference writes: they are saved from the nn.DataParallel wrapper
+        (scripts/test_rpn_3d.py:50-54) and carry a leading 'module.' on every key, which the reference strips in
+        lib/core.py:489-499 (load_weights(remove_module=True)); the same stripping happens here when EVERY key has it."""
+        self.refresh_engine()
+        keys = list(state_dict.keys())
+        if keys and all(k.startswith("module.") for k in keys):
+            meta = getattr(state_dict, "_metadata", None)
+            state_dict = type(state_dict)((k[len("module."):], v) for k, v in state_dict.items())
+            if meta is not None:                       # per-module versions: 'module' -> '', 'module.base' -> 'base'
+                state_dict._metadata = type(meta)(("" if k == "module" else k[len("module."):], v)
+                                                  for k, v in meta.items() if k == "module" or k.startswith("module."))
+        return super().load_state_dict(state_dict, *args, **kwargs)
+
+    def _replicate_for_data_parallel(self):
+        """nn.DataParallel (the reference's scripts/test_rpn_3d.py:50-51) replicates the module per device: a replica must not
+        share the packed engine (its plans live on the source device).  Each replica packs its own on first use; with ONE
+        visible device DataParallel calls the module itself and nothing is replicated.  For throughput use one process per
+        GPU (m3dssd_amd.dist) instead -- replicas are rebuilt by DataParallel on EVERY forward."""
+        replica = super()._replicate_for_data_parallel()
+        replica._engine = None
+        replica._param_sig = None
+        replica._is_replica = True
+        return replica
+
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + \
+            tuple((b.data_ptr(), b._version) for b in self.buffers())
 
     def set_compute_dtype(self, dtype):
         """'f32' (default: the reference's arithmetic) or 'bf16' (bf16 storage / MFMA, fp32 accumulation; see engine_bf16.py)."""
@@ -91,6 +131,8 @@ class RPN(nn.Module):
         return self
 
     def engine(self):
+        if self._engine is not None and os.environ.get("M3D_CHECK_PARAMS", "0") == "1" and self._param_sig != self._signature():
+            raise RuntimeError("RPN: parameters changed in place since the engine packed them; call net.refresh_engine()")
         if self._engine is None:
             dev = next(self.parameters()).device
             if dev.type != "cuda":
@@ -103,6 +145,7 @@ class RPN(nn.Module):
                 self._engine = Engine(self.state_dict(), self._conf, device=dev)
             else:
                 raise ValueError("compute_dtype must be 'f32' or 'bf16' (got %r)" % (self.compute_dtype,))
+            self._param_sig = self._signature() if os.environ.get("M3D_CHECK_PARAMS", "0") == "1" else None
         return self._engine
 
     def forward(self, x):

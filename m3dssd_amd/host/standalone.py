@@ -104,8 +104,20 @@ def dcn_layer_forward(dcn, x):
     _require_cuda(x)
     with torch.no_grad(), torch.cuda.device(x.device):
         v, _ = _to_nhwc(x, 32)
-        out, keep = dcn_layer_nhwc(dcn, v)
-        return _to_nchw(out, dcn.out_channels)
+        if dcn.deformable_groups == 1 and dcn.dilation == 1:       # the M3DSSD layers: everything stays NHWC
+            out, keep = dcn_layer_nhwc(dcn, v)
+            return _to_nchw(out, dcn.out_channels)
+        # general module contract (model/DCNv2/test.py:169-179: deformable_groups = 2): offset / mask conv on the fused conv
+        # kernel, then the drop-in op with the group count.  chunk(out, 3) + cat(o1, o2) of dcn_v2.py:66-67 = the first
+        # 2*G*kk channels are the offsets, the last G*kk the (sigmoid) mask.
+        kk, g = dcn.kernel_size[0] * dcn.kernel_size[1], dcn.deformable_groups
+        om, keep = conv_nhwc(v, dcn.conv_offset_mask.weight, dcn.conv_offset_mask.bias, None, dcn.stride, dcn.padding,
+                             sigmoid_from=2 * kk * g)
+        om = _to_nchw(om, 3 * kk * g)
+        from . import ops
+        return ops.dcn_v2_forward(x.float().contiguous(), om[:, :2 * kk * g].contiguous(), om[:, 2 * kk * g:].contiguous(),
+                                  dcn.weight.detach().float().contiguous(), dcn.bias.detach().float(), dcn.stride,
+                                  dcn.padding, dcn.dilation, g)
 
 
 def deform_conv_forward(mod, x):

@@ -1,0 +1,238 @@
+"""GPU tests added in round 3 (all through the C ABI of libm3dssd_hip.so):
+
+  * the host boundary on a device: 'module.'-prefixed checkpoints, loads through wrappers / containers re-pack the engine,
+    nn.DataParallel(net)(x) on the leased device == net(x) (scripts/test_rpn_3d.py:50-54);
+  * bench.py's N > 1 branch executed end to end with two ranks (M3D_DIST_BACKEND=gloo: the lease has ONE device, RCCL refuses
+    duplicate devices) -- the code path the driver runs on the 8-GPU node;
+  * the DCN / DCNv2 module contract with deformable_groups > 1 (model/DCNv2/test.py:169-179) against the oracle;
+  * non-finite sampling positions behave like the reference's compares (a NaN coordinate fails `h_im > -1 && ...`).
+"""
+import collections
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+from torch import nn
+
+from m3dssd_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CROP = (128, 320)
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _relerr(a, b):
+    return ((a - b).abs() / (1 + b.abs())).max().item()
+
+
+def _net(seed=0, bs=2):
+    from model.M3d_inference_align import build
+    conf = synth.synth_conf(CROP, 0, batch_size=bs, device="cuda:0")
+    net = build(conf, "test")
+    return net, conf, synth.synth_state_dict(seed)
+
+
+# ------------------------------------------------------------------------------------ host boundary
+def test_module_prefixed_checkpoint_then_forward_equals_plain_load():
+    dev = _dev()
+    x = synth.synth_frames(2, CROP, 5).to(dev)
+    net, conf, sd = _net()
+    net.load_state_dict(sd)
+    ref = [t.clone() for t in net.to(dev)(x)[:4]]
+    net2, _, _ = _net()
+    net2.load_state_dict(collections.OrderedDict(("module." + k, v) for k, v in sd.items()), strict=True)
+    got = net2.to(dev)(x)[:4]
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+
+
+def test_load_through_wrapper_repacks_the_engine():
+    """forward -> wrapper.load_state_dict(other checkpoint) -> forward must run the NEW weights (nn.Module.load_state_dict on a
+    parent recurses through child._load_from_state_dict and never calls RPN.load_state_dict)."""
+    dev = _dev()
+    x = synth.synth_frames(2, CROP, 6).to(dev)
+    net, conf, sd0 = _net(0)
+    sd1 = synth.synth_state_dict(1)
+    net.load_state_dict(sd0)
+    net = net.to(dev)
+    out0 = [t.clone() for t in net(x)[:4]]
+    wrapper = nn.DataParallel(net, device_ids=[0])
+    wrapper.load_state_dict(collections.OrderedDict(("module." + k, v) for k, v in sd1.items()))
+    out1 = [t.clone() for t in net(x)[:4]]
+    assert not torch.equal(out0[3], out1[3]), "the packed engine still holds the previous checkpoint"
+    fresh, _, _ = _net(1)
+    fresh.load_state_dict(sd1)
+    ref1 = fresh.to(dev)(x)[:4]
+    for a, b in zip(out1, ref1):
+        assert torch.equal(a, b)
+    holder = nn.ModuleDict({"det": net})
+    holder.load_state_dict(collections.OrderedDict(("det." + k, v) for k, v in sd0.items()))
+    for a, b in zip(net(x)[:4], out0):
+        assert torch.equal(a, b)
+
+
+def test_data_parallel_wrapper_on_the_leased_device_equals_the_module():
+    """The reference script wraps the net in nn.DataParallel (scripts/test_rpn_3d.py:50-51).  With one visible device the
+    wrapper calls the module itself; a replica made for a second device would pack its own engine (the replica hook is
+    exercised directly: it must not share the source's plans)."""
+    dev = _dev()
+    x = synth.synth_frames(2, CROP, 7).to(dev)
+    net, conf, sd = _net()
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    ref = [t.clone() for t in net(x)]
+    got = nn.DataParallel(net, device_ids=[0])(x)
+    assert len(got) == 6
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    rep = net._replicate_for_data_parallel()
+    assert rep._engine is None and net._engine is not None
+    # the replica shares the parameters (DataParallel would have broadcast them): it packs its OWN engine and agrees
+    rep._parameters, rep._buffers, rep._modules = net._parameters, net._buffers, net._modules
+    for a, b in zip(rep(x)[:4], ref[:4]):
+        assert torch.equal(a, b)
+    assert rep._engine is not net._engine
+
+
+# ------------------------------------------------------------------------------------ bench.py, N > 1 branch
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_bench(extra, env_extra, timeout=600):
+    import signal
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", **env_extra)
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, start_new_session=True, cwd=ROOT)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        out, err = p.communicate()
+        raise AssertionError("bench.py timed out\n" + (err or "")[-3000:])
+    return p.returncode, out, err
+
+
+def test_bench_two_ranks_gloo_emits_one_parseable_line():
+    """`python bench.py --gpus 2` self-launches under torch.distributed.run; both ranks share the leased device (gloo), run the
+    pipelined graph, the per-step gather_block, the barriers and the all_reduce(MAX) of the elapsed time; rank 0 prints ONE
+    JSON line for the whole job."""
+    rc, out, err = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                              {"M3D_DIST_BACKEND": "gloo"})
+    assert rc == 0, err[-3000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 16 and r["config"]["per_gpu_batch"] == 8
+    assert r["steps"] == 3 and r["scaling"] == "weak" and r["dist_backend"] == "gloo"
+    assert r["value"] > 0 and abs(r["value"] - 16 * 3 / (r["ms_per_step"] * 3e-3)) / r["value"] < 0.01
+    assert "configs2_bf16" not in r and "cpu_baseline" not in r          # N = 1 only
+    assert r["roofline"]["frac"] > 0
+
+
+def test_bench_nccl_refuses_more_ranks_than_devices():
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a single-device lease")
+    rc, out, err = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], {"M3D_DIST_BACKEND": "nccl"},
+                              timeout=300)
+    assert rc != 0 and "visible devices" in (out + err)
+
+
+def test_bench_default_line_carries_configs2_bf16():
+    """The driver's command (`python bench.py`, N = 1): the f32 headline line also holds the bs = 64 bf16 measurement."""
+    rc, out, err = _run_bench(["--steps", "5", "--warmup", "2", "--configs2-steps", "3", "--no-cpu-baseline"], {})
+    assert rc == 0, err[-3000:]
+    r = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    assert r["dtype"] == "f32" and r["config"]["per_gpu_batch"] == 8
+    c2 = r["configs2_bf16"]
+    assert c2["dtype"] == "bf16" and c2["config"]["per_gpu_batch"] == 64 and c2["steps"] == 3
+    assert c2["value"] > r["value"] and c2["roofline"]["peak"] == 2500.0 and "step_roofline" in c2
+
+
+# ------------------------------------------------------------------------------------ DCN module contract
+@pytest.mark.parametrize("shape", [(2, 64, 32, 40, 64, 3, 1, 1, 2), (1, 48, 9, 11, 20, 3, 2, 1, 4), (2, 64, 16, 16, 32, 1, 1, 0, 2)])
+def test_dcn_v2_deformable_groups_match_oracle(shape):
+    """deformable_groups > 1 through the drop-in op: group g's channels sample at group g's offsets / masks
+    (dcn_v2_im2col_cuda.cu:139-156)."""
+    from m3dssd_amd.host import ops
+    from oracle import dcn as odcn
+    dev = _dev()
+    n, c, h, w, co, k, stride, pad, G = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(co, c, k, k, generator=g) / (c * k * k) ** 0.5
+    b = torch.randn(co, generator=g)
+    ho, wo = odcn.out_size(h, w, k, k, stride, pad, 1)
+    off = torch.randn(n, G * 2 * k * k, ho, wo, generator=g) * 2.0
+    m = torch.rand(n, G * k * k, ho, wo, generator=g)
+    ref = odcn.dcn_v2_forward(x, off, m, wt, b, stride, pad, 1, G)
+    got = ops.dcn_v2_forward(x.to(dev), off.to(dev), m.to(dev), wt.to(dev), b.to(dev), stride, pad, 1, G).cpu()
+    assert got.shape == ref.shape and _relerr(got, ref) < 2e-4
+    # the groups really differ: feeding group 0's offsets to every group changes the result
+    off0 = off[:, :2 * k * k].repeat(1, G, 1, 1)
+    assert _relerr(odcn.dcn_v2_forward(x, off0, m, wt, b, stride, pad, 1, G), ref) > 1e-2
+    with pytest.raises(RuntimeError):
+        ops.dcn_v2_forward(x.to(dev), off.to(dev), m.to(dev), wt.to(dev), b.to(dev), stride, pad, 1, 5)
+
+
+def test_dcn_module_example_of_the_reference_with_two_groups():
+    """model/DCNv2/test.py:169-179 `example_dconv`: DCN(64, 64, (3, 3), 1, 1, deformable_groups=2) on 2 x 64 x 128 x 128."""
+    from model.DCNv2.dcn_v2 import DCN
+    from oracle import dcn as odcn
+    dev = _dev()
+    torch.manual_seed(3)
+    dcn = DCN(64, 64, kernel_size=(3, 3), stride=1, padding=1, deformable_groups=2)
+    assert tuple(dcn.conv_offset_mask.weight.shape) == (54, 64, 3, 3)
+    with torch.no_grad():
+        dcn.conv_offset_mask.weight.normal_(0, 0.02)
+        dcn.conv_offset_mask.bias.normal_(0, 0.5)
+        dcn.bias.normal_(0, 0.1)
+    x = torch.randn(2, 64, 128, 128)
+    with torch.no_grad():
+        out = torch.nn.functional.conv2d(x, dcn.conv_offset_mask.weight, dcn.conv_offset_mask.bias, padding=1)
+        o1, o2, mask = torch.chunk(out, 3, dim=1)                              # dcn_v2.py:65-68
+        ref = odcn.dcn_v2_forward(x, torch.cat((o1, o2), 1), torch.sigmoid(mask), dcn.weight, dcn.bias, 1, 1, 1, 2)
+        got = dcn.to(dev)(x.to(dev)).cpu()
+    assert tuple(got.shape) == (2, 64, 128, 128)
+    assert _relerr(got, ref) < 5e-4
+
+
+def test_dcn_non_finite_sampling_positions_contribute_nothing():
+    """`h_im > -1 && w_im > -1 && h_im < H && w_im < W` (dcn_v2_im2col_cuda.cu:165) is false for a NaN coordinate: the tap is
+    skipped.  csrc/common.h dcn_corners decides with fminf / fmaxf (which drop NaNs) and therefore carries an explicit
+    non-finite term; +-inf positions are outside by the ordinary test."""
+    from m3dssd_amd.host import ops
+    from oracle import dcn as odcn
+    dev = _dev()
+    g = torch.Generator().manual_seed(77)
+    n, c, h, w, co, k = 1, 32, 8, 16, 32, 3
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(co, c, k, k, generator=g) / 17.0
+    b = torch.randn(co, generator=g)
+    off = torch.randn(n, 2 * k * k, h, w, generator=g)
+    m = torch.rand(n, k * k, h, w, generator=g)
+    nan, inf = float("nan"), float("inf")
+    off[0, 0, 2, 3] = nan          # tap 0: dh NaN, dw finite
+    off[0, 3, 2, 4] = nan          # tap 1: dw NaN, dh finite
+    off[0, 8, 5, 5] = nan
+    off[0, 9, 5, 5] = nan          # tap 4: both
+    off[0, 10, 6, 6] = inf
+    off[0, 13, 6, 7] = -inf
+    ref = odcn.dcn_v2_forward(x, off, m, wt, b, 1, 1, 1, 1)
+    assert torch.isfinite(ref).all()
+    got = ops.dcn_v2_forward(x.to(dev), off.to(dev), m.to(dev), wt.to(dev), b.to(dev), 1, 1, 1, 1).cpu()
+    assert torch.isfinite(got).all()
+    assert _relerr(got, ref) < 2e-4

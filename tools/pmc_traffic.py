@@ -4,7 +4,12 @@
 Follows /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
 reports exactly half of the bytes of a wide (16 B/lane) coalesced streaming read -> doubled here (the igemm and
 MLP loaders are 16 B/lane); WRITE_SIZE is taken as is (uncalibrated per the guide -- ratios are reliable).
-usage: python tools/pmc_traffic.py gpurun_out/pmc3 profiles/r01_hbm_traffic.json
+usage: python tools/pmc_traffic.py gpurun_out/pmc3 profiles/r01_hbm_traffic.json [launches.json]
+
+launches.json (``bench.py --dump-launches``: the ordered [family label, kernel base name] list of the MFMA launches of ONE
+step) turns the per-SYMBOL averages into per-FAMILY ones: one kernel symbol serves several engine families (e.g.
+conv_wave_kernel<true,4> = the full-size deformable layers AND their split-K variants on small maps), so the rows of the
+counter CSV (dispatch order) are aligned with the repeating per-step launch sequence and averaged per family label.
 """
 import collections
 import csv
@@ -22,9 +27,43 @@ def per_kernel(path, counter):
     return {k: tot[k] / n[k] for k in tot}, n
 
 
-def main(d, out):
+def base_name(kernel_name):
+    n = kernel_name.split("(", 1)[0].split("<", 1)[0].strip()
+    return n[5:] if n.startswith("void ") else n
+
+
+def per_family(path, counter, launches):
+    """Align the CSV's MFMA-kernel rows (dispatch order) with the repeating per-step sequence `launches`."""
+    bases = set(b for _, b in launches)
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter and base_name(r["Kernel_Name"]) in bases]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    n = len(launches)
+    if not rows or len(rows) % n:
+        raise SystemExit("%s: %d MFMA-kernel rows are not a multiple of the %d launches of a step" % (path, len(rows), n))
+    tot, cnt, grids = collections.defaultdict(float), collections.defaultdict(int), collections.defaultdict(set)
+    for i, r in enumerate(rows):
+        label, b = launches[i % n]
+        if base_name(r["Kernel_Name"]) != b:
+            raise SystemExit("%s: dispatch %s is %s, the step sequence expects %s (%s) at position %d"
+                             % (path, r["Dispatch_Id"], base_name(r["Kernel_Name"]), b, label, i % n))
+        tot[label] += float(r["Counter_Value"])
+        cnt[label] += 1
+        grids[label].add((r["Kernel_Name"], int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)))
+    return {k: tot[k] / cnt[k] for k in tot}, cnt, grids
+
+
+def main(d, out, launches=None):
     f, nf = per_kernel(os.path.join(d, "FETCH_SIZE_counter_collection.csv"), "FETCH_SIZE")
     w, nw = per_kernel(os.path.join(d, "WRITE_SIZE_counter_collection.csv"), "WRITE_SIZE")
+    fam = {}
+    if launches:
+        seq = [tuple(x) for x in json.load(open(launches))]
+        ff, nff, grids = per_family(os.path.join(d, "FETCH_SIZE_counter_collection.csv"), "FETCH_SIZE", seq)
+        wf, _, _ = per_family(os.path.join(d, "WRITE_SIZE_counter_collection.csv"), "WRITE_SIZE", seq)
+        for k in ff:
+            fam[k] = {"launches": nff[k], "fetch_kib_raw": round(ff[k], 1), "write_kib": round(wf[k], 1),
+                      "hbm_bytes_per_launch": int((2.0 * ff[k] + wf[k]) * 1024),
+                      "kernels_and_workgroups": sorted("%s x %d" % g for g in grids[k])}
     res = {}
     for k in f:
         if k in w:
@@ -32,11 +71,15 @@ def main(d, out):
                       "hbm_bytes_per_launch": int((2.0 * f[k] + w[k]) * 1024)}
     json.dump({"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs of "
                          "`bench.py --steps 3 --warmup 2 --no-graph`; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB "
-                         "(gfx950 wide-read correction of MI355X_MICROARCH.md)", "kernels": res},
+                         "(gfx950 wide-read correction of MI355X_MICROARCH.md); `families` = the same rows averaged per "
+                         "engine family label (aligned with bench.py --dump-launches by dispatch order)",
+               "families": fam, "kernels": res},
               open(out, "w"), indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:8]:
         print("%-70s n=%4d  %8.1f MB/launch" % (k[:70], v["launches"], v["hbm_bytes_per_launch"] / 1e6))
+    for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]):
+        print("family %-62s n=%4d  %8.1f MB/launch" % (k[:62], v["launches"], v["hbm_bytes_per_launch"] / 1e6))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
