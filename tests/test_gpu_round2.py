@@ -395,7 +395,8 @@ def test_two_ranks_detect_and_gather_equal_single_process(tmp_path, backend):
     may refuse as a duplicate device -- then the RCCL leg is reported as skipped and the gloo leg still covers the path)."""
     res = _run_ranks(tmp_path, backend)
     if res.returncode != 0 and backend == "nccl" and (res.timed_out or "uplicate GPU" in res.stdout
-                                                      or "invalid usage" in res.stdout or "ncclInvalidUsage" in res.stdout):
+                                                      or "invalid usage" in res.stdout or "ncclInvalidUsage" in res.stdout
+                                                      or "needs one device per" in res.stdout):   # m3dssd_amd.dist's own check
         _log("two_ranks_nccl", dict(status="refused by RCCL: two ranks on one device", tail=res.stdout[-600:]))
         pytest.skip("RCCL refuses two ranks on the same device (single leased GPU)")
     assert res.returncode == 0, res.stdout[-3000:]
