@@ -34,7 +34,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming copy)
 CROP = (384, 1280)
 PER_GPU_BATCH = 8
-MFMA_FAMILIES = ("igemm", "wino", "head_mlp", "conv_wave", "bf16_conv", "bf16_halo", "bf16_anab")
+MFMA_FAMILIES = ("igemm", "wino", "head_mlp", "conv_wave", "bf16_conv", "bf16_halo", "bf16_anab", "bf16_dcn_patch")
 
 
 def _cpu_model():
@@ -88,6 +88,9 @@ def kernel_symbol(label):
     import re
     if label.startswith("bf16_anab"):
         return "bf16_anab_attend_kernel(AnabArgs)"
+    if label.startswith("bf16_dcn_patch"):
+        th = re.findall(r"\d+", label.split("<", 1)[1])[0]
+        return "void bf16_dcn_patch_kernel<%s, %s>(Bf16Args, void const*, unsigned int const*)" % (th, "10" if th == "16" else "6")
     if label.startswith("bf16_halo"):
         bn, tw = re.findall(r"\d+", label.split("<", 1)[1])[:2]
         return "void bf16_conv3x3_halo_kernel<%s, %s, %d, %d, %d>(Bf16Args)" % (bn, tw, 8 * int(tw), 4 if tw == "16" else 8,
@@ -271,8 +274,12 @@ def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=N
             for name, kind, flops, ms in eng.profile:
                 f.write("%s,\"%s\",%.3f,%.4f,%.1f\n" % (name, kind, flops / 1e9, ms, flops / 1e9 / max(ms, 1e-6)))
     if args.dump_launches and rank == 0:
-        seq = [[kind, kernel_symbol(kind).split("(", 1)[0].split("<", 1)[0].replace("void ", "").strip()]
-               for name, kind, flops, ms in eng.profile if kind.startswith(MFMA_FAMILIES)]
+        seq = []
+        for name, kind, flops, ms in eng.profile:
+            if kind.startswith(MFMA_FAMILIES):
+                seq.append([kind, kernel_symbol(kind).split("(", 1)[0].split("<", 1)[0].replace("void ", "").strip()])
+                if kind.startswith("bf16_dcn_patch"):        # the gated implicit-GEMM fallback is launched right behind it
+                    seq.append([kind + "/fallback", "bf16_conv_kernel"])
         json.dump(seq, open(args.dump_launches, "w"))
     per_kind = {}
     for name, kind, flops, ms in eng.profile:

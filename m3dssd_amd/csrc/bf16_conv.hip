@@ -53,6 +53,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (wave / WN) * (TM * 32), wn = (wave % WN) * (TN * 32);
+    if constexpr (DEFORM) {
+        // fallback role (bf16_dcn_patch.hip): the LDS-patch kernel has done this launch's work when the sampling window fits
+        if (a.gate) {
+            if (dcn_bound_radius(a.gate, reinterpret_cast<unsigned *>(lds), tid, 256) <= a.gate_rmax) return;
+            __syncthreads();
+        }
+    }
     BTRACE_INIT();
     BTRACE();
     BTRACE_REAL(0);
@@ -606,7 +613,15 @@ static int conv_bf16_variant(const m3d_conv_bf16_desc *d, long long *tiles)
     if (tiles) *tiles = big ? t32 : t16;
     return big ? 2 : 1;
 }
-extern "C" int m3d_conv_bf16_variant(const m3d_conv_bf16_desc *d) { return d ? conv_bf16_variant(d, nullptr) : -1; }
+extern "C" int m3d_conv_bf16_variant(const m3d_conv_bf16_desc *d)
+{
+    if (!d) return -1;
+    if (d->dcn_offmask) {
+        const int pv = dcn_patch_variant(d);
+        return pv == 16 ? 4 : (pv == 8 ? 3 : 0);
+    }
+    return conv_bf16_variant(d, nullptr);
+}
 
 extern "C" int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t stream)
 {
@@ -646,6 +661,7 @@ extern "C" int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t s
     const int bn = d->Cout_pad % 128 == 0 ? 128 : (d->Cout_pad % 64 == 0 ? 64 : 32);
     a.tiles_m = cdiv(M, 128); a.tiles_n = d->Cout_pad / bn;
     a.uniform_k = (d->Cin % 64 == 0 && K % 64 == 0) ? 1 : 0;
+    a.gate = nullptr; a.gate_rmax = 0;
 #ifdef BF16_TRACE
     a.trace = g_bf16_trace;
 #endif
@@ -668,6 +684,15 @@ extern "C" int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t s
 #undef HLAUNCH
         M3D_LAUNCH_CHECK();
         return M3D_OK;
+    }
+    // DCNv2 3x3 with an fp16 weight copy and a bound workspace: |offset| pre-pass, then the LDS-patch kernel and this file's
+    // implicit-GEMM kernel as its fallback -- both read the bound, exactly one of them does the work (bf16_dcn_patch.hip)
+    const int pvar = deform ? dcn_patch_variant(d) : 0;
+    if (pvar) {
+        int rc;
+        if ((rc = launch_dcn_bound(d, st))) return rc;
+        if ((rc = launch_dcn_patch(a, d, pvar, st))) return rc;
+        a.gate = (const unsigned *)d->dcn_ws; a.gate_rmax = dcn_patch_rmax(pvar);
     }
 #define LAUNCH(BN_, DF_) hipLaunchKernelGGL((bf16_conv_kernel<BN_, DF_>), grid, block, 0, st, a)
     if (bn == 128) { if (deform) LAUNCH(128, true); else LAUNCH(128, false); }

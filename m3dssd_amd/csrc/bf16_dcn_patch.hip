@@ -1,0 +1,313 @@
+// DCNv2 3x3 (stride 1, pad 1) of the bf16 path with the sampling window resident in LDS ("patch" kernel).
+//
+// Why: the implicit-GEMM tile of bf16_conv.hip gathers the four bilinear corners of every (pixel, tap, 64-channel K-step)
+// from global memory -- 80 KB per workgroup K-step through a vector L1 that delivers 64 B/clk/CU (1280 cycles against 512 of
+// MFMA) -- and combines them in fp32 (52 VALU instructions per 16-byte piece, 32 of them unpacking bf16 pairs: another ~1000
+// cycles).  On 128 -> 128 @ 48x160, bs 64 that is 0.385 ms = 377 TFLOP/s, 0.15 of the bf16 MFMA peak, with the L1 path alone
+// putting a floor of ~0.19 ms under ANY global-gather design (4 corners x 9 taps x the input through 64 B/clk/CU).
+//
+// Here a workgroup owns a TH x 16 patch of output pixels and a 32-channel chunk at a time:
+//   * the input window the 9 taps can reach -- the patch grown by 1 (tap) + R (largest |offset| of the launch, rounded up) + 1
+//     (high bilinear corner) on every side -- is read ONCE per chunk with coalesced 16-byte loads, converted bf16 -> fp16
+//     (exact: a bf16 value has 8 significant bits, fp16 keeps 11; values beyond +-65504 saturate) and parked in
+//     LDS with a pixel stride of 80 bytes (odd multiple of 16: consecutive pixels fall into different bank groups); positions
+//     outside the image are stored as zeros, which IS the reference's rule (dcn_v2_im2col_cuda.cu:18-47,165: a corner outside
+//     the image contributes nothing, a sample at h <= -1 or h >= H has no corner inside);
+//   * a lane = (pixel, K half) of the MFMA B operand reads its four corners straight from the patch (ds_read_b128, immediate
+//     offsets for the corner to the right) and combines them with 16 v_pk_fma_f16 per fragment -- fp16 pairs, no unpacking --
+//     the result IS the B fragment of v_mfma_f32_32x32x16_f16: no staged sample tile, no second LDS round trip;
+//   * the sampling state of a (pixel, tap) -- one LDS offset, four fp16 corner weights with the modulation mask folded in --
+//     is built once per workgroup and kept in 27 registers;
+//   * weights (fp16 copy of the packed bf16 weights, exact) are staged per (tap, chunk) as in the halo-tile kernel.
+// The offsets decide whether the window fits: a pre-pass (dcn_bound_kernel) reduces max |offset| of the launch to 256 partial
+// maxima; this kernel and the implicit-GEMM fallback both read them, exactly one of the two does the work (R <= RMAX here,
+// otherwise there).  Everything stays inside one stream / one captured graph, no host round trip.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+#include "bf16_tile.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define DP_PS 80                         // bytes per patch pixel: 32 fp16 channels + 16 bytes pad
+#define DP_WKB 64                        // bytes per weight row and step (32 fp16 channels)
+
+// ---- largest |offset| of a launch -------------------------------------------------------------------------------------------
+// partial[b] = max over the pixels of block b of the bit pattern of |offset| (non-negative floats order like their bits; a NaN
+// sorts above every number and sends the launch to the fallback kernel).
+__global__ __launch_bounds__(256) void dcn_bound_kernel(const float *__restrict__ om, int M, int om_cs, int n_off, unsigned *__restrict__ partial)
+{
+    __shared__ unsigned red[4];
+    unsigned mx = 0u;
+    const int n4 = (n_off + 3) >> 2;
+    for (int m = blockIdx.x * 256 + threadIdx.x; m < M; m += gridDim.x * 256) {
+        const f32x4 *row = reinterpret_cast<const f32x4 *>(om + (size_t)m * om_cs);
+        for (int q = 0; q < n4; ++q) {
+            const f32x4 v = row[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * q + e < n_off) mx = max(mx, __float_as_uint(v[e]) & 0x7fffffffu);
+        }
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, s, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
+}
+
+template <int TH, int RMAX>
+__global__ __launch_bounds__(TH * 32) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void bf16_dcn_patch_kernel(const Bf16Args a, const void *__restrict__ wgt16, const unsigned *__restrict__ bound)
+{
+    constexpr int TW = 16, BM = TH * TW, BN = 128, NT = TH * 32, WAVES = TH / 2;
+    constexpr int PHMAX = TH + 3 + 2 * RMAX, PWMAX = TW + 3 + 2 * RMAX;
+    constexpr int HBYTES = PHMAX * PWMAX * DP_PS;
+    constexpr int HP = (PHMAX * PWMAX * 4 + NT - 1) / NT;        // 16-byte patch pieces per thread and chunk, at most
+    constexpr int PB = BN * (DP_WKB / 16) / NT;                  // weight pieces per thread and step
+    static_assert(PB >= 1 && BM * BN * 2 <= HBYTES, "tile shape");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[HBYTES + 2 * BN * DP_WKB];
+    unsigned char *Hs = lds, *Ws = lds + HBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // ---- does the window of this launch fit?  (uniform over the launch: the fallback kernel takes the opposite branch) --------
+    const int R = dcn_bound_radius(bound, reinterpret_cast<unsigned *>(lds), tid, NT);
+    if (R > RMAX) return;
+    const int PH = TH + 3 + 2 * R, PW = TW + 3 + 2 * R, PWB = PW * DP_PS;
+
+    const int ntiles = a.tiles_m * a.tiles_n;
+    int tile = blockIdx.x;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = tile & 7, idx = tile >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = tile / a.tiles_n, tile_n = tile - tile_m * a.tiles_n;
+    const int n0 = tile_n * BN;
+    const int tpx = a.Wo / TW, tpy = (a.Ho + TH - 1) / TH;
+    const int img = tile_m / (tpx * tpy), trem = tile_m - img * tpx * tpy;
+    const int y0 = (trem / tpx) * TH, x0 = (trem % tpx) * TW;
+    const int py0 = y0 - 1 - R, px0 = x0 - 1 - R;               // image position of patch pixel (0, 0)
+
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
+    const __amdgpu_buffer_rsrc_t rwgt = make_rsrc(wgt16, a.wgt_bytes);
+    float ssc = 1.f, ssh = 0.f;              // epilogue scale / shift of channel n0 + tid, fetched now, used after the K loop
+    if (tid < BN && n0 + tid < a.Cout) {
+        if (a.scale) ssc = a.scale[n0 + tid];
+        if (a.shift) ssh = a.shift[n0 + tid];
+    }
+
+    // ---- sampling state of this lane's pixel for the 9 taps (both K halves of a pixel build the same state) -----------------
+    const int p = wave * 32 + l31, ty = p / TW, tx = p - ty * TW;
+    const int oy = y0 + ty, ox = x0 + tx;
+    const bool pvalid = oy < a.Ho && ox < a.Wo;
+    const int mpx = pvalid ? (img * a.Ho + oy) * a.Wo + ox : -1;
+    int soff[9];
+    unsigned swa[9], swb[9];
+    {
+        f32x4 omv[7];
+        const f32x4 *omp = reinterpret_cast<const f32x4 *>(a.om + (size_t)(pvalid ? mpx : 0) * a.om_cs);
+#pragma unroll
+        for (int q = 0; q < 7; ++q) omv[q] = omp[q];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float dh = omv[(2 * t) >> 2][(2 * t) & 3], dw = omv[(2 * t + 1) >> 2][(2 * t + 1) & 3];
+            const float mk = pvalid ? omv[(18 + t) >> 2][(18 + t) & 3] : 0.f;
+            const float h_im = (float)(oy - 1 + t / 3) + dh, w_im = (float)(ox - 1 + t % 3) + dw;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const float lhh = h_im - hf, lww = w_im - wf, uh = 1.f - lhh, uw = 1.f - lww;
+            // |dh|, |dw| <= R puts (hf, wf) inside [py0, py0 + PH - 2] x [px0, px0 + PW - 2]; the clamp only keeps a lane without a
+            // pixel (or a launch whose bound was wrong) inside the LDS allocation
+            const int r = min(max((int)hf - py0, 0), PH - 2), cc = min(max((int)wf - px0, 0), PW - 2);
+            soff[t] = (r * PW + cc) * DP_PS + lh * 16;
+            const f32x2 wa = {uh * uw * mk, uh * lww * mk}, wb = {lhh * uw * mk, lhh * lww * mk};
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            swa[t] = __builtin_bit_cast(unsigned, __builtin_convertvector(wa, f16x2));       // round to nearest even
+            swb[t] = __builtin_bit_cast(unsigned, __builtin_convertvector(wb, f16x2));
+        }
+    }
+
+    // ---- patch staging map: piece q = tid + NT*i -> patch pixel q >> 2, 16-byte piece q & 3 ------------------------------------
+    const int npieces = PH * PW * 4;
+    const int piece = tid & 3, pix0 = tid >> 2;
+    const int hy0 = pix0 / PW, hx0 = pix0 - hy0 * PW;
+    const int dq = (NT / 4) / PW, dr = (NT / 4) - dq * PW;       // pixel advance per pass, as (rows, columns)
+    const int hdst0 = pix0 * DP_PS + piece * 16;
+    // weight staging map (as the halo-tile kernel at 32-channel steps): thread = (row tid >> 2, piece tid & 3), piece XOR (row >> 2) & 3
+    const int wrsub = tid >> 2;
+    constexpr int WRPP = NT / 4;
+    const unsigned woff0 = ((unsigned)(n0 + wrsub) * (unsigned)(a.KT * 64) + (unsigned)piece * 8u) * 2u;
+    const unsigned wrow_step = (unsigned)WRPP * (unsigned)(a.KT * 64) * 2u;
+    const int wdst0 = wrsub * DP_WKB + ((piece ^ ((wrsub >> 2) & 3)) << 4);
+    u32x4 rh[HP], rw[3][PB];
+    const int NC = a.Cin >> 5;                                   // 32-channel chunks
+
+    auto load_patch = [&](int c) __attribute__((always_inline)) {
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(c) * 64u;
+        int hy = hy0, hx = hx0;
+#pragma unroll
+        for (int i = 0; i < HP; ++i) {
+            const int y = py0 + hy, x = px0 + hx;
+            const bool ok = tid + NT * i < npieces && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            const unsigned off = ok ? ((unsigned)((img * a.H + y) * a.W + x) * (unsigned)a.in_cs + (unsigned)piece * 8u) * 2u : M3D_BUF_OOB;
+            rh[i] = buf_load_u32x4(rin, off, so);
+            hx += dr; hy += dq;
+            if (hx >= PW) { hx -= PW; ++hy; }
+        }
+    };
+    auto store_patch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < HP; ++i)
+            if (tid + NT * i < npieces) {
+                u32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {                   // bf16 pair -> fp16 pair (exact inside the fp16 range)
+                    const unsigned d = rh[i][e];
+                    v[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(d << 16), __uint_as_float(d & 0xffff0000u)));
+                }
+                *reinterpret_cast<u32x4 *>(Hs + hdst0 + i * (NT / 4) * DP_PS) = v;
+            }
+    };
+    auto load_w = [&](int c, int u, auto rtag) __attribute__((always_inline)) {
+        constexpr int RS = decltype(rtag)::value;
+        if (u >= 9) { u -= 9; ++c; }
+        if (c >= NC) return;
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(u * a.Cin + c * 32) * 2u;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) rw[RS][i] = buf_load_u32x4(rwgt, woff0, so + (unsigned)i * wrow_step);
+    };
+    auto store_w = [&](int buf, auto rtag) __attribute__((always_inline)) {
+        constexpr int RS = decltype(rtag)::value;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) *reinterpret_cast<u32x4 *>(Ws + buf * BN * DP_WKB + wdst0 + i * WRPP * DP_WKB) = rw[RS][i];
+    };
+
+    f32x16 acc[4][1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][0][r] = 0.f;
+
+#define RT(n) std::integral_constant<int, (n) % 3>{}
+    load_patch(0);
+    load_w(0, 0, RT(0));
+    load_w(0, 1, RT(1));
+    __syncthreads();                                            // the bound reduction used the start of the LDS
+    store_patch();
+    store_w(0, RT(0));
+    __syncthreads();
+    const int swk = (l31 >> 2) & 3;                             // swizzle term of this lane's weight rows
+    int t = 0;                                                  // step index; weight buffer t & 1
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int u = 0; u < 9; ++u, ++t) {
+            const bool last = (c == NC - 1) && u == 8;
+            if (u % 3 == 0) load_w(c, u + 2, RT(2)); else if (u % 3 == 1) load_w(c, u + 2, RT(0)); else load_w(c, u + 2, RT(1));
+            if (u == 5 && c + 1 < NC) load_patch(c + 1);        // the next chunk's window travels under the last taps of this one
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned char *Wb = Ws + (t & 1) * BN * DP_WKB + l31 * DP_WKB;
+            const unsigned char *P0 = Hs + soff[u], *P1 = P0 + PWB;
+            const unsigned wa = swa[u], wb = swb[u];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const u32x4 c00 = *reinterpret_cast<const u32x4 *>(P0 + s * 32), c01 = *reinterpret_cast<const u32x4 *>(P0 + s * 32 + DP_PS);
+                const u32x4 c10 = *reinterpret_cast<const u32x4 *>(P1 + s * 32), c11 = *reinterpret_cast<const u32x4 *>(P1 + s * 32 + DP_PS);
+                const int co = ((2 * s + lh) ^ swk) << 4;
+                f16x8 fw[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const f16x8 *>(Wb + j * 32 * DP_WKB + co);
+                // (1-lh)(1-lw) v1 + (1-lh) lw v2 + lh (1-lw) v3 + lh lw v4 (dcn_v2_im2col_cuda.cu:44-46), mask folded into the
+                // weights, on fp16 pairs (v_pk_mul_f16 / v_pk_fma_f16; the weight half is broadcast by op_sel).  Plain vector code,
+                // not inline asm: the fragment feeds the MFMA right behind it, and the wait states a VALU result needs before a
+                // matrix instruction reads it are only inserted for instructions the compiler can see (an asm version of these
+                // 16 instructions produced wrong fragments in some waves of the 8-wave tile, depending on the code around it).
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const h2 w2a = __builtin_bit_cast(h2, wa), w2b = __builtin_bit_cast(h2, wb);
+                const h2 w00 = __builtin_shufflevector(w2a, w2a, 0, 0), w01 = __builtin_shufflevector(w2a, w2a, 1, 1);
+                const h2 w10 = __builtin_shufflevector(w2b, w2b, 0, 0), w11 = __builtin_shufflevector(w2b, w2b, 1, 1);
+                u32x4 fb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned d00 = c00[e], d01 = c01[e], d10 = c10[e], d11 = c11[e];
+                    h2 r = __builtin_bit_cast(h2, d00) * w00;
+                    r = __builtin_elementwise_fma(__builtin_bit_cast(h2, d01), w01, r);
+                    r = __builtin_elementwise_fma(__builtin_bit_cast(h2, d10), w10, r);
+                    r = __builtin_elementwise_fma(__builtin_bit_cast(h2, d11), w11, r);
+                    fb[e] = __builtin_bit_cast(unsigned, r);
+                }
+                const f16x8 fp = __builtin_bit_cast(f16x8, fb);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j], fp, acc[j][0], 0, 0, 0);
+            }
+            if (!last) {
+                if (u % 3 == 0) store_w((t + 1) & 1, RT(1)); else if (u % 3 == 1) store_w((t + 1) & 1, RT(2)); else store_w((t + 1) & 1, RT(0));
+            }
+            if (u == 8 && c + 1 < NC) {
+                __syncthreads();                                // every wave is done reading the window
+                store_patch();
+            }
+            __syncthreads();
+        }
+    }
+#undef RT
+
+    int mpix[1] = {mpx}, lrow[1] = {p};
+    float *ssl = reinterpret_cast<float *>(lds + sizeof(lds) - 2 * BN * 4);      // the staging areas are free: the loop ended on a barrier
+    if (tid < BN) { ssl[tid] = ssc; ssl[BN + tid] = ssh; }
+    __syncthreads();
+    if (a.out_mode == 0) {
+        if (a.sigmoid_from < 0) conv_epilogue_fast<4, 1>(a, acc, mpix, lrow, n0, 0, lh, ssl, BN, lds);
+        else conv_epilogue<4, 1>(a, acc, mpix, n0, 0, lh, 0, ssl, BN, lds, lrow);
+        __syncthreads();
+        store_otile<BN, BM, NT>(a, lds, n0, 0, tid, [&](int row) {
+            const int y = y0 + row / TW, x = x0 + row % TW;
+            return (y < a.Ho && x < a.Wo) ? (img * a.Ho + y) * a.Wo + x : -1;
+        });
+    } else {
+        conv_epilogue<4, 1>(a, acc, mpix, n0, 0, lh, 0, ssl, BN);
+    }
+}
+
+// Which patch kernel serves a descriptor: 0 = none (the implicit-GEMM kernel only), 16 / 8 = rows of the pixel patch.
+int dcn_patch_variant(const m3d_conv_bf16_desc *d)
+{
+    static int on = -1;                   // M3D_BF16_DCN_PATCH=0: implicit-GEMM kernel everywhere (A/B)
+    if (on < 0) { const char *e = getenv("M3D_BF16_DCN_PATCH"); on = e ? atoi(e) : 1; }
+    if (!on || !d->dcn_offmask || !d->wgt_f16 || !d->dcn_ws || d->dcn_ws_bytes < DCN_BOUND_PARTIALS * 4) return 0;
+    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->groups != 1 || d->wgt_img_stride != 0) return 0;
+    if (d->Cin % 32 != 0 || d->Cout_pad % 128 != 0 || d->W % 16 != 0 || d->dcn_om_cs < 28 || d->dcn_om_cs % 4 != 0) return 0;
+    if (d->H % 16 == 0) return 16;
+    if (d->H % 8 == 0) return 8;
+    return 0;
+}
+int dcn_patch_rmax(int variant) { return variant == 16 ? 10 : 6; }
+
+int launch_dcn_bound(const m3d_conv_bf16_desc *d, hipStream_t st)
+{
+    const long long M = (long long)d->N * d->Ho * d->Wo;
+    hipLaunchKernelGGL(dcn_bound_kernel, dim3(DCN_BOUND_PARTIALS), dim3(256), 0, st, d->dcn_offmask, (int)M, d->dcn_om_cs, 2 * d->kh * d->kw,
+                       (unsigned *)d->dcn_ws);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+int launch_dcn_patch(const Bf16Args &a0, const m3d_conv_bf16_desc *d, int variant, hipStream_t st)
+{
+    Bf16Args a = a0;
+    a.tiles_n = d->Cout_pad / 128;
+    const unsigned *bound = (const unsigned *)d->dcn_ws;
+    if (variant == 16) {
+        a.tiles_m = d->N * (d->Ho / 16) * (d->Wo / 16);
+        hipLaunchKernelGGL((bf16_dcn_patch_kernel<16, 10>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, st, a, d->wgt_f16, bound);
+    } else {
+        a.tiles_m = d->N * (d->Ho / 8) * (d->Wo / 16);
+        hipLaunchKernelGGL((bf16_dcn_patch_kernel<8, 6>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, st, a, d->wgt_f16, bound);
+    }
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}

@@ -81,6 +81,12 @@ def pack_conv_bf16(weight, cout_pad=None, cin_pad=None, device=None):
 
 
 class PackedBf16:
+    def f16(self):
+        """fp16 copy of the packed weights for the LDS-patch DCNv2 kernel (exact for |w| in [6.1e-5, 65504]; made on first use)."""
+        if getattr(self, "_wp16", None) is None:
+            self._wp16 = self.wp.float().to(torch.float16).contiguous()
+        return self._wp16
+
     def __init__(self, eng, weight, bias=None, bn=None, cout_pad=None):
         dev = eng.device
         self.cout, self.cin, self.kh, self.kw = weight.shape
@@ -206,7 +212,7 @@ class EngineBF16(Engine):
 
     def _conv16(self, plan, name, x, out=None, wgt=None, kpad=None, cout=None, cout_pad=None, kh=1, kw=1, stride=1, pad=0,
                 scale=None, shift=None, act=0, res=None, res_mode=0, sigmoid_from=-1, om=None, out_mode=0, planar=None,
-                wgt_img_stride=0, groups=1, in_goff=0, wgt_goff=0, out_goff=0, ss_goff=0, cin=None, flops_cin=None):
+                wgt_img_stride=0, groups=1, in_goff=0, wgt_goff=0, out_goff=0, ss_goff=0, cin=None, flops_cin=None, wgt_f16=None):
         """One m3d_conv_bf16_forward launch appended to the plan.  x: View16 (bf16); out: View16 (bf16 or fp32 NHWC) or
         planar = (tensor, img_stride, channel offset) for the fp32 planar staging of the head outputs."""
         d = ConvBf16Desc()
@@ -233,13 +239,21 @@ class EngineBF16(Engine):
         d.act, d.sigmoid_from = act, sigmoid_from
         if om is not None:
             d.dcn_offmask, d.dcn_om_cs = om.ptr, om.cs
+            if wgt_f16 is not None:
+                # LDS-patch DCNv2 kernel (csrc/bf16_dcn_patch.hip): fp16 copy of the packed weights + the device scratch of the
+                # |offset| bound; the library decides per launch, on the device, whether the sampling window fits
+                ws = torch.zeros(256, device=self.device, dtype=torch.int32)
+                plan.keep += [wgt_f16, ws]
+                d.wgt_f16, d.dcn_ws, d.dcn_ws_bytes = wgt_f16.data_ptr(), ws.data_ptr(), ws.numel() * 4
         d.groups, d.in_group_off, d.wgt_group_off, d.out_group_off, d.ss_group_off = groups, in_goff, wgt_goff, out_goff, ss_goff
         L = self.L
         ref = ctypes.byref(d)
         flops = 2.0 * x.n * d.Ho * d.Wo * cout * kh * kw * (flops_cin if flops_cin is not None else cin) * groups
         bn = 128 if cout_pad % 128 == 0 else (64 if cout_pad % 64 == 0 else 32)
         variant = L.m3d_conv_bf16_variant(ref)          # which kernel the library runs for this descriptor
-        if variant:
+        if variant >= 3:
+            kind = "bf16_dcn_patch<%d>" % (8 * (variant - 2))     # LDS-patch DCNv2 (+ the gated implicit-GEMM fallback behind it)
+        elif variant:
             kind = "bf16_halo<%d,%d>" % (bn, 16 * variant)
         else:
             kind = "bf16_conv<%d%s>" % (bn, ",deform" if om is not None else "")
@@ -250,7 +264,8 @@ class EngineBF16(Engine):
         self._conv16(plan, name, x, out, wgt=pc.wp, kpad=pc.kpad, cout=pc.cout, cout_pad=pc.cout_pad, kh=pc.kh, kw=pc.kw,
                      stride=stride, pad=pad, scale=pc.scale if (affine and pc.has_affine) else None,
                      shift=pc.shift if (affine and pc.has_affine) else None, act=act, res=res, res_mode=res_mode,
-                     sigmoid_from=sigmoid_from, om=om, out_mode=out_mode, cin=pc.cin)
+                     sigmoid_from=sigmoid_from, om=om, out_mode=out_mode, cin=pc.cin,
+                     wgt_f16=pc.f16() if om is not None else None)
 
     # ------------------------------------------------------------------ plan construction
     def _build_plan(self, B, H, W):

@@ -60,7 +60,7 @@ def _nhwc16(x, cs=None):
 
 
 def _run_conv(x, wt, bias=None, bn=None, stride=1, pad=0, act=0, res=None, res_mode=0, sigmoid_from=-1, out_mode=0, om=None,
-              in_cs=None, variant=None):
+              in_cs=None, variant=None, patch=False):
     """Through the C ABI.  Returns [N, Cout, Ho, Wo] fp32 (bf16 outputs widened)."""
     from m3dssd_amd import _hip
     from m3dssd_amd.engine_bf16 import pack_conv_bf16
@@ -96,6 +96,10 @@ def _run_conv(x, wt, bias=None, bn=None, stride=1, pad=0, act=0, res=None, res_m
         o = om.to(dev).contiguous()
         d.dcn_offmask, d.dcn_om_cs = o.data_ptr(), o.shape[-1]
         keep.append(o)
+        if patch:           # LDS-patch DCNv2 kernel: fp16 weight copy + the device scratch of the |offset| bound
+            w16, ws = wp.float().to(torch.float16).contiguous(), torch.zeros(256, device=dev, dtype=torch.int32)
+            d.wgt_f16, d.dcn_ws, d.dcn_ws_bytes = w16.data_ptr(), ws.data_ptr(), 1024
+            keep += [w16, ws]
     if out_mode == 0:
         ocs = (co + 7) // 8 * 8 + 8
         out = torch.full((n, ho, wo, ocs), 512.0, device=dev, dtype=BF16)
@@ -417,6 +421,112 @@ def test_dcn_bf16_matches_oracle(shape):
     # fp32 output mode isolates the sample rounding from the output rounding
     got32 = _run_conv(x, wt, b, None, 1, pad, 0, None, 0, -1, 1, om)
     assert (got32 - ref).abs().max().item() < 1e-2 * scale
+
+
+def _dcn_case(shape, off_std, seed=0, clamp=None):
+    n, c, h, w, co = shape
+    g = torch.Generator().manual_seed(sum(shape) + seed)
+    x = _r(torch.randn(n, c, h, w, generator=g) + 0.5)
+    wt = _r(torch.randn(co, c, 3, 3, generator=g) / (c * 9) ** 0.5)
+    b = torch.randn(co, generator=g) * 0.1
+    off = torch.randn(n, 18, h, w, generator=g) * off_std
+    if clamp is not None:
+        off = off.clamp(-clamp, clamp)
+    m = torch.rand(n, 9, h, w, generator=g)
+    om = torch.cat([off, m], 1).permute(0, 2, 3, 1).contiguous()
+    om = torch.cat([om, torch.zeros(n, h, w, 5)], -1).contiguous()          # pixel stride 32 like the engine's maps
+    return x, wt, b, off, m, om
+
+
+@pytest.mark.parametrize("shape,variant,off_std,clamp", [
+    ((2, 128, 16, 32, 128), 4, 1.5, None),        # 16 x 16 patches, offsets up to ~6
+    ((1, 128, 48, 160, 128), 4, 2.0, 9.9),        # the full-size backbone map, window radius 10
+    ((2, 256, 24, 80, 256), 3, 1.2, 5.9),         # 8 x 16 patches, two channel tiles, radius 6
+    ((3, 64, 8, 16, 128), 3, 0.3, None),          # one patch per image: every window crosses all four image borders
+    ((1, 32, 16, 16, 100), 4, 1.0, None),         # ragged Cout (pad 128), one chunk
+])
+def test_dcn_bf16_patch_kernel_matches_oracle(shape, variant, off_std, clamp):
+    """The LDS-patch DCNv2 kernel (csrc/bf16_dcn_patch.hip: fp16 window in LDS, v_pk_fma_f16 bilinear combine straight into the
+    B operand of v_mfma_f32_32x32x16_f16) against oracle/dcn.py on the bf16-rounded operands, and against the implicit-GEMM
+    kernel it replaces.  Its intermediate (the fp16 sample, 11 significant bits) is finer than the implicit-GEMM kernel's (bf16
+    sample, 8 bits): the same 1 % of the output scale bounds both; the two kernels agree to that bound as well."""
+    from oracle import dcn as odcn
+    x, wt, b, off, m, om = _dcn_case(shape, off_std, 1, clamp)
+    ref = odcn.dcn_v2_forward(x, off, m, wt, b, 1, 1, 1, 1)
+    scale = ref.abs().max().item()
+    got32 = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 1, om, variant=variant, patch=True)
+    err = (got32 - ref).abs().max().item()
+    old32 = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 1, om, variant=0)
+    err_old = (old32 - ref).abs().max().item()
+    _log("dcn_bf16_patch", dict(shape=list(shape), err=err, err_implicit_gemm=err_old, scale=scale))
+    assert err < 1e-2 * scale
+    assert err <= max(err_old * 1.25, 2e-3 * scale)            # not less accurate than the kernel it replaces
+    # bf16 NHWC output with BatchNorm + LeakyReLU + residual through the shared epilogue
+    g = torch.Generator().manual_seed(3)
+    co = shape[4]
+    bn = (torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.1, torch.randn(co, generator=g) * 0.1,
+          torch.rand(co, generator=g) + 0.5)
+    res = _r(torch.randn(shape[0], co, shape[2], shape[3], generator=g))
+    ref2 = F.leaky_relu(F.batch_norm(odcn.dcn_v2_forward(x, off, m, wt, b, 1, 1, 1, 1), bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)
+                        + res, 0.01)
+    got2 = _run_conv(x, wt, b, bn, 1, 1, 1, res, 0, -1, 0, om, variant=variant, patch=True)
+    s2 = ref2.abs().max().item()
+    assert (got2 - ref2).abs().max().item() < 1e-2 * s2 + 2.0 ** -8 * s2
+
+
+def test_dcn_bf16_patch_kernel_hands_over_when_the_window_does_not_fit():
+    """The decision is taken on the device from the launch's largest |offset|: inside the radius the patch kernel does the work,
+    one offset beyond it (or a NaN) and the implicit-GEMM kernel behind it does -- the results are then bit-identical to a
+    launch without the patch kernel."""
+    from oracle import dcn as odcn
+    shape = (2, 64, 16, 32, 128)
+    x, wt, b, off, m, om = _dcn_case(shape, 1.0, 2, 4.0)
+    base = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 0, om, variant=0)
+    fit = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 0, om, variant=4, patch=True)
+    assert not torch.equal(fit, base)                           # a different kernel did the work (fp16 sample vs bf16 sample)
+    for bad in (10.25, -37.0, float("nan")):
+        om2 = om.clone()
+        om2[1, 7, 9, 5] = bad                                   # dw of tap 2 at one pixel
+        base2 = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 0, om2, variant=0)
+        got2 = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 0, om2, variant=4, patch=True)
+        assert torch.equal(got2, base2), bad
+    # exactly at the radius it still fits
+    om3 = om.clone()
+    om3[0, 3, 4, 0] = 10.0
+    off3 = om3[..., :18].permute(0, 3, 1, 2).contiguous()
+    ref3 = odcn.dcn_v2_forward(x, off3, m, wt, b, 1, 1, 1, 1)
+    got3 = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 1, om3, variant=4, patch=True)
+    base3 = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 1, om3, variant=0)
+    assert not torch.equal(got3, base3)
+    assert (got3 - ref3).abs().max().item() < 1e-2 * ref3.abs().max().item()
+
+
+def test_dcn_bf16_patch_kernel_border_positions():
+    """Exact border positions through the zero-padded window: a 3x3 deformable conv whose centre tap samples the grid of
+    _border_grid_offsets (exactly -1, just inside, between rows, the last row, past it, exactly H) while the other taps have
+    mask 0 -- the patch kernel must reproduce the reference's corner rules without any per-corner test."""
+    from oracle import dcn as odcn
+    h, w, c, co = 16, 32, 32, 128
+    g = torch.Generator().manual_seed(9)
+    x = _r(torch.randn(1, c, h, w, generator=g) + 3.0)
+    wt = _r(torch.randn(co, c, 3, 3, generator=g) / (9 * c) ** 0.5)
+    b = torch.zeros(co)
+    off = torch.zeros(1, 18, h, w)
+    m = torch.zeros(1, 9, h, w)
+    o1 = _border_grid_offsets(h, w)                              # absolute position hs[i % 8] for a 1x1 tap at (i, j)
+    off[:, 8:10] = o1                                            # centre tap (index 4) of a 3x3 / pad 1 kernel sits at (i, j) too
+    m[:, 4] = 1.0
+    # keep the launch inside the patch radius: the grid asks for |offset| up to 16 on this map; fold rows / columns into [-8, 8]
+    keep = (off.abs() <= 9.5).all(1, keepdim=True)
+    off = off * keep
+    m = m * keep
+    ref = odcn.dcn_v2_forward(x, off, m, wt, b, 1, 1, 1, 1)
+    om = torch.cat([off, m, torch.zeros(1, 5, h, w)], 1).permute(0, 2, 3, 1).contiguous()
+    got = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 1, om, variant=4, patch=True)
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() < 1e-2 * scale
+    zero_rows = ref.abs().amax(dim=(0, 1, 3)) == 0
+    assert zero_rows.any() and torch.equal(got[0, :, zero_rows, :], torch.zeros_like(got[0, :, zero_rows, :]))
 
 
 def _border_grid_offsets(h, w):
