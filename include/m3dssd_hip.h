@@ -172,7 +172,7 @@ typedef struct m3d_conv_bf16_desc {
     /* Deformable 3x3 / stride 1 / pad 1 only, all three optional (NULL / 0 = implicit-GEMM kernel as before): an fp16 copy of
      * `wgt` (same [Cout_pad][Kpad] layout; bf16 -> fp16 is exact for |w| in [6.1e-5, 65504]) and >= 1024 bytes of device
      * scratch enable the LDS-patch kernel (csrc/bf16_dcn_patch.hip): the launch's largest |offset| is reduced on the device
-     * into dcn_ws, and the sampling runs from an LDS-resident fp16 window when it fits (|offset| <= 10 on maps with
+     * into dcn_ws, and the sampling runs from an LDS-resident fp16 window when it fits (|offset| <= 9 on maps with
      * H % 16 == 0, <= 6 with H % 8 == 0; W % 16 == 0, Cin % 32 == 0, Cout_pad % 128 == 0), else the implicit-GEMM kernel
      * does the launch's work -- decided on the device, no host synchronisation. */
     const void *wgt_f16;

@@ -14,7 +14,7 @@ from m3dssd_amd.engine_bf16 import pack_conv_bf16          # noqa: E402
 dev = torch.device("cuda:0")
 L = _hip.lib()
 SHAPES = [(128, 128, 48, 160, 64), (256, 128, 24, 80, 64), (256, 256, 24, 80, 64)]
-CASES = [(0.25, 0.9), (1.0, 2.9), (1.5, 4.9), (2.0, 6.9), (3.0, 9.9)] if len(sys.argv) < 2 else \
+CASES = [(0.25, 0.9), (1.0, 2.9), (1.5, 4.9), (2.0, 6.9), (3.0, 8.9)] if len(sys.argv) < 2 else \
     [(float(s), float(s) * 3.3) for s in sys.argv[1:]]
 st = torch.cuda.current_stream().cuda_stream
 for cin, cout, H, W, B in SHAPES:
