@@ -735,6 +735,63 @@ def test_bf16_network_matches_fp32_oracle_within_stated_tolerance(crop, B, pad):
         assert ((o_mask - torch.gather(fg, 1, ind))[diff].abs() < BF16_PROB_TOL).all()
 
 
+# What the bf16 path means for the DECODED boxes (pixels / metres / radians), measured on the rows the fp32 oracle keeps: the
+# normalised regression outputs above go through exp() for the sizes and are scaled by anchor sizes for the centres.
+# Measured (2 frames of 1280x384, synthetic weights; gpurun_out/parity_r02.jsonl "bf16_physical_units"): rows kept after NMS --
+# 2-D corners median 1.5 px / max 5.4 px (boxes are hundreds of pixels wide: exp() of the size regression), projected 3-D centre
+# 0.31 / 0.82 px, depth 0.9 / 2.8 mm, w / h / l 1.1 % / 2.7 %, rotation 0.0025 / 0.007 rad; over the 3000 pre-NMS rows the
+# maxima are 21.7 px, 1.8 px, 9 mm, 6.3 %, 0.058 rad.  The bounds below are (median, max) with a 2x margin.
+BF16_PHYS_TOL = {"box2d_px": (3.0, 45.0), "xy3d_px": (1.0, 4.0), "z_m": (0.005, 0.02), "whl_rel": (0.03, 0.13), "ry_rad": (0.006, 0.12)}
+
+
+@pytest.mark.parametrize("crop,B", [((384, 1280), 2)])
+def test_bf16_decoded_boxes_in_physical_units(crop, B):
+    """The bf16 engine's outputs decoded with the reference's rules (lib/rpn_util.py:1442-1521, oracle/detect.py) next to the fp32
+    oracle's (the engine's top-1 anchor / hard-mask decisions injected), on the rows the ORACLE's detector keeps after NMS (<= 40
+    per image) and on its 3000 pre-NMS rows: 2-D box corners in pixels, projected 3-D centre in pixels, depth in metres,
+    w / h / l relative, rotation in radians.  Asserted as (median, max) pairs over the kept rows."""
+    from oracle import detect as odet
+    from oracle import model_cpu
+    net, conf = _net(crop, B, "bf16")
+    sd = synth.synth_state_dict(0)
+    x = synth.synth_frames(B, crop, 1234)
+    with torch.no_grad():
+        cls, prob, b2, b3, fs, rois = (t.cpu() for t in net(x.to(_dev())))
+    plan = net.engine().plan_for(B, *crop)
+    fh, fw = crop[0] // 8, crop[1] // 8
+    ind = plan.named["sel_idx"].view(B, 1, fh, fw).long().cpu()
+    prob_sel = plan.named["sel_prob"].view(B, 1, fh, fw).cpu()
+    cconf = synth.synth_conf(crop, 0, batch_size=B, device="cpu")
+    with torch.no_grad():
+        o = model_cpu.rpn_forward(sd, cconf, x, inject={"sel": {"ind": ind, "hard": (prob_sel > 0.5).float()}})
+    rep = {}
+    for scope in ("kept", "top3000"):
+        d = {k: [] for k in BF16_PHYS_TOL}
+        dscore = []
+        for i in range(B):
+            ab, keep, top = odet.detect_image(o[1][i], o[2][i], o[3][i], o[5], cconf)
+            rows = torch.from_numpy(top[keep] if scope == "kept" else top)
+            r2, r3, rs, _, _ = odet.decode(o[1][i], o[2][i], o[3][i], o[5], cconf)
+            g2, g3, gs, _, _ = odet.decode(prob[i], b2[i], b3[i], rois, cconf)
+            d["box2d_px"].append((g2[rows] - r2[rows]).abs().max(1)[0])
+            d["xy3d_px"].append((g3[rows, :2] - r3[rows, :2]).abs().max(1)[0])
+            d["z_m"].append((g3[rows, 2] - r3[rows, 2]).abs())
+            d["whl_rel"].append(((g3[rows, 3:6] - r3[rows, 3:6]).abs() / r3[rows, 3:6].abs()).max(1)[0])
+            d["ry_rad"].append((g3[rows, 6] - r3[rows, 6]).abs())
+            dscore.append((gs[rows] - rs[rows]).abs())
+        for k, v in d.items():
+            v = torch.cat(v)
+            rep["%s_%s" % (scope, k)] = [v.median().item(), v.max().item()]
+        rep[scope + "_score"] = torch.cat(dscore).max().item()
+        rep[scope + "_rows"] = int(sum(len(v) for v in d["z_m"]))
+    _log("bf16_physical_units", rep)
+    for k, (tmed, tmax) in BF16_PHYS_TOL.items():
+        for scope in ("kept", "top3000"):
+            med, mx = rep["%s_%s" % (scope, k)]
+            assert med < tmed and mx < tmax, (scope, k, med, mx)
+    assert rep["kept_score"] < BF16_PROB_TOL
+
+
 def test_anab_pool_nested_bf16_matches_fp32_kernel():
     """m3d_anab_pool_nested_bf16 (K|V map stored as bf16) against m3d_anab_pool_nested on the widened values: same sums."""
     from m3dssd_amd import _hip

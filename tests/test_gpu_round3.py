@@ -236,3 +236,52 @@ def test_dcn_non_finite_sampling_positions_contribute_nothing():
     got = ops.dcn_v2_forward(x.to(dev), off.to(dev), m.to(dev), wt.to(dev), b.to(dev), 1, 1, 1, 1).cpu()
     assert torch.isfinite(got).all()
     assert _relerr(got, ref) < 2e-4
+
+
+# ------------------------------------------------------------------------------------ run-to-run identity, every kernel family
+def _soak(dtype, B, crop, n):
+    """n forwards on the same frames: every output and every named intermediate buffer of the plan (all kernel families of the
+    step write one: Winograd wave / LDS, wave-granular conv plain and deformable, block igemm, fused heads, halo tile, DCNv2
+    patch / implicit GEMM, front end, ANAB, pooling / up-sampling helpers) compared bit for bit with the first forward."""
+    from model.M3d_inference_align import build
+    conf = synth.synth_conf(crop, 0, batch_size=B, device="cuda:0")
+    net = build(conf, "test")
+    net.load_state_dict(synth.synth_state_dict(0), strict=True)
+    net = net.to(_dev()).set_compute_dtype(dtype)
+    x = synth.synth_frames(B, crop, 7).to(_dev())
+    ref, plan, bad, kinds = None, None, [], set()
+    for it in range(n):
+        with torch.no_grad():
+            outs = net(x)[:4]
+        torch.cuda.synchronize()
+        if plan is None:
+            plan = net.engine().plan_for(B, *crop)
+            kinds = set(op[1].split("<")[0] for op in plan.ops)
+        snap = {"out%d" % i: t.clone() for i, t in enumerate(outs)}
+        for k, v in plan.named.items():
+            t = getattr(v, "t", v)
+            if torch.is_tensor(t):
+                snap[k] = t.clone()
+        if ref is None:
+            ref = snap
+            continue
+        diff = [k for k in snap if not torch.equal(ref[k].view(torch.uint8), snap[k].view(torch.uint8))]
+        if diff:
+            bad.append((it, diff[:6]))
+    return bad, len(ref), kinds
+
+
+def test_fp32_forward_is_bit_identical_over_100_runs_at_the_bench_size():
+    """the compare-built padding predicates of the non-deformable MFMA kernels (Winograd wave, plain wave conv,
+    fused heads) sit next to matrix instructions at 2-3 waves per SIMD like the deformable kernels did when they dropped a
+    corner once per 10^5..10^6 states; a wrong select there would show as run-to-run differences at these grid sizes."""
+    bad, nbuf, kinds = _soak("f32", 8, (384, 1280), 100)
+    assert {"wino_wave", "conv_wave", "head_mlp", "igemm"} <= kinds, kinds
+    assert not bad, bad[:3]
+    assert nbuf > 20
+
+
+def test_bf16_forward_is_bit_identical_over_40_runs_at_batch_64():
+    bad, nbuf, kinds = _soak("bf16", 64, (384, 1280), 40)
+    assert {"bf16_halo", "bf16_conv", "bf16_head_mlp", "bf16_frontend", "bf16_anab", "bf16_dcn_patch"} <= kinds, kinds
+    assert not bad, bad[:3]
