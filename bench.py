@@ -98,6 +98,8 @@ def kernel_symbol(label):
     if label.startswith("bf16_conv"):
         return "void bf16_conv_kernel<%s, %s>(Bf16Args)" % (re.findall(r"\d+", label.split("<", 1)[1])[0],
                                                             "true" if "deform" in label else "false")
+    if label.startswith("wino44"):
+        return "wino44_kernel(Wino44Args)"
     if label.startswith("wino_wave"):
         return "void wino_wave_kernel<%s>(WinoArgs)" % ("true" if "splitk" in label else "false")
     if label.startswith("wino"):
@@ -383,7 +385,7 @@ def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=N
     peak_tf = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
     families = {}
     for k, (ms, fl, cnt) in sorted(igemm.items(), key=lambda kv: -kv[1][0]):
-        div = 2.25 if k.startswith("wino") else 1.0
+        div = 4.0 if k.startswith("wino44") else (2.25 if k.startswith("wino") else 1.0)
         tf = fl / (ms * 1e-3) / 1e12 / div if ms > 0 else 0.0
         tr, src = pmc_traffic(k)
         families[k] = {"kernel": kernel_symbol(k), "launches_per_step": cnt, "ms_per_step": round(ms, 3),
@@ -395,7 +397,7 @@ def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=N
     if rank == 0:
         value = world * B * steps / dt
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-        wino_div = 2.25 if dominant.startswith("wino") else 1.0
+        wino_div = 4.0 if dominant.startswith("wino44") else (2.25 if dominant.startswith("wino") else 1.0)
         out = {
             "metric": ("images/sec at 1280x384 bs=8, 1/2/4/8 MI355X; 3D-box Linf vs ref" if not bf16 else
                        "images/sec at 1280x384 bs=64 bf16 (BASELINE.json configs[2]), 1/2/4/8 MI355X"),
@@ -416,9 +418,12 @@ def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=N
             "roofline": {"bound": "mfma", "kernel": kernel_symbol(dominant), "achieved": round(achieved / wino_div, 2),
                          "peak": peak_tf, "unit": "TFLOP/s",
                          "frac": round(achieved / wino_div / peak_tf, 4),
-                         "note": ("achieved = MFMA FLOPs executed by the Winograd F(2x2,3x3) launches (2*16*Cin*Cout per 2x2 output "
-                                  "tile = direct-convolution FLOPs of SURVEY 8d / 2.25) / HIP-event time; peak = dense fp32 MFMA at "
-                                  "the 2.4 GHz boost clock") if wino_div > 1 else
+                         "note": (("achieved = MFMA FLOPs executed by the Winograd F(4x4,3x3) launches (2*36*Cin*Cout per 4x4 output "
+                                   "tile = direct-convolution FLOPs of SURVEY 8d / 4) / HIP-event time; peak = dense fp32 MFMA at "
+                                   "the 2.4 GHz boost clock") if wino_div == 4.0 else
+                                  ("achieved = MFMA FLOPs executed by the Winograd F(2x2,3x3) launches (2*16*Cin*Cout per 2x2 output "
+                                   "tile = direct-convolution FLOPs of SURVEY 8d / 2.25) / HIP-event time; peak = dense fp32 MFMA at "
+                                   "the 2.4 GHz boost clock")) if wino_div > 1 else
                                  "achieved = algorithmic FLOPs of the launches / HIP-event time",
                          "direct_conv_equivalent_tflops": round(achieved, 2),
                          "traffic": pmc_traffic(dominant)[0], "traffic_source": pmc_traffic(dominant)[1],

@@ -130,6 +130,17 @@ int m3d_wino_conv3x3_variant(const m3d_conv_desc *d);
 int m3d_wino_conv3x3_splitk_plan(const m3d_conv_desc *d, int *splits, long long *ws_bytes);
 /* Same with the kernel chosen by the caller: variant -1 = automatic, 0 = LDS kernel, 1 = wave kernel (tests, tuning). */
 int m3d_wino_conv3x3_forward_ex(const m3d_conv_desc *d, int variant, m3d_stream_t stream);
+/* Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32 (csrc/wino44_conv.hip): 4x fewer MFMA FLOPs than the direct 3x3 convolution
+ * (F(2x2,3x3): 2.25x).  Same descriptor and epilogue (scale / shift, residual, LeakyReLU) as m3d_wino_conv3x3_forward; `wgt`
+ * points to U = G g G^T (6x6 per filter, fp64 -> fp32) packed [Cout_pad/32][Cin/16][36 xi][2][64][4], see
+ * m3dssd_amd/engine.py:pack_wino44.  Needs H % 4 == W % 4 == 0, Cin % 16 == 0, Cout_pad % 64 == 0, no sigmoid channels, NHWC
+ * output (m3d_wino44_applicable = 1).  fp32 rounding error ~7x that of direct summation (rms 1.5e-6 of the output scale at
+ * Cin = 128). */
+int m3d_wino44_applicable(const m3d_conv_desc *d);
+int m3d_wino44_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t stream);
+/* nb = 16-channel blocks per wave: 2 (128-channel workgroups; needs Cout_pad % 128 == 0), 1 (64-channel workgroups), 0 = 2 where
+ * the 16-tile strips x 128-channel blocks give >= 200 workgroups, else 1 (tests, tuning). */
+int m3d_wino44_conv3x3_forward_ex(const m3d_conv_desc *d, int nb, m3d_stream_t stream);
 
 /* Average launch geometry chosen for a descriptor (for roofline bookkeeping / tests). */
 int m3d_conv2d_tile(const m3d_conv_desc *d, int *bm, int *bn, int *bk, int *grid);

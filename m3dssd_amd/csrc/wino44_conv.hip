@@ -1,0 +1,376 @@
+// Winograd F(4x4,3x3) convolution (3x3, stride 1, pad 1, fp32) on v_mfma_f32_16x16x4_f32.
+//
+// Why: the F(2x2,3x3) wave kernel (wino_conv.hip) executes 16 multiplies per 4 outputs (direct: 36); F(4x4,3x3) executes 36
+// per 16 outputs -- 1.78x fewer MFMA FLOPs again.  Its 36 transform positions do not fit the one-wave 32 x 32-tile design (36 x
+// 16 accumulator registers), so the tile is 16 output tiles x 32 output channels per wave on 16x16x4 blocks (36 x 2 x 4 = 288
+// accumulator registers of the wave's 512), and the price of the smaller MFMA block -- twice the operand traffic per FLOP --
+// is paid by sharing the input side across the workgroup:
+//   * workgroup = 4 waves = 16 tiles (16 x 1 strip of 4x4-pixel output tiles) x 128 output channels; a stage = 16 input
+//     channels; thread (tile, channel) loads its 6x6 patch (36 dword loads, padding positions read 0 through the buffer range
+//     check), runs B^T d B (144 scalar FMA / add: ONE input channel per thread, so the transform costs 1/4 of what it would
+//     cost per wave) and writes the 36 values to LDS, V[xi][tile][16 channels];
+//   * per transform position xi a wave reads its A operand with ONE ds_read_b128 (lane = (tile, channel quad): the four
+//     floats are the four k-steps of the stage) and runs 8 MFMAs (4 k-steps x 2 channel blocks of 16) against B fragments that
+//     stream global -> register in fragment order, four positions ahead (hand-counted s_waitcnt, as in wino_conv.hip);
+//   * V is double buffered: the transform of stage s + 1 is written while other waves may still read stage s -- one barrier
+//     per stage (288 MFMAs per wave);
+//   * A^T M A (36 -> 16 values per (tile, channel)), folded BatchNorm / bias, residual and LeakyReLU run in registers.
+// fp32 error: the F(4x4,3x3) transforms amplify rounding ~7x relative to F(2x2,3x3) / direct summation (rms 1.5e-6 vs 2.2e-7
+// of the output scale at Cin = 128, max 1.5e-5; tools/ and DESIGN.md); U = G g G^T is computed in fp64 and rounded once.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+struct Wino44Args {
+    const float *in;
+    const float *U;          // [Cout_pad/32][Cin/16][36][2][64 lanes][4]
+    float *out;
+    const float *scale, *shift, *res;
+    int in_cs, out_cs, res_cs;
+    unsigned in_bytes, out_bytes, res_bytes;
+    int N, H, W, Cin, Cout;
+    int TH, TW, NT;          // 4x4 output tiles per image (rows, cols), total
+    int act, res_mode;
+#ifdef WINO_TRACE
+    long long *trace;
+#endif
+};
+
+#define W44_LA 4             // transform positions the B fragments run ahead (ring of 4 register sets)
+
+#ifdef WINO_TRACE
+// diagnostic build (make trace): s_memtime stamps of lane 0 of waves 0 and 3 of every workgroup, 64 slots each (tools/wino44_trace.py)
+static long long *g_w44_trace = nullptr;
+extern "C" void m3d_wino44_set_trace(void *p) { g_w44_trace = (long long *)p; }
+#define W44_TRACE_INIT() long long *trp = (a.trace && (wave == 0 || wave == 3)) ? a.trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 + (wave ? 1 : 0)) * 64 : nullptr; int tri = 0
+#define W44_TRACE() do { if (trp && lane == 0 && tri < 64) trp[tri++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define W44_TRACE_INIT()
+#define W44_TRACE()
+#endif
+
+__device__ __forceinline__ void w44_load_dword(float &dst, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void w44_load_x4(f32x4 &dst, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+template <int N, int NB>
+__device__ __forceinline__ void w44_wait(f32x4 (&u)[2])
+{
+    // the registers are operands so that no use of them can be scheduled above the wait.  One operand per register set: naming
+    // the same variable twice makes the compiler COPY it for the second operand -- a copy of a register whose load is still in
+    // flight, written back over the landed value afterwards (this is what the single-block variant first did).
+    if constexpr (NB == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(u[0]), "+v"(u[1]) : "n"(N));
+    else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(u[0]) : "n"(N));
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void w44_static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        w44_static_for<I + 1, N>(f);
+    }
+}
+
+// y = B^T x for F(4x4,3x3): B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+__device__ __forceinline__ void w44_bt(const float x0, const float x1, const float x2, const float x3, const float x4, const float x5,
+                                       float &y0, float &y1, float &y2, float &y3, float &y4, float &y5)
+{
+    y0 = fmaf(4.f, x0, fmaf(-5.f, x2, x4));
+    const float a = fmaf(-4.f, x2, x4), b = fmaf(-4.f, x1, x3);
+    y1 = a + b;
+    y2 = a - b;
+    const float c = x4 - x2, e = x3 - x1;
+    y3 = fmaf(2.f, e, c);
+    y4 = fmaf(-2.f, e, c);
+    y5 = fmaf(4.f, x1, fmaf(-5.f, x3, x5));
+}
+// y = A^T m: A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+__device__ __forceinline__ void w44_at(const float m0, const float m1, const float m2, const float m3, const float m4, const float m5,
+                                       float &y0, float &y1, float &y2, float &y3)
+{
+    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+    y0 = m0 + s1 + s2;
+    y1 = fmaf(2.f, d2, d1);
+    y2 = fmaf(4.f, s2, s1);
+    y3 = fmaf(8.f, d2, d1) + m5;
+}
+
+// NB = 16-channel blocks per wave: 2 (workgroup = 128 output channels) or 1 (64 output channels: Cout = 64 layers, and layers
+// whose 16-tile strips x 128-channel blocks would leave CUs idle -- 256 -> 256 @ 24x80, bs 8: 120 workgroups become 240).
+template <int NB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino44_kernel(const Wino44Args a)
+{
+    __shared__ __attribute__((aligned(16))) float Vs[2 * 36 * 256];     // V[buf][xi][tile 16][channel 16]
+    __shared__ int pixb[16];                                             // first output pixel of each tile (-1: no such tile)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NS = a.Cin >> 4;
+    W44_TRACE_INIT();
+    W44_TRACE();
+
+    // ---- this thread's transform unit: tile ut of the strip, input channel uc of the stage ----------------------------------
+    const int ut = tid >> 4, uc = tid & 15;
+    unsigned vM[6], v0[6], v5[6];    // byte offsets of the patch rows at the tile's first pixel column: columns 1..4 / column 0
+                                     // (base one pixel to the left, out of range at the left image border) / column 5 (+ 4 pixels)
+    {
+        const int t = blockIdx.x * 16 + ut;
+        const bool tv = t < a.NT;
+        const int tt = tv ? t : 0;
+        const int n = tt / (a.TH * a.TW), rem = tt - n * a.TH * a.TW;
+        const int ty = rem / a.TW, tx = rem - ty * a.TW;
+        if (uc == 0) pixb[ut] = tv ? (n * a.H + 4 * ty) * a.W + 4 * tx : -1;
+        const bool c5ok = 4 * tx + 4 < a.W;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int hi = 4 * ty - 1 + r;
+            const bool ok = tv && hi >= 0 && hi < a.H;
+            const unsigned base = ((unsigned)((n * a.H + hi) * a.W + 4 * tx) * (unsigned)a.in_cs + (unsigned)uc) * 4u;
+            vM[r] = ok ? base : M3D_BUF_OOB;
+            v0[r] = (ok && tx > 0) ? base - (unsigned)a.in_cs * 4u : M3D_BUF_OOB;
+            v5[r] = (ok && c5ok) ? base : M3D_BUF_OOB;
+        }
+    }
+    const unsigned cs4 = (unsigned)a.in_cs * 4u;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
+    // B fragments of this wave's 16 * NB output channels: [32-channel block][stage][xi][j][lane][4]
+    const int cb16 = (blockIdx.y * 4 + wave) * NB;               // first 16-channel block of this wave
+    const int cb32 = cb16 >> 1, j0 = cb16 & 1;
+    const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.U + (size_t)cb32 * NS * (36 * 2 * 256), (unsigned)NS * (36u * 2u * 1024u));
+    const unsigned ulane = (unsigned)lane * 16u + (unsigned)j0 * 1024u;
+
+    float d[36];
+    auto load_patch = [&](int s) __attribute__((always_inline)) {
+        const unsigned so = (unsigned)s * 64u;                   // 16 channels per stage
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            w44_load_dword(d[r * 6 + 0], rin, v0[r], so);
+#pragma unroll
+            for (int c = 1; c < 5; ++c) w44_load_dword(d[r * 6 + c], rin, vM[r], so + (unsigned)(c - 1) * cs4);
+            w44_load_dword(d[r * 6 + 5], rin, v5[r], so + 4u * cs4);
+        }
+    };
+    // B^T d B of the patch in d[] -> V[buf][xi][ut][uc], in 12 pieces (6 columns of the first pass into tq[], 6 rows of the
+    // second pass + their 6 LDS writes): inside a stage the pieces ride between the MFMAs of positions 5..16 -- one wave per
+    // SIMD issues in order, a 16x16x4 MFMA occupies the matrix pipe for 32 cycles and the issue port for a fraction of that, so
+    // a dozen scalar FMAs per position fill slots that are otherwise empty (as a block after the 288 MFMAs the transform cost
+    // 1900 of every 14600 cycles with the matrix pipe idle, tools/wino44_trace.py)
+    float tq[36];
+    auto transform_col = [&](auto ctag) __attribute__((always_inline)) {
+        constexpr int c = decltype(ctag)::value;
+        w44_bt(d[0 * 6 + c], d[1 * 6 + c], d[2 * 6 + c], d[3 * 6 + c], d[4 * 6 + c], d[5 * 6 + c],
+               tq[0 * 6 + c], tq[1 * 6 + c], tq[2 * 6 + c], tq[3 * 6 + c], tq[4 * 6 + c], tq[5 * 6 + c]);
+    };
+    auto transform_row = [&](int buf, auto rtag) __attribute__((always_inline)) {
+        constexpr int r = decltype(rtag)::value;
+        float *vb = Vs + buf * (36 * 256) + ut * 16 + uc;
+        float v[6];
+        w44_bt(tq[r * 6 + 0], tq[r * 6 + 1], tq[r * 6 + 2], tq[r * 6 + 3], tq[r * 6 + 4], tq[r * 6 + 5], v[0], v[1], v[2], v[3], v[4], v[5]);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) vb[(r * 6 + c) * 256] = v[c];
+    };
+    auto transform_store = [&](int buf) __attribute__((always_inline)) {
+        transform_col(std::integral_constant<int, 0>{}); transform_col(std::integral_constant<int, 1>{});
+        transform_col(std::integral_constant<int, 2>{}); transform_col(std::integral_constant<int, 3>{});
+        transform_col(std::integral_constant<int, 4>{}); transform_col(std::integral_constant<int, 5>{});
+        transform_row(buf, std::integral_constant<int, 0>{}); transform_row(buf, std::integral_constant<int, 1>{});
+        transform_row(buf, std::integral_constant<int, 2>{}); transform_row(buf, std::integral_constant<int, 3>{});
+        transform_row(buf, std::integral_constant<int, 4>{}); transform_row(buf, std::integral_constant<int, 5>{});
+    };
+    auto tie_patch = [&]() __attribute__((always_inline)) {      // the loads have landed (vmcnt waits below); pin the registers
+        asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]), "+v"(d[8]),
+                          "+v"(d[9]), "+v"(d[10]), "+v"(d[11]), "+v"(d[12]), "+v"(d[13]), "+v"(d[14]), "+v"(d[15]), "+v"(d[16]), "+v"(d[17]));
+        asm volatile("" : "+v"(d[18]), "+v"(d[19]), "+v"(d[20]), "+v"(d[21]), "+v"(d[22]), "+v"(d[23]), "+v"(d[24]), "+v"(d[25]), "+v"(d[26]),
+                          "+v"(d[27]), "+v"(d[28]), "+v"(d[29]), "+v"(d[30]), "+v"(d[31]), "+v"(d[32]), "+v"(d[33]), "+v"(d[34]), "+v"(d[35]));
+    };
+
+    f32x4 Uf[4][2];              // ring of four register sets: one in use, three in flight
+    auto load_u = [&](int s, int xi, auto slot_tag) __attribute__((always_inline)) {
+        constexpr int SL = decltype(slot_tag)::value;
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((s * 36 + xi) * 2) * 1024u;
+        w44_load_x4(Uf[SL][0], ru, ulane, so);
+        if constexpr (NB == 2) w44_load_x4(Uf[SL][1], ru, ulane, so + 1024u);
+    };
+
+    // ---- prologue: stage 0's patch, transform, first B fragments, stage 1's patch ------------------------------------------
+    load_patch(0);
+    f32x4 acc[36][NB];
+#pragma unroll
+    for (int x = 0; x < 36; ++x)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[x][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tie_patch();
+    W44_TRACE();
+    transform_store(0);
+    W44_TRACE();
+    load_u(0, 0, std::integral_constant<int, 0>{});
+    load_u(0, 1, std::integral_constant<int, 1>{});
+    load_u(0, 2, std::integral_constant<int, 2>{});
+    load_u(0, 3, std::integral_constant<int, 3>{});
+    if (NS > 1) load_patch(1);
+    __syncthreads();
+    W44_TRACE();
+
+    const int atile = lane & 15, aq = lane >> 4;
+    // One stage: 36 positions x 8 MFMAs on V[buf].  Outstanding loads on entry, oldest first: B fragments of positions 0..3 (4 NB
+    // loads), then -- unless LAST -- the 36 patch loads of the next stage.  Behind position xi the fragments of xi + 4 go out (the
+    // next stage's first four behind positions 32..35): the loads younger than position xi's fragments number 3 NB, plus the 36
+    // patch loads while xi < 4; the patch has landed when position 4 starts.
+    auto stage = [&](int s, auto last_tag) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const float *vbuf = Vs + (s & 1) * (36 * 256) + atile * 16 + aq * 4;
+        f32x4 anext = *reinterpret_cast<const f32x4 *>(vbuf);
+        // (compile-time positions: a `#pragma unroll` loop of this size was left rolled once the transform pieces were added, which
+        // made acc[xi] a dynamically indexed array -- 288 accumulators in scratch memory)
+        w44_static_for<0, 36>([&](auto xtag) __attribute__((always_inline)) {
+            constexpr int xi = decltype(xtag)::value;
+            constexpr int nx = xi + W44_LA;
+            // loads younger than position xi's fragments when they are waited for: positions xi+1 .. xi+3 (NB loads each: slot
+            // xi % 4 holds position xi until its MFMAs are issued, the fragments of xi + 4 go out behind them), plus the 36 patch
+            // loads while xi < 4 (not LAST)
+            if constexpr (!LAST) {
+                if constexpr (xi < W44_LA) w44_wait<3 * NB + 36, NB>(Uf[xi % 4]);
+                else w44_wait<3 * NB, NB>(Uf[xi % 4]);
+            } else {
+                if constexpr (xi <= 32) w44_wait<3 * NB, NB>(Uf[xi % 4]);
+                else w44_wait<(35 - xi) * NB, NB>(Uf[xi % 4]);
+            }
+            // A operand: this position's was fetched during the previous position; the next one goes out before this position's
+            // MFMAs (left alone, the scheduler sinks the read to the last MFMA of the position)
+            const f32x4 av = anext;
+            if constexpr (xi + 1 < 36) anext = *reinterpret_cast<const f32x4 *>(vbuf + (xi + 1) * 256);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    acc[xi][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], Uf[xi % 4][j][e], acc[xi][j], 0, 0, 0);
+            if constexpr (!LAST) {
+                // the next stage's patch has landed since position 4 (vmcnt(3 NB) there covers everything older).  The pieces cost
+                // MFMA time where they sit (~10 cycles per VALU instruction: nothing hides under a SIMD's MFMA stream on this part,
+                // DESIGN.md) -- but they no longer cost a separate phase with its own latencies
+                if constexpr (xi == 4) tie_patch();
+                if constexpr (xi >= 5 && xi <= 10) transform_col(std::integral_constant<int, xi - 5>{});
+                if constexpr (xi >= 11 && xi <= 16) transform_row((s + 1) & 1, std::integral_constant<int, xi - 11>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // fragments of position xi + 4 (this stage) or of the next stage's position xi + 4 - 36.  (Issued BETWEEN the MFMAs
+            // of the position with a lookahead of 3 they measured the same for 32-channel waves and 10 % slower for 16-channel
+            // waves: the matrix pipe is not what waits.)
+            if constexpr (nx < 36) load_u(s, nx, std::integral_constant<int, nx % 4>{});
+            else if constexpr (!LAST) load_u(s + 1, nx - 36, std::integral_constant<int, nx % 4>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        W44_TRACE();
+        if constexpr (!LAST) {
+            if (s + 2 < NS) load_patch(s + 2);     // d[] is free: the transform of stage s + 1 finished behind position 16
+            __builtin_amdgcn_sched_barrier(0);
+            W44_TRACE();
+            __syncthreads();
+            W44_TRACE();
+        }
+    };
+    for (int s = 0; s + 1 < NS; ++s) stage(s, std::false_type{});
+    stage(NS - 1, std::true_type{});
+
+    // ---- A^T M A + epilogue in registers: lane = channel co0 + 16j + (lane & 15), tiles 4*(lane >> 4) + i --------------------
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out, a.out_bytes);
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res ? a.res : a.out, a.res ? a.res_bytes : 0u);
+    const unsigned ocs4 = (unsigned)a.out_cs * 4u, rcs4 = (unsigned)a.res_cs * 4u;
+    const int4 pb4 = *reinterpret_cast<const int4 *>(&pixb[4 * aq]);
+    const int pbv[4] = {pb4.x, pb4.y, pb4.z, pb4.w};
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int co = (cb16 + j) * 16 + atile;
+        const bool cok = co < a.Cout;
+        const float sc = (cok && a.scale) ? a.scale[co] : 1.f;
+        const float sh = (cok && a.shift) ? a.shift[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = cok && pbv[i] >= 0;
+            const unsigned ob = ok ? ((unsigned)pbv[i] * (unsigned)a.out_cs + (unsigned)co) * 4u : M3D_BUF_OOB;
+            const unsigned rb = (ok && a.res) ? ((unsigned)pbv[i] * (unsigned)a.res_cs + (unsigned)co) * 4u : M3D_BUF_OOB;
+            float rv[16];
+            if (a.res) {
+#pragma unroll
+                for (int yy = 0; yy < 4; ++yy)
+#pragma unroll
+                    for (int xx = 0; xx < 4; ++xx)
+                        rv[yy * 4 + xx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, rb, (unsigned)(yy * a.W + xx) * rcs4, 0));
+            }
+            float z[4][6];                         // A^T M: rows yy, columns b
+#pragma unroll
+            for (int b = 0; b < 6; ++b)
+                w44_at(acc[0 * 6 + b][j][i], acc[1 * 6 + b][j][i], acc[2 * 6 + b][j][i], acc[3 * 6 + b][j][i], acc[4 * 6 + b][j][i],
+                       acc[5 * 6 + b][j][i], z[0][b], z[1][b], z[2][b], z[3][b]);
+#pragma unroll
+            for (int yy = 0; yy < 4; ++yy) {
+                float y[4];
+                w44_at(z[yy][0], z[yy][1], z[yy][2], z[yy][3], z[yy][4], z[yy][5], y[0], y[1], y[2], y[3]);
+#pragma unroll
+                for (int xx = 0; xx < 4; ++xx) {
+                    float v = y[xx];
+                    if (a.res) {
+                        if (a.res_mode) v = fmaf(v + rv[yy * 4 + xx], sc, sh);
+                        else v = fmaf(v, sc, sh) + rv[yy * 4 + xx];
+                    } else {
+                        v = fmaf(v, sc, sh);
+                    }
+                    if (a.act == 1) v = fmaxf(v, v * M3D_LEAKY_SLOPE);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, ob, (unsigned)(yy * a.W + xx) * ocs4, 0);
+                }
+            }
+        }
+    }
+    W44_TRACE();
+}
+
+// 1 if the F(4x4,3x3) kernel serves the descriptor (geometry only; the caller passes U44-packed weights in d->wgt)
+extern "C" int m3d_wino44_applicable(const m3d_conv_desc *d)
+{
+    if (!d || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->dil > 1) return 0;
+    if (d->dcn_offmask || d->out_nchw || d->wgt_img_stride || d->sigmoid_from >= 0) return 0;
+    if (d->H % 4 || d->W % 4 || d->Cin % 16 || d->Cout_pad % 64 || d->in_cs % 4) return 0;
+    return 1;
+}
+
+extern "C" int m3d_wino44_conv3x3_forward_ex(const m3d_conv_desc *d, int nb, m3d_stream_t stream)
+{
+    M3D_REQUIRE(d && d->in && d->wgt && d->out, "wino44: null pointer");
+    M3D_REQUIRE(m3d_wino44_applicable(d), "wino44: 3x3 / stride 1 / pad 1, H %% 4 == W %% 4 == 0, Cin %% 16 == 0, Cout_pad %% 64 == 0 only");
+    M3D_REQUIRE(d->Ho == d->H && d->Wo == d->W, "wino44: Ho/Wo mismatch");
+    Wino44Args a;
+    a.in = d->in; a.U = d->wgt; a.out = d->out; a.scale = d->scale; a.shift = d->shift; a.res = d->res;
+    a.in_cs = d->in_cs; a.out_cs = d->out_cs; a.res_cs = d->res_cs;
+    const long long pix = (long long)d->N * d->H * d->W;
+    M3D_REQUIRE(pix * d->in_cs * 4 < (1ll << 31) && pix * d->out_cs * 4 < (1ll << 31), "wino44: views must be < 2 GiB");
+    a.in_bytes = (unsigned)(pix * d->in_cs * 4);
+    a.out_bytes = (unsigned)(pix * d->out_cs * 4);
+    a.res_bytes = d->res ? (unsigned)(pix * d->res_cs * 4) : 0u;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
+    a.TH = d->H / 4; a.TW = d->W / 4; a.NT = d->N * a.TH * a.TW;
+    a.act = d->act; a.res_mode = d->res_mode;
+#ifdef WINO_TRACE
+    a.trace = g_w44_trace;
+#endif
+    // 128-channel workgroups (2 blocks of 16 per wave) where they fill the chip, else 64-channel workgroups
+    const int strips = cdiv(a.NT, 16);
+    M3D_REQUIRE(nb >= 0 && nb <= 2 && !(nb == 2 && d->Cout_pad % 128), "wino44: nb = 0 (automatic), 1 or 2 (needs Cout_pad %% 128 == 0)");
+    const bool nb2 = d->Cout_pad % 128 == 0 && (nb == 2 || (nb == 0 && (long long)strips * (d->Cout_pad / 128) >= 200));
+    if (nb2) hipLaunchKernelGGL(wino44_kernel<2>, dim3(strips, d->Cout_pad / 128), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(wino44_kernel<1>, dim3(strips, d->Cout_pad / 64), dim3(256), 0, (hipStream_t)stream, a);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+extern "C" int m3d_wino44_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t stream)
+{
+    return m3d_wino44_conv3x3_forward_ex(d, 0, stream);
+}

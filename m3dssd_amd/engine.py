@@ -82,8 +82,18 @@ class PackedConv:
         self._eng_device = eng.device
         self._frag = None
         self.wino = None
+        self._w_cpu = None
         if USE_WINO and self.kh == 3 and self.kw == 3 and self.cin_pad == self.cin and self.cin % 16 == 0 and self.cin >= 32:
             self.wino = pack_wino(w, self.cout_pad, eng.device)
+            if USE_WINO44 and self.cout_pad % 64 == 0:
+                self._w_cpu = w.detach().cpu()            # F(4x4,3x3) weights are packed on first use (wino44())
+        self._wino44 = None
+
+    def wino44(self):
+        """U = G g G^T of Winograd F(4x4,3x3) in the fragment order of m3d_wino44_conv3x3_forward, or None."""
+        if self._wino44 is None and self._w_cpu is not None:
+            self._wino44 = pack_wino44(self._w_cpu, self.cout_pad, self._eng_device)
+        return self._wino44
 
 
     def frag(self):
@@ -120,12 +130,37 @@ def pack_wino(weight, cout_pad, device):
     return u.to(torch.float32).reshape(-1).to(device)
 
 
+_WINO44_G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
+                          [0, 0, 1]], dtype=torch.float64)
+
+
+def pack_wino44(weight, cout_pad, device):
+    """[Cout, Cin, 3, 3] -> Winograd F(4x4,3x3) weights U = G g G^T (6 x 6 per filter, computed in fp64, rounded once to fp32) in
+    the B-fragment order of v_mfma_f32_16x16x4_f32 for m3d_wino44_conv3x3_forward: [Cout_pad/32][Cin/16][36 xi][j 2][lane 64][e 4]
+    with value U[xi][cin = 16 s + 4 (lane >> 4) + e][cout = 32 cb + 16 j + (lane & 15)]."""
+    g = weight.detach().to("cpu", torch.float64)
+    co, ci = g.shape[0], g.shape[1]
+    assert g.shape[2:] == (3, 3) and ci % 16 == 0 and cout_pad % 32 == 0 and cout_pad >= co
+    u = torch.einsum("ai,ocij,bj->aboc", _WINO44_G, g, _WINO44_G).reshape(36, co, ci)
+    if cout_pad != co:
+        u = torch.cat([u, u.new_zeros(36, cout_pad - co, ci)], 1)
+    # [xi][cb][j][n16][s][q][e] -> [cb][s][xi][j][q][n16][e]   (lane = q * 16 + n16)
+    u = u.view(36, cout_pad // 32, 2, 16, ci // 16, 4, 4).permute(1, 4, 0, 2, 5, 3, 6).contiguous()
+    return u.to(torch.float32).reshape(-1).to(device)
+
+
 WINO_MIN_BLOCKS = int(os.environ.get("M3D_WINO_MIN_BLOCKS", "128"))
 USE_ANAB_WAVE = os.environ.get("M3D_ANAB_WAVE", "1") != "0"
 USE_ANAB_NESTED = os.environ.get("M3D_ANAB_NESTED", "1") != "0"
 USE_DCN_WAVE = os.environ.get("M3D_DCN_WAVE", "1") != "0"
 USE_CONV_WAVE = os.environ.get("M3D_CONV_WAVE", "1") != "0"
 USE_WINO = os.environ.get("M3D_WINO", "1") != "0"
+USE_WINO44 = os.environ.get("M3D_WINO44", "1") != "0"
+# F(4x4,3x3) workgroups (16 tiles x 128 or 64 channels, one per CU, 256 CUs): 128-channel workgroups need >= 200 of them; the
+# 64-channel form (half the MFMAs per transformed input) pays from ~2 rounds on: in the network, bs 8, level2 (64 -> 64 @ 96x320,
+# 960 workgroups) gains 10 %, level4 (256 -> 256 @ 24x80, 240 workgroups) loses 5 % against the F(2x2,3x3) wave kernel
+WINO44_MIN_WGS = int(os.environ.get("M3D_WINO44_MIN_WGS", "200"))
+WINO44_MIN_WGS_NB1 = int(os.environ.get("M3D_WINO44_MIN_WGS_NB1", "400"))
 
 
 class _Plan:
@@ -322,6 +357,20 @@ class Engine:
         # the Winograd kernel works on 256-pixel x 32-channel tiles: a narrow layer (the 27-channel DCN offset/mask
         # convs) on a small map yields < 128 workgroups and goes to the split-K igemm instead
         wino_blocks = -(-(x.n * x.h * x.w) // 256) * (d.Cout_pad // 32)
+        strips = -(-(x.n * x.h * x.w) // 256)
+        nb = 2 if (d.Cout_pad % 128 == 0 and strips * (d.Cout_pad // 128) >= WINO44_MIN_WGS) else \
+            (1 if strips * (d.Cout_pad // 64) >= WINO44_MIN_WGS_NB1 else 0)
+        if (pc is not None and wgt_ptr is None and getattr(pc, "_w_cpu", None) is not None and om is None and planar is None
+                and sigmoid_from < 0 and L.m3d_wino44_applicable(ref) == 1 and nb):
+            # Winograd F(4x4,3x3): 4x fewer MFMA FLOPs than the direct convolution (F(2x2,3x3): 2.25x) where the layer fills the
+            # chip with 16-tile workgroups (csrc/wino44_conv.hip)
+            u44 = pc.wino44()
+            plan.keep.append(u44)
+            d.wgt = u44.data_ptr()
+            flops = 2.0 * x.n * d.Ho * d.Wo * d.Cout * 9 * pc.cin
+            plan.ops.append((name, "wino44<16,%d>" % (16 * nb), flops,
+                             lambda st: _hip.check(L.m3d_wino44_conv3x3_forward_ex(ref, nb, st)), d))
+            return
         if (pc is not None and wgt_ptr is None and getattr(pc, "wino", None) is not None and kh == 3 and kw == 3
                 and stride == 1 and pad == 1 and om is None and planar is None and x.h % 2 == 0 and x.w % 2 == 0
                 and wino_blocks >= WINO_MIN_BLOCKS):

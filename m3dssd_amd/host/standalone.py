@@ -47,11 +47,15 @@ def _affine(co, bias, bn, dev):
 
 
 def conv_nhwc(v, weight, bias=None, bn=None, stride=1, pad=0, act=0, res=None, res_mode=0, sigmoid_from=-1, om=None,
-              cout_pad_to=32, out_cs_to=4, wino=False, splitk=True, wino_variant=-1, wino_splitk=False):
+              cout_pad_to=32, out_cs_to=4, wino=False, splitk=True, wino_variant=-1, wino_splitk=False, wino44=False, wino44_nb=0):
     """One m3d_conv2d_forward (or, with wino=True, m3d_wino_conv3x3_forward) launch on an NHWC view;
     returns (View, keepalive)."""
-    wp, co, cop, kh, kw = _pack(weight, v.c, cout_pad_to)
-    if wino:
+    wp, co, cop, kh, kw = _pack(weight, v.c, (128 if wino44_nb == 2 else 64) if wino44 else cout_pad_to)
+    if wino44:
+        from ..engine import pack_wino44
+        assert weight.shape[1] == v.c, "wino44 path: no channel padding"
+        wp = pack_wino44(weight, cop, v.t.device)
+    elif wino:
         from ..engine import pack_wino
         assert weight.shape[1] == v.c, "wino path: no channel padding"
         wp = pack_wino(weight, cop, v.t.device)
@@ -73,6 +77,9 @@ def conv_nhwc(v, weight, bias=None, bn=None, stride=1, pad=0, act=0, res=None, r
     if om is not None:
         d.dcn_offmask, d.dcn_om_cs = om.ptr, om.cs
     ws = None
+    if wino44:
+        _hip.check(_hip.lib().m3d_wino44_conv3x3_forward_ex(ctypes.byref(d), wino44_nb, _stream()))
+        return out, (wp, scale, shift, None)
     if not wino:                               # small-M layers: give the igemm its split-K scratch
         splits, ws_bytes = ctypes.c_int(), ctypes.c_longlong()
         _hip.check(_hip.lib().m3d_conv2d_splitk_plan(ctypes.byref(d), ctypes.byref(splits), ctypes.byref(ws_bytes)))

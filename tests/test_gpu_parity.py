@@ -884,8 +884,8 @@ def test_full_size_batch8_uses_wave_kernels_and_matches_batch1():
         kinds8 = {op[1] for op in net.engine().plan_for(8, 384, 1280).ops}
         one = [t.clone() for t in net(x[5:6])[:4]]
         kinds1 = {op[1] for op in net.engine().plan_for(1, 384, 1280).ops}
-    assert "wino_wave<32,32>" in kinds8 and any(k.startswith("conv_wave") for k in kinds8)
-    assert "wino_wave<32,32>" not in kinds1
+    assert any(k.startswith("wino44") for k in kinds8) and any(k.startswith("conv_wave") for k in kinds8)
+    assert "wino_wave<32,32>" not in kinds1 and "wino44<16,32>" not in kinds1
     for name, u, s_, tol in zip(("cls", "prob", "bbox_2d", "bbox_3d"), full, one, (1e-3, 1e-4, 1e-3, 1e-3)):
         err = (u[5:6] - s_).abs().max().item()
         assert err < tol, (name, err)

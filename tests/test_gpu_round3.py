@@ -285,3 +285,68 @@ def test_bf16_forward_is_bit_identical_over_40_runs_at_batch_64():
     bad, nbuf, kinds = _soak("bf16", 64, (384, 1280), 40)
     assert {"bf16_halo", "bf16_conv", "bf16_head_mlp", "bf16_frontend", "bf16_anab", "bf16_dcn_patch"} <= kinds, kinds
     assert not bad, bad[:3]
+
+
+# ------------------------------------------------------------------------------------ Winograd F(4x4,3x3)
+WINO44_CASES = [
+    # n, cin, h, w, cout, bias, bn, act, res
+    (1, 16, 4, 4, 128, False, False, 0, False),          # one tile, one stage: every patch border is an image border
+    (2, 32, 8, 12, 128, True, False, 1, False),          # 12 tiles: ragged 16-tile strip, strips crossing image rows
+    (1, 128, 16, 40, 128, True, True, 1, True),          # level3 geometry (scaled): BN + residual + LeakyReLU
+    (2, 64, 12, 20, 256, True, True, 1, False),          # two channel blocks of 128
+    (1, 48, 20, 36, 100, True, True, 0, True),           # Cout 100 (pad 128), three stages
+    (3, 128, 48, 160, 128, False, True, 1, True),        # full-size level3 map, 3 images
+]
+
+
+@pytest.mark.parametrize("nb", [1, 2])
+@pytest.mark.parametrize("case", WINO44_CASES + [(2, 64, 24, 32, 64, True, True, 1, True), (1, 32, 8, 8, 40, True, False, 0, False)])
+def test_winograd_f4x4_conv3x3_matches_torch(case, nb):
+    """m3d_wino44_conv3x3_forward (Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32, csrc/wino44_conv.hip) vs F.conv2d, same
+    epilogue contract as the F(2x2,3x3) kernels.  Tolerance 2e-4 (1 + |ref|) like every fp32 conv here; the measured error is
+    logged next to that of the F(2x2,3x3) wave kernel on the same operands (F(4x4) amplifies fp32 rounding ~7x)."""
+    import torch.nn.functional as F
+    from m3dssd_amd.host import standalone as S
+    dev = _dev()
+    n, ci, h, w, co, bias, bn, act, res = case
+    if nb == 2 and co <= 64:
+        nb = 1                                              # 64-channel layers: one 16-channel block per wave only
+    g = torch.Generator().manual_seed(sum(case) + 11)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5
+    b = torch.randn(co, generator=g) if bias else None
+    ref = F.conv2d(x.double(), wt.double(), None if b is None else b.double(), padding=1)
+    bnm = None
+    if bn:
+        bnm = torch.nn.BatchNorm2d(co).eval()
+        with torch.no_grad():
+            bnm.weight.uniform_(0.5, 1.5, generator=g)
+            bnm.bias.normal_(0, 0.2, generator=g)
+            bnm.running_mean.normal_(0, 0.2, generator=g)
+            bnm.running_var.uniform_(0.5, 1.5, generator=g)
+        ref = bnm.double()(ref)
+        bnm = bnm.float()
+    r = None
+    if res:
+        r = torch.randn(n, co, h, w, generator=g)
+        ref = ref + r.double()
+    if act:
+        ref = F.leaky_relu(ref, 0.01)
+    ref = ref.float()
+    errs = {}
+    for kind in ("wino44", "wino22"):
+        if kind == "wino22" and (h % 2 or w % 2):
+            continue
+        with torch.no_grad():
+            v, _ = S._to_nhwc(x.to(dev))
+            rv = S._to_nhwc(r.to(dev))[0] if res else None
+            out, keep = S.conv_nhwc(v, wt.to(dev), None if b is None else b.to(dev), None if bnm is None else bnm.to(dev), 1, 1,
+                                    act=act, res=rv, wino44=(kind == "wino44"), wino44_nb=nb, wino=(kind == "wino22"), wino_variant=1)
+            got = S._to_nchw(out, co).cpu()
+        assert got.shape == ref.shape
+        errs[kind] = ((got - ref).abs() / (1 + ref.abs())).max().item()
+    d = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "parity_r02.jsonl"), "a") as f:
+            f.write(json.dumps({"test": "wino44", "case": list(case), "nb": nb, **errs}) + "\n")
+    assert errs["wino44"] < 2e-4, errs

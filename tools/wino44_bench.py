@@ -1,0 +1,47 @@
+"""Single-layer timing of the fp32 3x3 stride-1 convolutions at bs 8: Winograd F(4x4,3x3) (csrc/wino44_conv.hip) against the
+F(2x2,3x3) wave kernel, with the error of both against a float64 reference.   python tools/wino44_bench.py"""
+import ctypes
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, ".")
+from m3dssd_amd import _hip                                   # noqa: E402
+from m3dssd_amd.engine import pack_wino, pack_wino44          # noqa: E402
+
+dev = torch.device("cuda:0")
+L = _hip.lib()
+st = torch.cuda.current_stream().cuda_stream
+SHAPES = [(128, 128, 48, 160, 8), (128, 256, 48, 160, 8), (256, 256, 24, 80, 8), (64, 64, 96, 320, 8), (512, 512, 12, 40, 8)]
+for cin, cout, H, W, B in SHAPES:
+    g = torch.Generator().manual_seed(cin + H)
+    xf = torch.randn(B, cin, H, W, generator=g)
+    wf = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    x = xf.permute(0, 2, 3, 1).contiguous().to(dev)
+    ref = F.conv2d(xf[:1].double(), wf.double(), padding=1).float().permute(0, 2, 3, 1)
+    fl = 2.0 * B * H * W * cout * 9 * cin
+    line = "%3d->%3d %3dx%3d bs%d:" % (cin, cout, H, W, B)
+    for kind in ("F(2x2)", "F(4x4)"):
+        U = (pack_wino if kind == "F(2x2)" else pack_wino44)(wf, cout, dev)
+        out = torch.zeros(B, H, W, cout, device=dev)
+        d = _hip.ConvDesc()
+        d.inp, d.in_cs, d.N, d.H, d.W, d.Cin = x.data_ptr(), cin, B, H, W, cin
+        d.wgt, d.Cout, d.Cout_pad = U.data_ptr(), cout, cout
+        d.kh = d.kw = 3
+        d.stride, d.pad, d.dil, d.Ho, d.Wo = 1, 1, 1, H, W
+        d.out, d.out_cs, d.act, d.sigmoid_from = out.data_ptr(), cout, 0, -1
+        fn = (lambda: L.m3d_wino_conv3x3_forward_ex(ctypes.byref(d), 1, st)) if kind == "F(2x2)" else \
+            (lambda: L.m3d_wino44_conv3x3_forward(ctypes.byref(d), st))
+        for _ in range(3):
+            _hip.check(fn())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        err = ((out[:1].cpu() - ref).abs() / (1 + ref.abs())).max().item()
+        line += "  %s %.4f ms (%.0f direct-equivalent TFLOP/s, err %.1e)" % (kind, ms, fl / ms / 1e9, err)
+    print(line, flush=True)
