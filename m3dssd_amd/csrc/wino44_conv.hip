@@ -91,15 +91,16 @@ __device__ __forceinline__ void w44_bt(const float x0, const float x1, const flo
     y4 = fmaf(-2.f, e, c);
     y5 = fmaf(4.f, x1, fmaf(-5.f, x3, x5));
 }
-// y = A^T m: A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
-__device__ __forceinline__ void w44_at(const float m0, const float m1, const float m2, const float m3, const float m4, const float m5,
-                                       float &y0, float &y1, float &y2, float &y3)
+// y = A^T m: A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]; on f32x4 = the four tiles of a lane at once (four
+// independent chains per instruction: the epilogue runs with one wave per SIMD and nothing else to hide a dependent add behind)
+__device__ __forceinline__ void w44_at(const f32x4 m0, const f32x4 m1, const f32x4 m2, const f32x4 m3, const f32x4 m4, const f32x4 m5,
+                                       f32x4 &y0, f32x4 &y1, f32x4 &y2, f32x4 &y3)
 {
-    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+    const f32x4 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
     y0 = m0 + s1 + s2;
-    y1 = fmaf(2.f, d2, d1);
-    y2 = fmaf(4.f, s2, s1);
-    y3 = fmaf(8.f, d2, d1) + m5;
+    y1 = d2 * 2.f + d1;
+    y2 = s2 * 4.f + s1;
+    y3 = d2 * 8.f + d1 + m5;
 }
 
 // NB = 16-channel blocks per wave: 2 (workgroup = 128 output channels) or 1 (64 output channels: Cout = 64 layers, and layers
@@ -156,22 +157,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             w44_load_dword(d[r * 6 + 5], rin, v5[r], so + 4u * cs4);
         }
     };
-    // B^T d B of the patch in d[] -> V[buf][xi][ut][uc], in 12 pieces (6 columns of the first pass into tq[], 6 rows of the
+    auto load_patch_one = [&](int s, auto qtag) __attribute__((always_inline)) {
+        constexpr int q = decltype(qtag)::value, r = q / 6, c = q % 6;
+        const unsigned so = (unsigned)s * 64u;
+        if constexpr (c == 0) w44_load_dword(d[q], rin, v0[r], so);
+        else if constexpr (c == 5) w44_load_dword(d[q], rin, v5[r], so + 4u * cs4);
+        else w44_load_dword(d[q], rin, vM[r], so + (unsigned)(c - 1) * cs4);
+    };
+    // B^T d B of the patch in d[] -> V[buf][xi][ut][uc], in 12 pieces (6 columns of the first pass, in place, 6 rows of the
     // second pass + their 6 LDS writes): inside a stage the pieces ride between the MFMAs of positions 5..16 -- one wave per
     // SIMD issues in order, a 16x16x4 MFMA occupies the matrix pipe for 32 cycles and the issue port for a fraction of that, so
     // a dozen scalar FMAs per position fill slots that are otherwise empty (as a block after the 288 MFMAs the transform cost
     // 1900 of every 14600 cycles with the matrix pipe idle, tools/wino44_trace.py)
-    float tq[36];
-    auto transform_col = [&](auto ctag) __attribute__((always_inline)) {
+    auto transform_col = [&](auto ctag) __attribute__((always_inline)) {       // first pass IN PLACE: d[] doubles as the temporary
         constexpr int c = decltype(ctag)::value;
-        w44_bt(d[0 * 6 + c], d[1 * 6 + c], d[2 * 6 + c], d[3 * 6 + c], d[4 * 6 + c], d[5 * 6 + c],
-               tq[0 * 6 + c], tq[1 * 6 + c], tq[2 * 6 + c], tq[3 * 6 + c], tq[4 * 6 + c], tq[5 * 6 + c]);
+        float t0, t1, t2, t3, t4, t5;
+        w44_bt(d[0 * 6 + c], d[1 * 6 + c], d[2 * 6 + c], d[3 * 6 + c], d[4 * 6 + c], d[5 * 6 + c], t0, t1, t2, t3, t4, t5);
+        d[0 * 6 + c] = t0; d[1 * 6 + c] = t1; d[2 * 6 + c] = t2; d[3 * 6 + c] = t3; d[4 * 6 + c] = t4; d[5 * 6 + c] = t5;
     };
     auto transform_row = [&](int buf, auto rtag) __attribute__((always_inline)) {
         constexpr int r = decltype(rtag)::value;
         float *vb = Vs + buf * (36 * 256) + ut * 16 + uc;
         float v[6];
-        w44_bt(tq[r * 6 + 0], tq[r * 6 + 1], tq[r * 6 + 2], tq[r * 6 + 3], tq[r * 6 + 4], tq[r * 6 + 5], v[0], v[1], v[2], v[3], v[4], v[5]);
+        w44_bt(d[r * 6 + 0], d[r * 6 + 1], d[r * 6 + 2], d[r * 6 + 3], d[r * 6 + 4], d[r * 6 + 5], v[0], v[1], v[2], v[3], v[4], v[5]);
 #pragma unroll
         for (int c = 0; c < 6; ++c) vb[(r * 6 + c) * 256] = v[c];
     };
@@ -210,21 +218,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     W44_TRACE();
     transform_store(0);
     W44_TRACE();
+    // INTERLEAVE (16-channel waves): the patch loads of stage s + 2 ride inside stage s.  With 32-channel waves (288 accumulators of
+    // the 512 registers) that variant made the compiler spill, and a spill is a vector memory instruction in the middle of the
+    // hand-counted vmcnt sequence (wrong fragments): there the 36 loads stay a block at the end of the stage.
+    constexpr bool INTERLEAVE = NB == 1;
+    if (INTERLEAVE && NS > 1) load_patch(1);          // older than the first fragments: the steady-state order of a stage entry
     load_u(0, 0, std::integral_constant<int, 0>{});
     load_u(0, 1, std::integral_constant<int, 1>{});
     load_u(0, 2, std::integral_constant<int, 2>{});
     load_u(0, 3, std::integral_constant<int, 3>{});
-    if (NS > 1) load_patch(1);
+    if (!INTERLEAVE && NS > 1) load_patch(1);
     __syncthreads();
     W44_TRACE();
 
     const int atile = lane & 15, aq = lane >> 4;
-    // One stage: 36 positions x 8 MFMAs on V[buf].  Outstanding loads on entry, oldest first: B fragments of positions 0..3 (4 NB
-    // loads), then -- unless LAST -- the 36 patch loads of the next stage.  Behind position xi the fragments of xi + 4 go out (the
-    // next stage's first four behind positions 32..35): the loads younger than position xi's fragments number 3 NB, plus the 36
-    // patch loads while xi < 4; the patch has landed when position 4 starts.
-    auto stage = [&](int s, auto last_tag) __attribute__((always_inline)) {
-        constexpr bool LAST = decltype(last_tag)::value;
+    // One stage: 36 positions x 8 MFMAs on V[buf].  Outstanding loads on entry, oldest first: the 36 patch loads of the next stage
+    // (unless LAST), then the B fragments of positions 0..3 (4 NB loads).  Behind position xi the fragments of xi + 4 go out (the
+    // next stage's first four behind positions 32..35), and -- ISSUE: there is a stage s + 2 -- behind positions 17..28 three of the
+    // 36 patch loads of stage s + 2 each (d[] is free once the first transform pass has read it, position 10, and the second pass
+    // has released its temporaries, position 16 -- earlier the two together spill; issued as a block at the end of the stage the
+    // loads cost ~1000 of its ~12700 cycles with the matrix pipe idle).  Loads younger than position xi's fragments when they are
+    // waited for: 3 NB fragment loads + 3 per position of [xi-4, xi-1] that lies in [17, 28].
+    auto stage = [&](int s, auto last_tag, auto issue_tag) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value, ISSUE = decltype(issue_tag)::value;
         const float *vbuf = Vs + (s & 1) * (36 * 256) + atile * 16 + aq * 4;
         f32x4 anext = *reinterpret_cast<const f32x4 *>(vbuf);
         // (compile-time positions: a `#pragma unroll` loop of this size was left rolled once the transform pieces were added, which
@@ -232,16 +248,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         w44_static_for<0, 36>([&](auto xtag) __attribute__((always_inline)) {
             constexpr int xi = decltype(xtag)::value;
             constexpr int nx = xi + W44_LA;
-            // loads younger than position xi's fragments when they are waited for: positions xi+1 .. xi+3 (NB loads each: slot
-            // xi % 4 holds position xi until its MFMAs are issued, the fragments of xi + 4 go out behind them), plus the 36 patch
-            // loads while xi < 4 (not LAST)
-            if constexpr (!LAST) {
-                if constexpr (xi < W44_LA) w44_wait<3 * NB + 36, NB>(Uf[xi % 4]);
-                else w44_wait<3 * NB, NB>(Uf[xi % 4]);
-            } else {
-                if constexpr (xi <= 32) w44_wait<3 * NB, NB>(Uf[xi % 4]);
-                else w44_wait<(35 - xi) * NB, NB>(Uf[xi % 4]);
-            }
+            // slot xi % 4 holds position xi until its MFMAs are issued; the fragments of xi + 4 go out behind them
+            constexpr int plo = xi - 4 > 17 ? xi - 4 : 17, phi = xi - 1 < 28 ? xi - 1 : 28;
+            constexpr int pyoung = !INTERLEAVE ? (xi < W44_LA ? 36 : 0)                  // block issue: the next stage's patch sits
+                                               : ((ISSUE && phi >= plo) ? 3 * (phi - plo + 1) : 0);   // behind the first fragments
+            if constexpr (!LAST) w44_wait<3 * NB + pyoung, NB>(Uf[xi % 4]);
+            else if constexpr (xi <= 32) w44_wait<3 * NB, NB>(Uf[xi % 4]);
+            else w44_wait<(35 - xi) * NB, NB>(Uf[xi % 4]);
             // A operand: this position's was fetched during the previous position; the next one goes out before this position's
             // MFMAs (left alone, the scheduler sinks the read to the last MFMA of the position)
             const f32x4 av = anext;
@@ -253,7 +266,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int j = 0; j < NB; ++j)
                     acc[xi][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], Uf[xi % 4][j][e], acc[xi][j], 0, 0, 0);
             if constexpr (!LAST) {
-                // the next stage's patch has landed since position 4 (vmcnt(3 NB) there covers everything older).  The pieces cost
+                // the next stage's patch has landed by position 4 in either issue order.  The pieces cost
                 // MFMA time where they sit (~10 cycles per VALU instruction: nothing hides under a SIMD's MFMA stream on this part,
                 // DESIGN.md) -- but they no longer cost a separate phase with its own latencies
                 if constexpr (xi == 4) tie_patch();
@@ -266,65 +279,127 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // waves: the matrix pipe is not what waits.)
             if constexpr (nx < 36) load_u(s, nx, std::integral_constant<int, nx % 4>{});
             else if constexpr (!LAST) load_u(s + 1, nx - 36, std::integral_constant<int, nx % 4>{});
+            if constexpr (INTERLEAVE && ISSUE && xi >= 17 && xi <= 28) {
+                load_patch_one(s + 2, std::integral_constant<int, 3 * (xi - 17)>{});
+                load_patch_one(s + 2, std::integral_constant<int, 3 * (xi - 17) + 1>{});
+                load_patch_one(s + 2, std::integral_constant<int, 3 * (xi - 17) + 2>{});
+            }
             __builtin_amdgcn_sched_barrier(0);
         });
         W44_TRACE();
         if constexpr (!LAST) {
-            if (s + 2 < NS) load_patch(s + 2);     // d[] is free: the transform of stage s + 1 finished behind position 16
+            if constexpr (!INTERLEAVE) { if (s + 2 < NS) load_patch(s + 2); }
             __builtin_amdgcn_sched_barrier(0);
             W44_TRACE();
             __syncthreads();
             W44_TRACE();
         }
     };
-    for (int s = 0; s + 1 < NS; ++s) stage(s, std::false_type{});
-    stage(NS - 1, std::true_type{});
+    if constexpr (INTERLEAVE) {
+        for (int s = 0; s + 2 < NS; ++s) stage(s, std::false_type{}, std::true_type{});
+        if (NS > 1) stage(NS - 2, std::false_type{}, std::false_type{});
+    } else {
+        for (int s = 0; s + 1 < NS; ++s) stage(s, std::false_type{}, std::false_type{});
+    }
+    stage(NS - 1, std::true_type{}, std::false_type{});
 
-    // ---- A^T M A + epilogue in registers: lane = channel co0 + 16j + (lane & 15), tiles 4*(lane >> 4) + i --------------------
+    // ---- A^T M A in registers (lane = channel co0 + 16 j + (lane & 15), tiles 4 (lane >> 4) + i), then through the wave's slice
+    // of the (now free) V buffers so that the stores are 16 bytes per lane: a lane holds ONE channel of 4 tiles x 16 pixels -- written
+    // out directly that is 128 four-byte stores per lane, 64 bytes contiguous per pixel, and took 18000 of the workgroup's 131000
+    // cycles (tools/wino44_trace.py).  Per 16-channel block: [16 tiles][16 pixels + pad][16 channels] in LDS (tile stride 272
+    // floats: the four tile groups of a store instruction land in different banks), read back as (tile k, pixel lane >> 2,
+    // channel quad lane & 3): 1 KB contiguous per read, 16 bytes per lane per store, residual fetched in the same shape.
+    __syncthreads();                                  // every wave is done with the last stage's V
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out, a.out_bytes);
     const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res ? a.res : a.out, a.res ? a.res_bytes : 0u);
-    const unsigned ocs4 = (unsigned)a.out_cs * 4u, rcs4 = (unsigned)a.res_cs * 4u;
-    const int4 pb4 = *reinterpret_cast<const int4 *>(&pixb[4 * aq]);
-    const int pbv[4] = {pb4.x, pb4.y, pb4.z, pb4.w};
+    float *ot = Vs + wave * (16 * 272);               // this wave's slice: 17 KB of the 72 KB
+    const int opx = lane >> 2, ocq = lane & 3;        // read-back role: pixel of the 4x4 tile, channel quad
+    const unsigned pixoff = (unsigned)((opx >> 2) * a.W + (opx & 3));
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const int co = (cb16 + j) * 16 + atile;
-        const bool cok = co < a.Cout;
-        const float sc = (cok && a.scale) ? a.scale[co] : 1.f;
-        const float sh = (cok && a.shift) ? a.shift[co] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool ok = cok && pbv[i] >= 0;
-            const unsigned ob = ok ? ((unsigned)pbv[i] * (unsigned)a.out_cs + (unsigned)co) * 4u : M3D_BUF_OOB;
-            const unsigned rb = (ok && a.res) ? ((unsigned)pbv[i] * (unsigned)a.res_cs + (unsigned)co) * 4u : M3D_BUF_OOB;
-            float rv[16];
-            if (a.res) {
-#pragma unroll
-                for (int yy = 0; yy < 4; ++yy)
-#pragma unroll
-                    for (int xx = 0; xx < 4; ++xx)
-                        rv[yy * 4 + xx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, rb, (unsigned)(yy * a.W + xx) * rcs4, 0));
-            }
-            float z[4][6];                         // A^T M: rows yy, columns b
+        // the residual of the whole block is fetched in one go (16 loads in flight under the second transform pass; fetched inside
+        // the store loop every iteration waited out its own memory round trip)
+        const int c0 = (cb16 + j) * 16 + ocq * 4;     // first of this lane's four channels
+        const bool blockfull = (cb16 + j) * 16 + 16 <= a.Cout;
+        const unsigned ovoff = (pixoff * (unsigned)a.out_cs + (unsigned)c0) * 4u, rvoff = (pixoff * (unsigned)a.res_cs + (unsigned)c0) * 4u;
+        f32x4 rvv[16];
+        {
+            f32x4 z[4][6];                         // A^T M: rows yy, columns b; the vector runs over the lane's four tiles
 #pragma unroll
             for (int b = 0; b < 6; ++b)
-                w44_at(acc[0 * 6 + b][j][i], acc[1 * 6 + b][j][i], acc[2 * 6 + b][j][i], acc[3 * 6 + b][j][i], acc[4 * 6 + b][j][i],
-                       acc[5 * 6 + b][j][i], z[0][b], z[1][b], z[2][b], z[3][b]);
+                w44_at(acc[0 * 6 + b][j], acc[1 * 6 + b][j], acc[2 * 6 + b][j], acc[3 * 6 + b][j], acc[4 * 6 + b][j], acc[5 * 6 + b][j],
+                       z[0][b], z[1][b], z[2][b], z[3][b]);
+            // the block's accumulators are dead now: their registers take the residual, fetched under the second pass (earlier --
+            // before the first pass -- the kernel needed more than its 512 registers, and a compiler-inserted spill is a vector
+            // memory instruction that breaks the hand-counted vmcnt of the main loop)
+            if (a.res && blockfull) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int pb = __builtin_amdgcn_readfirstlane(pixb[k]);
+                    rvv[k] = buf_load_f32x4(rres, rvoff, pb >= 0 ? (unsigned)pb * (unsigned)a.res_cs * 4u : M3D_BUF_OOB);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) rvv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            float *op = ot + (4 * aq) * 272 + atile;
 #pragma unroll
             for (int yy = 0; yy < 4; ++yy) {
-                float y[4];
+                f32x4 y[4];
                 w44_at(z[yy][0], z[yy][1], z[yy][2], z[yy][3], z[yy][4], z[yy][5], y[0], y[1], y[2], y[3]);
 #pragma unroll
-                for (int xx = 0; xx < 4; ++xx) {
-                    float v = y[xx];
+                for (int xx = 0; xx < 4; ++xx)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) op[i * 272 + (yy * 4 + xx) * 16] = y[xx][i];
+            }
+        }
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c0 + e < a.Cout) {
+                if (a.scale) sc[e] = a.scale[c0 + e];
+                if (a.shift) sh[e] = a.shift[c0 + e];
+            }
+        // Masking without branches: a tile that does not exist puts the out-of-range marker into the SGPR offset of its loads /
+        // stores, channels past Cout into the lane offset (the buffer range check drops the access).  Only a 16-channel block
+        // that straddles Cout (wave-uniform test) takes the element-wise path.
+        if (blockfull) {
+            // LeakyReLU as max(v, slope v) with slope 1 = none; without a residual rvv is zero
+            const float slope = a.act == 1 ? M3D_LEAKY_SLOPE : 1.f;
+            auto body = [&](auto rm_tag) __attribute__((always_inline)) {
+                constexpr bool RM1 = decltype(rm_tag)::value;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int pb = __builtin_amdgcn_readfirstlane(pixb[k]);
+                    const unsigned osoff = pb >= 0 ? (unsigned)pb * (unsigned)a.out_cs * 4u : M3D_BUF_OOB;
+                    f32x4 v = *reinterpret_cast<const f32x4 *>(ot + k * 272 + lane * 4);
+                    const f32x4 rv = rvv[k];
+                    if constexpr (RM1) v = (v + rv) * sc + sh;
+                    else v = v * sc + sh + rv;
+                    v = __builtin_elementwise_max(v, v * slope);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, ovoff, osoff, 0);
+                }
+            };
+            if (a.res_mode) body(std::true_type{}); else body(std::false_type{});
+        } else {
+            for (int k = 0; k < 16; ++k) {
+                const int pb = __builtin_amdgcn_readfirstlane(pixb[k]);
+                const unsigned osoff = pb >= 0 ? (unsigned)pb * (unsigned)a.out_cs * 4u : M3D_BUF_OOB;
+                const unsigned rsoff = pb >= 0 ? (unsigned)pb * (unsigned)a.res_cs * 4u : M3D_BUF_OOB;
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(ot + k * 272 + lane * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned em = c0 + e < a.Cout ? (unsigned)e * 4u : M3D_BUF_OOB;
+                    float v = v0[e];
                     if (a.res) {
-                        if (a.res_mode) v = fmaf(v + rv[yy * 4 + xx], sc, sh);
-                        else v = fmaf(v, sc, sh) + rv[yy * 4 + xx];
+                        const float rv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, rvoff + em, rsoff, 0));
+                        if (a.res_mode) v = fmaf(v + rv, sc[e], sh[e]);
+                        else v = fmaf(v, sc[e], sh[e]) + rv;
                     } else {
-                        v = fmaf(v, sc, sh);
+                        v = fmaf(v, sc[e], sh[e]);
                     }
                     if (a.act == 1) v = fmaxf(v, v * M3D_LEAKY_SLOPE);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, ob, (unsigned)(yy * a.W + xx) * ocs4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, ovoff + em, osoff, 0);
                 }
             }
         }
@@ -361,6 +436,20 @@ extern "C" int m3d_wino44_conv3x3_forward_ex(const m3d_conv_desc *d, int nb, m3d
     a.trace = g_w44_trace;
 #endif
     // 128-channel workgroups (2 blocks of 16 per wave) where they fill the chip, else 64-channel workgroups
+#ifndef WINO_TRACE
+    {
+        // the main loop counts its outstanding vector-memory instructions by hand: a build in which the compiler spills registers
+        // (scratch loads / stores are vector-memory instructions too) would wait for the wrong loads -- refuse to run such a build
+        static int scratch = -1;
+        if (scratch < 0) {
+            hipFuncAttributes f1, f2;
+            M3D_HIP(hipFuncGetAttributes(&f1, reinterpret_cast<const void *>(&wino44_kernel<1>)));
+            M3D_HIP(hipFuncGetAttributes(&f2, reinterpret_cast<const void *>(&wino44_kernel<2>)));
+            scratch = (int)(f1.localSizeBytes + f2.localSizeBytes);
+        }
+        M3D_REQUIRE(scratch == 0, "wino44: this build of the kernel uses %d bytes of scratch memory per lane (register spills)", scratch);
+    }
+#endif
     const int strips = cdiv(a.NT, 16);
     M3D_REQUIRE(nb >= 0 && nb <= 2 && !(nb == 2 && d->Cout_pad % 128), "wino44: nb = 0 (automatic), 1 or 2 (needs Cout_pad %% 128 == 0)");
     const bool nb2 = d->Cout_pad % 128 == 0 && (nb == 2 || (nb == 0 && (long long)strips * (d->Cout_pad / 128) >= 200));
