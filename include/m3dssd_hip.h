@@ -396,6 +396,13 @@ int m3d_topk_decode(const unsigned int *score_bits, const float *prob, const flo
                     const float *rois /*[R][5]*/, const float *anchors /*[A][9]*/, const float *means /*[11]*/,
                     const float *stds /*[11]*/, float *aboxes, int *rows_out, void *workspace, long long workspace_bytes,
                     int B, int R, int k, m3d_stream_t stream);
+/* Same with the test-time scale factor of every image (scale [B] device floats, or NULL = 1): the 2-D corners and the projected
+ * 3-D centre are divided by it right after the decode -- BEFORE the NMS that follows, as im_detect_3d does
+ * (lib/rpn_util.py:1504-1506; the +1 area convention of the NMS is not scale invariant). */
+int m3d_topk_decode_scaled(const unsigned int *score_bits, const float *prob, const float *bbox_2d, const float *bbox_3d,
+                           const float *rois, const float *anchors, const float *means, const float *stds, const float *scale,
+                           float *aboxes, int *rows_out, void *workspace, long long workspace_bytes, int B, int R, int k,
+                           m3d_stream_t stream);
 /* Decode `n_rows` selected rows per image -> aboxes [B][n_rows][14]
  * (x1,y1,x2,y2,score,cls,x3d,y3d,z3d,w3d,h3d,l3d,ry3d,anchor). */
 int m3d_decode_rows(const long long *rows /*[B][n_rows] row ids*/, const float *prob, const float *bbox_2d,
@@ -433,7 +440,7 @@ int m3d_refine_3d(const float *aboxes, const int *counts, int B, int K, const do
                   double score_thresh, int hill_climbing, double step_r_init, double r_lim, double *out, m3d_stream_t stream);
 /* The same with the two per-image steps im_detect_3d / test_kitti_3d apply between NMS and the loop folded in, so that the call can
  * sit in a captured graph right behind m3d_select_post: scale [B] fp32 (device, or NULL) -- x1 y1 x2 y2 x3d y3d are divided by
- * scale[b] in float32 first (lib/rpn_util.py:1528-1531, `aboxes[:, 0:4] /= scale_factor`); clip_wh [B][2] fp32 = (imW, imH)
+ * scale[b] in float32 first (`coords_2d[:, 0:4] /= scale_factor`, lib/rpn_util.py:1506-1507 -- the reference does it BEFORE the NMS: pass the factors to m3d_topk_decode_scaled and NULL here to reproduce that); clip_wh [B][2] fp32 = (imW, imH)
  * (device, or NULL; an entry <= 0 disables it) -- the 2-D box is then clipped to [0, imW - 1] x [0, imH - 1] (:1533-1538).  The
  * rows themselves are not modified.  K may include the count row of a m3d_select_post block (it lies past counts[b]). */
 int m3d_refine_3d_ex(const float *aboxes, const int *counts, int B, int K, const double *p2, const double *p2_inv,

@@ -141,6 +141,7 @@ SIGNATURES = {
     "m3d_decode_rows": (c_int, [P] * 9 + [c_int] * 3 + [P]),
     "m3d_topk_decode_workspace_bytes": (c_ll, [c_int, c_int]),
     "m3d_topk_decode": (c_int, [P] * 11 + [c_ll] + [c_int] * 3 + [P]),
+    "m3d_topk_decode_scaled": (c_int, [P] * 12 + [c_ll] + [c_int] * 3 + [P]),
     "m3d_select_post": (c_int, [P] * 3 + [c_int] * 3 + [P, P, P]),
     "m3d_nms_workspace_bytes": (c_ll, [c_int, c_int]),
     "m3d_nms_sorted_dev": (c_int, [P, c_int, c_int, c_int, c_float, P, P, P, P]),

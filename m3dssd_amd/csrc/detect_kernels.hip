@@ -91,6 +91,7 @@ struct TopkArgs {
     float *aboxes;                    // [B][k][14]
     int *rows_out;                    // [B][k] selected rows, score-descending (optional)
     unsigned long long *cand;         // workspace [B][2][R]
+    const float *scale;               // [B] or null: test-time scale factor of each image (lib/rpn_util.py:1504-1506)
     int R, k;
 };
 
@@ -231,8 +232,18 @@ __global__ __launch_bounds__(TOPK_NT) void topk_decode_kernel(TopkArgs a)
     for (int i = tid; i < k; i += TOPK_NT) {
         const int row = (int)(0xFFFFFFFFu - (unsigned)sel[i]);
         if (a.rows_out) a.rows_out[(size_t)img * k + i] = row;
-        decode_row(row, (size_t)img * R + row, a.prob, a.b2, a.b3, a.rois, a.anchors, a.means, a.stds,
-                   a.aboxes + ((size_t)img * k + i) * 14);
+        float *q = a.aboxes + ((size_t)img * k + i) * 14;
+        decode_row(row, (size_t)img * R + row, a.prob, a.b2, a.b3, a.rois, a.anchors, a.means, a.stds, q);
+        if (a.scale) {
+            // `coords_2d[:, 0:4] /= scale_factor; coords_3d[:, 0:2] /= scale_factor` BEFORE the sort and the NMS, as the reference
+            // does it (lib/rpn_util.py:1504-1506): the +1 convention of the NMS areas is not scale invariant, so an IoU next to
+            // nms_thres can fall on the other side when the division comes after the NMS.  float32 divisions like torch's.
+            const float sf = a.scale[img];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q[c] = __fdiv_rn(q[c], sf);
+            q[6] = __fdiv_rn(q[6], sf);
+            q[7] = __fdiv_rn(q[7], sf);
+        }
     }
 }
 
@@ -246,6 +257,15 @@ extern "C" int m3d_topk_decode(const unsigned int *score_bits, const float *prob
                                int *rows_out, void *workspace, long long workspace_bytes, int B, int R, int k,
                                m3d_stream_t stream)
 {
+    return m3d_topk_decode_scaled(score_bits, prob, bbox_2d, bbox_3d, rois, anchors, means, stds, nullptr, aboxes, rows_out, workspace,
+                                  workspace_bytes, B, R, k, stream);
+}
+
+extern "C" int m3d_topk_decode_scaled(const unsigned int *score_bits, const float *prob, const float *bbox_2d, const float *bbox_3d,
+                                      const float *rois, const float *anchors, const float *means, const float *stds,
+                                      const float *scale, float *aboxes, int *rows_out, void *workspace, long long workspace_bytes,
+                                      int B, int R, int k, m3d_stream_t stream)
+{
     M3D_REQUIRE(score_bits && prob && bbox_2d && bbox_3d && rois && anchors && means && stds && aboxes && workspace,
                 "topk_decode: null pointer");
     M3D_REQUIRE(B >= 1 && R >= 1 && R < (1 << 22), "topk_decode: R (%d) must be in [1, 2^22)", R);
@@ -257,7 +277,7 @@ extern "C" int m3d_topk_decode(const unsigned int *score_bits, const float *prob
     TopkArgs a;
     a.score_bits = score_bits; a.prob = prob; a.b2 = bbox_2d; a.b3 = bbox_3d; a.rois = rois; a.anchors = anchors;
     a.means = means; a.stds = stds; a.aboxes = aboxes; a.rows_out = rows_out; a.cand = (unsigned long long *)workspace;
-    a.R = R; a.k = k;
+    a.R = R; a.k = k; a.scale = scale;
     hipLaunchKernelGGL(topk_decode_kernel, dim3(B), dim3(TOPK_NT), 0, (hipStream_t)stream, a);
     M3D_LAUNCH_CHECK();
     return M3D_OK;

@@ -20,7 +20,7 @@ struct RefineArgs {
     const double *p2;        // [B][16] row-major 4x4 projection matrices
     const double *p2_inv;    // [B][16] their inverses (np.linalg.inv on the host, as the reference computes them)
     double *out;             // [B][K][16]: valid, cls, alpha, x1, y1, x2, y2, h3d, w3d, l3d, x3d, y3d, z3d, ry3d, score, 0
-    const float *scale;      // [B] or null: rows are divided back to the original image scale first (lib/rpn_util.py:1528-1531)
+    const float *scale;      // [B] or null: rows are divided back to the original image scale first (lib/rpn_util.py:1506-1507; callers that want the reference order -- before the NMS -- pass the factors to m3d_topk_decode_scaled and NULL here)
     const float *clip_wh;    // [B][2] = (imW, imH) or null: then the 2-D box is clipped to the image (:1533-1538); <= 0: not clipped
     int B, K, hill_climbing;
     double score_thresh, step_r_init, r_lim, step_z_init, z_lim, min_ol_dif;

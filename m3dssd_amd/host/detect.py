@@ -33,9 +33,23 @@ def check_conf(conf):
                          % (len(conf.lbls) + 1))
 
 
-def detect_from_outputs(eng, plan, prob, bbox_2d, bbox_3d, rois, conf):
+def _scale_tensor(scale, B, dev):
+    """scale: None, a float, or [B] floats / tensor -> device float32 [B] (or None when every factor is 1)."""
+    if scale is None:
+        return None
+    if torch.is_tensor(scale):
+        return scale.to(dev, torch.float32).reshape(B).contiguous()
+    arr = np.broadcast_to(np.asarray(scale, dtype=np.float32).reshape(-1), (B,)).copy()
+    if (arr == 1.0).all():
+        return None
+    return torch.from_numpy(arr).to(dev)
+
+
+def detect_from_outputs(eng, plan, prob, bbox_2d, bbox_3d, rois, conf, scale=None):
     """top-N-pre select + decode -> NMS on the engine's output buffers (current stream of their device).
-    -> (aboxes [B, n_pre, 14] score-sorted, keep [B, n_pre] int32 positions, num_keep [B] int32)."""
+    -> (aboxes [B, n_pre, 14] score-sorted, keep [B, n_pre] int32 positions, num_keep [B] int32).
+    scale: per-image test-time scale factors (device float32 [B]) -- the boxes are divided by them BEFORE the NMS like the
+    reference's im_detect_3d does (lib/rpn_util.py:1504-1506)."""
     L = _hip.lib()
     dev = prob.device
     B, R = prob.shape[0], prob.shape[1]
@@ -49,16 +63,18 @@ def detect_from_outputs(eng, plan, prob, bbox_2d, bbox_3d, rois, conf):
         num = torch.empty(B, device=dev, dtype=torch.int32)
         tk_bytes = L.m3d_topk_decode_workspace_bytes(B, R)
         ws = torch.empty(max(tk_bytes, L.m3d_nms_workspace_bytes(B, n_pre)), device=dev, dtype=torch.uint8)
-        _hip.check(L.m3d_topk_decode(bits.data_ptr(), prob.data_ptr(), bbox_2d.data_ptr(), bbox_3d.data_ptr(),
-                                     rois.data_ptr(), P["anchors"].data_ptr(), P["means"].data_ptr(),
-                                     P["stds"].data_ptr(), aboxes.data_ptr(), None, ws.data_ptr(), tk_bytes, B, R, n_pre, st))
+        _hip.check(L.m3d_topk_decode_scaled(bits.data_ptr(), prob.data_ptr(), bbox_2d.data_ptr(), bbox_3d.data_ptr(),
+                                            rois.data_ptr(), P["anchors"].data_ptr(), P["means"].data_ptr(),
+                                            P["stds"].data_ptr(), None if scale is None else scale.data_ptr(), aboxes.data_ptr(),
+                                            None, ws.data_ptr(), tk_bytes, B, R, n_pre, st))
         _hip.check(L.m3d_nms_sorted_dev(aboxes.data_ptr(), B, n_pre, 14, float(conf.nms_thres), ws.data_ptr(),
                                         keep.data_ptr(), num.data_ptr(), st))
     return aboxes, keep, num
 
 
-def detect_device(net, im, conf, top_post=None):
-    """-> (aboxes [B, n_pre, 14] score-sorted, keep [B, n_pre] int32 positions, num_keep [B] int32), device tensors."""
+def detect_device(net, im, conf, top_post=None, scale=None):
+    """-> (aboxes [B, n_pre, 14] score-sorted, keep [B, n_pre] int32 positions, num_keep [B] int32), device tensors.
+    scale: test-time scale factor(s) of the frames (float, [B] floats or tensor): applied before the NMS."""
     if im.dim() == 3:
         im = im[None]
     dev = next(net.parameters()).device
@@ -68,19 +84,16 @@ def detect_device(net, im, conf, top_post=None):
         cls, prob, bbox_2d, bbox_3d, feat_size, rois = net(im)
         eng = net.engine()
         plan = eng.plan_for(prob.shape[0], im.shape[2], im.shape[3])
-        return detect_from_outputs(eng, plan, prob, bbox_2d, bbox_3d, rois, conf)
+        return detect_from_outputs(eng, plan, prob, bbox_2d, bbox_3d, rois, conf, _scale_tensor(scale, prob.shape[0], dev))
 
 
 def im_detect_3d(im, net, rpn_conf, obj=None, gpu=0, synced=False):
     if synced:
         raise NotImplementedError("the synced=True branch of im_detect_3d is not used by test_kitti_3d")
-    aboxes, keep, num = detect_device(net, im, rpn_conf)
+    scale = getattr(obj, "scale_factor", 1.0) if obj is not None else 1.0
+    aboxes, keep, num = detect_device(net, im, rpn_conf, scale=scale)       # scaled before the NMS (lib/rpn_util.py:1504-1506)
     k = int(num[0].item())
     out = aboxes[0][keep[0, :k].long()].cpu().numpy()
-    scale = getattr(obj, "scale_factor", 1.0) if obj is not None else 1.0
-    if scale != 1.0:
-        out[:, 0:4] /= scale
-        out[:, 6:8] /= scale
     if rpn_conf.clip_boxes and obj is not None:
         out[:, 0] = np.clip(out[:, 0], 0, obj.imW - 1)
         out[:, 1] = np.clip(out[:, 1], 0, obj.imH - 1)
@@ -110,7 +123,7 @@ def select_post(aboxes, keep, num, conf):
     return block[:, :-1], counts
 
 
-def detect_batch(net, im, conf):
+def detect_batch(net, im, conf, scale=None):
     """-> (dets [B, nms_topN_post, 14] zero-padded, counts [B] int32) device tensors (dets is a view of the
-    [B, nms_topN_post + 1, 14] gather block, see select_block)."""
-    return select_post(*detect_device(net, im, conf), conf)
+    [B, nms_topN_post + 1, 14] gather block, see select_block).  scale: see detect_device."""
+    return select_post(*detect_device(net, im, conf, scale=scale), conf)

@@ -36,7 +36,7 @@ def _get(obj, key, default=None):
 def _meta_arrays(metas, rpn_conf):
     """Per-image calibration / scale / clip size of a batch, as m3d_refine_3d_ex takes them."""
     p2 = np.stack([np.asarray(_get(m, "p2"), dtype=np.float64).reshape(4, 4) for m in metas])
-    scale = np.asarray([float(_get(m, "scale_factor", 1.0) or 1.0) for m in metas], dtype=np.float32)   # rpn_util.py:1528-1531
+    scale = np.asarray([float(_get(m, "scale_factor", 1.0) or 1.0) for m in metas], dtype=np.float32)   # rpn_util.py:1435,1506-1507
     clip = np.zeros((len(metas), 2), dtype=np.float32)
     if getattr(rpn_conf, "clip_boxes", False):                                                           # :1533-1538
         for b, m in enumerate(metas):
@@ -56,10 +56,10 @@ def _write(refined, metas, rpn_conf, results_path):
 def _flush(ims, metas, net, rpn_conf, results_path, dev):
     """A batch outside the pipelined graph (the ragged last one, or a one-off padded size): eager launches."""
     x = torch.cat([im if im.dim() == 4 else im[None] for im in ims]).to(dev, torch.float32)
-    dets, counts = detect_batch(net, x, rpn_conf)
     meta = _meta_arrays(metas, rpn_conf)
+    dets, counts = detect_batch(net, x, rpn_conf, scale=meta["scale"])          # scaled before the NMS, like the reference
     ref = R.refine_detections(dets, counts, meta["p2"], hill_climbing=bool(getattr(rpn_conf, "hill_climbing", True)),
-                              scale=meta["scale"], clip_wh=meta["clip_wh"])
+                              scale=None, clip_wh=meta["clip_wh"])
     _write(ref, metas, rpn_conf, results_path)
     return dets.shape[0]
 
@@ -96,9 +96,12 @@ class _Pipelined:
             self.open = None
 
 
-def test_kitti_3d(dataset_test, net, rpn_conf, results_path, test_path, use_log=True, writer=None, phase="validation"):
-    """Same arguments as the reference.  Returns (result text, stats dict) of get_official_eval_result, or (None, None) when
-    the label folder of `phase` does not exist (the reference would raise while reading it)."""
+def test_kitti_3d(dataset_test, net, rpn_conf, results_path, test_path, use_log=True, writer=None, phase="validation",
+                  require_labels=True):
+    """Same arguments as the reference (+ require_labels).  Returns (result text, stats dict) of get_official_eval_result.
+    A missing label folder of `phase` raises FileNotFoundError like the reference does when it reads it
+    (lib/rpn_util.py:1868-1876) -- a wrong test_path / phase must not look like a successful run without AP;
+    require_labels=False writes the result files only and returns (None, None)."""
     os.makedirs(results_path, exist_ok=True)
     dev = next(net.parameters()).device
     net.eval()
@@ -127,17 +130,27 @@ def test_kitti_3d(dataset_test, net, rpn_conf, results_path, test_path, use_log=
     if key in rpn_conf and rpn_conf[key]:
         gt_path = os.path.join(test_path, _get(rpn_conf[key][0], "name"), sub, "label_2")
     if gt_path is None or not os.path.isdir(gt_path):
+        if require_labels:
+            raise FileNotFoundError("test_kitti_3d: label folder of phase %r not found (%s); result files are in %s"
+                                    % (phase, gt_path, results_path))
+        logging.warning("test_kitti_3d: no label folder for phase %r (%s): result files written, no AP", phase, gt_path)
         return None, None
     dt_annos = get_label_annos(results_path)
     gt_annos = get_label_annos(gt_path)
     res, res_stats = get_official_eval_result(gt_annos, dt_annos, [0, 1, 2])
-    if writer is not None:                                 # lib/rpn_util.py:1880-1896
+    if writer is not None:                                 # lib/rpn_util.py:1767-1768,1880-1896
+        # the reference's step: the results folder is named results_<iteration> (file_parts(...)[1] without 'results_')
+        test_iter = os.path.basename(os.path.normpath(results_path.replace("/data", ""))).replace("results_", "")
+        step = int(test_iter) if test_iter.isdigit() else 0
         for lbl in rpn_conf.lbls:
             for item in ("aos", "3d", "bev", "image"):
                 k = "{}_{}".format(lbl, item)
+                if item == "3d" and lbl == "Car" and k + "_easy_R40" in res_stats:
+                    writer.add_scalars("Test/" + k, {"easyR40": res_stats[k + "_easy_R40"], "modR40": res_stats[k + "_moderate_R40"],
+                                                     "hardR40": res_stats[k + "_hard_R40"]}, step)
                 if k + "_easy" in res_stats:
                     writer.add_scalars("Test/" + k, {"easy": res_stats[k + "_easy"], "mod": res_stats[k + "_moderate"],
-                                                     "hard": res_stats[k + "_hard"]}, 0)
+                                                     "hard": res_stats[k + "_hard"]}, step)
     if use_log:
         logging.info(res)
     else:

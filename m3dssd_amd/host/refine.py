@@ -33,7 +33,7 @@ def refine_detections(dets, counts, p2, score_thresh=0.75, hill_climbing=True, s
     """dets [B, K, 14] float32 device rows (detect_batch / im_detect_3d format), counts [B] int32 device, p2 [B, 4, 4] (or
     [4, 4]) projection matrices (numpy / host) -> float64 device tensor [B, K, 16]:
     valid, cls, alpha, x1, y1, x2, y2, h3d, w3d, l3d, x3d, y3d, z3d, ry3d, score, 0.
-    scale [B] (host floats): the rows are first divided back to the original image scale (lib/rpn_util.py:1528-1531);
+    scale [B] (host floats): the rows are first divided back to the original image scale (lib/rpn_util.py:1506-1507; None when detect_batch(..., scale=) already did it before the NMS, the reference order);
     clip_wh [B, 2] = (imW, imH): the 2-D boxes are clipped to the image (:1533-1538; an entry <= 0 = not clipped)."""
     if not dets.is_cuda:
         raise NotImplementedError("refine_detections: ROCm device tensors expected")

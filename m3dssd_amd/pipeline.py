@@ -58,14 +58,17 @@ class PipelinedDetector:
 
     def _detect(self):
         prob, b2, b3 = self._outs
-        block, counts = select_block(*detect_from_outputs(self.eng, self.plan, prob, b2, b3, self._rois, self.conf), self.conf)
+        # refine mode carries the frames' test-time scale factors: the boxes are divided by them inside the decode, before the NMS
+        # (lib/rpn_util.py:1504-1506), not in the refinement behind it
+        block, counts = select_block(*detect_from_outputs(self.eng, self.plan, prob, b2, b3, self._rois, self.conf,
+                                                          self._scale if self.refine else None), self.conf)
         if not self.refine:
             return block, counts, None
         B, K1, _ = block.shape                          # K1 = kept rows + the count row (past counts[b]: refined to zeros)
         out = torch.empty(B, K1, 16, device=self.dev, dtype=torch.float64)
         st = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
         _hip.check(_hip.lib().m3d_refine_3d_ex(block.data_ptr(), counts.data_ptr(), B, K1, self._p2.data_ptr(),
-                                               self._p2_inv.data_ptr(), self._scale.data_ptr(), self._clip.data_ptr(),
+                                               self._p2_inv.data_ptr(), None, self._clip.data_ptr(),
                                                *self._rargs, out.data_ptr(), st))
         return block, counts, out
 

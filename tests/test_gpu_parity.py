@@ -964,9 +964,16 @@ def test_pipelined_detector_matches_detect_batch():
             outs.append(tuple(t.clone() for t in r))
     outs.append(tuple(t.clone() for t in pipe.flush()))
     assert len(outs) == 3
-    for (gd, gc, gr), (rd, rc), m in zip(outs, ref, metas):
-        assert torch.equal(gc, rc) and torch.equal(gd, rd)
-        want = HR.refine_detections(rd, rc, m["p2"], hill_climbing=bool(getattr(conf, "hill_climbing", True)), scale=m["scale"],
+    from m3dssd_amd.host.detect import detect_batch as _db
+    n_changed = 0
+    for (gd, gc, gr), (rd, rc), m, x in zip(outs, ref, metas, xs):
+        # the frames' scale factors divide the boxes inside the decode, BEFORE the NMS (lib/rpn_util.py:1506-1507): the pipelined
+        # rows equal the eager detection with the same factors; image 0 (factor 1) equals the unscaled reference bit for bit
+        sd, sc = (t.clone() for t in _db(net, x, conf, scale=m["scale"]))
+        assert torch.equal(gc, sc) and torch.equal(gd, sd)
+        assert torch.equal(gd[0], rd[0]) and int(gc[0]) == int(rc[0])
+        n_changed += int(not torch.equal(gc, rc))
+        want = HR.refine_detections(sd, sc, m["p2"], hill_climbing=bool(getattr(conf, "hill_climbing", True)), scale=None,
                                     clip_wh=m["clip_wh"])
         assert gr.shape == want.shape and torch.equal(gr, want)
         assert float(gr[:, :, 0].sum()) > 0                # some rows were refined

@@ -183,8 +183,10 @@ def test_test_kitti_3d_writes_results_and_evaluates(tmp_path):
     os.makedirs(label_dir)
     # labels = the detector's own output of a first pass with alpha jittered -> a non-trivial AP
     res_dir = tmp_path / "results" / "data"
-    text, stats = test_kitti_3d(dataset, net, conf, str(res_dir), str(tmp_path), use_log=False, phase="train")
-    assert text is None                                              # no label folder for that phase: results only
+    with pytest.raises(FileNotFoundError):                           # like the reference: a missing label folder is an error ...
+        test_kitti_3d(dataset, net, conf, str(res_dir), str(tmp_path), use_log=False, phase="train")
+    text, stats = test_kitti_3d(dataset, net, conf, str(res_dir), str(tmp_path), use_log=False, phase="train", require_labels=False)
+    assert text is None                                              # ... unless the caller asks for the result files only
     files = sorted(os.listdir(res_dir))
     assert files == ["%06d.txt" % i for i in range(7)]
     from lib.rpn_util import detect_batch
@@ -193,20 +195,26 @@ def test_test_kitti_3d_writes_results_and_evaluates(tmp_path):
         ref = R.refine_detections(dets.clone(), counts, np.stack([p2] * (hi - lo))).cpu().numpy()
         for b in range(hi - lo):
             assert open(res_dir / ("%06d.txt" % (lo + b))).read() == R.kitti_text(ref[b], conf.lbls)
-    # scale_factor != 1 and clip_boxes (lib/rpn_util.py:1528-1538): applied inside m3d_refine_3d_ex (full batches: in the captured
-    # graph) == the reference's float32 array operations followed by the plain refinement
+    # scale_factor != 1 (lib/rpn_util.py:1506-1507: BEFORE the sort and the NMS, inside m3d_topk_decode_scaled) and clip_boxes
+    # (:1557-1561, inside m3d_refine_3d_ex; full batches: both in the captured graph) == the eager detection with the same factors
+    # followed by the float32 clip and the plain refinement
     conf.clip_boxes = True
     scales = [0.8 + 0.05 * i for i in range(7)]
     dataset2 = [(frames[i:i + 1], Conf(id="%06d" % i, p2=p2, scale_factor=scales[i], imW=300, imH=110)) for i in range(7)]
     res2 = tmp_path / "results2" / "data"
-    test_kitti_3d(dataset2, net, conf, str(res2), str(tmp_path), use_log=False, phase="train")
+    test_kitti_3d(dataset2, net, conf, str(res2), str(tmp_path), use_log=False, phase="train", require_labels=False)
     n_clipped = 0
     for lo, hi in ((0, 3), (3, 6), (6, 7)):
-        dets, counts = detect_batch(net, frames[lo:hi].to(dev), conf)
+        dets, counts = detect_batch(net, frames[lo:hi].to(dev), conf, scale=scales[lo:hi])
         d = dets.clone()
+        # the scaled rows are the unscaled decode divided in float32 -- for the rows both detections keep
+        un, _ = detect_batch(net, frames[lo:hi].to(dev), conf)
+        un = un.clone()
         sc = torch.tensor(scales[lo:hi], device=dev, dtype=torch.float32)
-        d[:, :, 0:4] /= sc[:, None, None]
-        d[:, :, 6:8] /= sc[:, None, None]
+        un[:, :, 0:4] /= sc[:, None, None]
+        un[:, :, 6:8] /= sc[:, None, None]
+        same = (un[:, :, 13] == d[:, :, 13]) & (un[:, :, 4] == d[:, :, 4])
+        assert same.float().mean() > 0.5 and torch.equal(un[same], d[same])
         n_clipped += int((d[:, :, 2] > 299).sum()) + int((d[:, :, 3] > 109).sum())
         d[:, :, 0].clamp_(0, 299); d[:, :, 2].clamp_(0, 299); d[:, :, 1].clamp_(0, 109); d[:, :, 3].clamp_(0, 109)
         ref = R.refine_detections(d, counts, np.stack([p2] * (hi - lo))).cpu().numpy()
