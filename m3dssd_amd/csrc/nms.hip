@@ -6,9 +6,12 @@
 //    (nms_kernel.cu:24-32,71); this file is compiled with -ffp-contract=off and HIP's default
 //    correctly-rounded fp32 division, so kept indices are bit-identical to the CPU oracle.
 //  * nms_reduce_kernel: one workgroup per image replaces the host loop of nms_kernel.cu:124-141.
-//    Lane j of wave 0 owns the 64-bit "removed" word of column tile j (n <= 4096).  Per row tile: the
+//    Lane j of wave 0 owns the 64-bit "removed" word of column tile j (n <= 4096; the host-pointer
+//    twin `_nms` takes larger inputs over the reference's own route: device masks + greedy pass on the host).  Per row tile: the
 //    64 sequential decisions run on scalar-broadcast words (v_readlane) while the four waves already
 //    hold the tile's 64 mask rows (prefetched one tile ahead) and OR in those whose box was kept.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define NMS_TPB 64
@@ -174,10 +177,35 @@ extern "C" void _nms(int *keep_out, int *num_out, const float *boxes_host, int b
               hipMalloc(&keep_dev, sizeof(int) * boxes_num) == hipSuccess &&
               hipMalloc(&num_dev, sizeof(int)) == hipSuccess;
     ok = ok && hipMemcpy(boxes_dev, boxes_host, bbytes, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && m3d_nms_sorted_dev(boxes_dev, 1, boxes_num, boxes_dim, nms_overlap_thresh, mask_dev, keep_dev, num_dev,
-                                  nullptr) == M3D_OK;
-    ok = ok && hipMemcpy(num_out, num_dev, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
-    ok = ok && hipMemcpy(keep_out, keep_dev, sizeof(int) * (*num_out), hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok && boxes_num > 64 * NMS_TPB) {
+        // The reference has no row limit (nms_kernel.cu:91-144); the on-device greedy reduce keeps one 64-bit "removed" word per
+        // lane (4096 boxes).  Larger inputs take the reference's own route: bitmask tiles on the device, greedy pass on the host
+        // over the upper triangle (nms_kernel.cu:124-141) -- the only words the pass reads are the ones the mask kernel writes.
+        const int cb = (boxes_num + NMS_TPB - 1) / NMS_TPB;
+        hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, 1), dim3(NMS_TPB), 0, nullptr, boxes_num, boxes_dim, nms_overlap_thresh,
+                           boxes_dev, (unsigned long long *)mask_dev);
+        unsigned long long *mask_host = (unsigned long long *)malloc((size_t)boxes_num * cb * sizeof(unsigned long long));
+        unsigned long long *remv = (unsigned long long *)calloc(cb, sizeof(unsigned long long));
+        ok = mask_host && remv && hipGetLastError() == hipSuccess &&
+             hipMemcpy(mask_host, mask_dev, (size_t)boxes_num * cb * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess;
+        int kept = 0;
+        for (int i = 0; ok && i < boxes_num; ++i) {
+            const int nblock = i / NMS_TPB, inblock = i % NMS_TPB;
+            if (!(remv[nblock] & (1ULL << inblock))) {
+                keep_out[kept++] = i;
+                const unsigned long long *p = mask_host + (size_t)i * cb;
+                for (int j = nblock; j < cb; ++j) remv[j] |= p[j];
+            }
+        }
+        if (ok) *num_out = kept;
+        else if (!mask_host || !remv) m3d_set_error("_nms: out of host memory");
+        free(mask_host); free(remv);
+    } else {
+        ok = ok && m3d_nms_sorted_dev(boxes_dev, 1, boxes_num, boxes_dim, nms_overlap_thresh, mask_dev, keep_dev, num_dev,
+                                      nullptr) == M3D_OK;
+        ok = ok && hipMemcpy(num_out, num_dev, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+        ok = ok && hipMemcpy(keep_out, keep_dev, sizeof(int) * (*num_out), hipMemcpyDeviceToHost) == hipSuccess;
+    }
     if (!ok) { printf("_nms: %s\n", m3d_last_error()); *num_out = 0; }
     (void)hipFree(boxes_dev); (void)hipFree(mask_dev); (void)hipFree(keep_dev); (void)hipFree(num_dev);
 }

@@ -350,3 +350,21 @@ def test_winograd_f4x4_conv3x3_matches_torch(case, nb):
         with open(os.path.join(d, "parity_r02.jsonl"), "a") as f:
             f.write(json.dumps({"test": "wino44", "case": list(case), "nb": nb, **errs}) + "\n")
     assert errs["wino44"] < 2e-4, errs
+
+
+# ------------------------------------------------------------------------------------ NMS beyond the device reduce's 4096 rows
+@pytest.mark.parametrize("n", [4097, 6000, 12000])
+def test_nms_twin_has_no_row_limit(n):
+    """`_nms` (lib/nms/gpu_nms.hpp:1-2) has no row limit in the reference (nms_kernel.cu:91-144).  The on-device greedy reduce holds
+    4096 rows; larger inputs go through device masks + the reference's host pass and must give the oracle's keep list bit for bit."""
+    import numpy as np
+    from lib.nms.gpu_nms import gpu_nms
+    from oracle import nms as onms
+    rng = np.random.default_rng(n)
+    ctr = rng.uniform([0, 0], [1280, 384], (n, 2))
+    wh = rng.uniform([5, 5], [200, 150], (n, 2))
+    score = rng.permutation(n).astype(np.float64) / n
+    dets = np.concatenate([ctr - wh / 2, ctr + wh / 2, score[:, None]], 1).astype(np.float32)
+    got = gpu_nms(dets, 0.4, device_id=0)
+    want = onms.gpu_nms(dets, 0.4)
+    assert list(got) == list(want) and len(got) > 50
