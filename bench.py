@@ -90,7 +90,7 @@ def kernel_symbol(label):
         return "bf16_anab_attend_kernel(AnabArgs)"
     if label.startswith("bf16_dcn_patch"):
         th = re.findall(r"\d+", label.split("<", 1)[1])[0]
-        return "void bf16_dcn_patch_kernel<%s, %s>(Bf16Args, void const*, unsigned int const*)" % (th, "10" if th == "16" else "6")
+        return "void bf16_dcn_patch_kernel<%s, %s>(Bf16Args, void const*, unsigned int const*)" % (th, "9, 3" if th == "16" else "6, 1")
     if label.startswith("bf16_halo"):
         bn, tw = re.findall(r"\d+", label.split("<", 1)[1])[:2]
         return "void bf16_conv3x3_halo_kernel<%s, %s, %d, %d, %d>(Bf16Args)" % (bn, tw, 8 * int(tw), 4 if tw == "16" else 8,
@@ -98,8 +98,8 @@ def kernel_symbol(label):
     if label.startswith("bf16_conv"):
         return "void bf16_conv_kernel<%s, %s>(Bf16Args)" % (re.findall(r"\d+", label.split("<", 1)[1])[0],
                                                             "true" if "deform" in label else "false")
-    if label.startswith("wino44"):
-        return "wino44_kernel(Wino44Args)"
+    if label.startswith("wino44"):                 # wino44<16,32[,splitkN]>: 16 tiles x 32 (NB = 2) or 16 (NB = 1) channels per wave
+        return "void wino44_kernel<%d>(Wino44Args)" % (int(re.findall(r"\d+", label)[2]) // 16)
     if label.startswith("wino_wave"):
         return "void wino_wave_kernel<%s>(WinoArgs)" % ("true" if "splitk" in label else "false")
     if label.startswith("wino"):

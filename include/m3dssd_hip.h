@@ -141,6 +141,20 @@ int m3d_wino44_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t stream);
 /* nb = 16-channel blocks per wave: 2 (128-channel workgroups; needs Cout_pad % 128 == 0), 1 (64-channel workgroups), 0 = 2 where
  * the 16-tile strips x 128-channel blocks give >= 200 workgroups, else 1 (tests, tuning). */
 int m3d_wino44_conv3x3_forward_ex(const m3d_conv_desc *d, int nb, m3d_stream_t stream);
+/* Split-K for maps whose 16-tile strips x 128-channel blocks do not fill the chip (256 -> 256 @ 24x80, 512 -> 512 @ 12x40 at
+ * bs 8): *splits slices of >= 64 input channels run as gridDim.z, raw partial outputs go to splitk_ws ([splits][N*H*W][Cout_pad]
+ * fp32, *ws_bytes), a second launch adds them in slice order and applies the epilogue.  *splits = 1 / *ws_bytes = 0: no split.
+ * m3d_wino44_conv3x3_forward[_ex with nb != 1] splits when the descriptor carries a workspace of at least *ws_bytes. */
+int m3d_wino44_splitk_plan(const m3d_conv_desc *d, int *splits, long long *ws_bytes);
+/* Same as _ex, and every thread of the launch first touches a few 128-byte lines of [touch, touch + touch_bytes): the engine
+ * passes the U tensor of the NEXT F(4x4) layer, which is then in the memory-side cache instead of HBM when that layer's B
+ * fragments (four transform positions of lookahead) ask for it -- 256 -> 256 @ 24x80: 0.087 -> 0.063 ms in the network.
+ * touch = NULL: none. */
+int m3d_wino44_conv3x3_forward_touch(const m3d_conv_desc *d, int nb, const void *touch, long long touch_bytes, m3d_stream_t stream);
+
+/* Touches one dword of every 128-byte line of [p, p + bytes): warms the memory-side cache with a weight tensor ahead of a
+ * kernel whose operand lookahead does not cover an HBM round trip (the engine issues it before the F(4x4,3x3) layers). */
+int m3d_cache_touch(const void *p, long long bytes, m3d_stream_t stream);
 
 /* Average launch geometry chosen for a descriptor (for roofline bookkeeping / tests). */
 int m3d_conv2d_tile(const m3d_conv_desc *d, int *bm, int *bn, int *bk, int *grid);

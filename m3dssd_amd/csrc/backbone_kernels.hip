@@ -541,3 +541,27 @@ extern "C" int m3d_upsample2x_add(const float *in, int in_cs, const float *wgt, 
     M3D_LAUNCH_CHECK();
     return M3D_OK;
 }
+
+// ---- cache warm-up ---------------------------------------------------------------------------------------------------------------
+// One dword of every 128-byte line of [p, p + bytes): brings a weight tensor from HBM into the memory-side cache (and the L2 of the
+// XCD that touched the line) just before a kernel whose operand lookahead covers an L2 / MALL round trip but not an HBM one
+// (csrc/wino44_conv.hip: B fragments four transform positions = ~1400 cycles ahead).
+__global__ __launch_bounds__(256) void cache_touch_kernel(const char *p, long long lines)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < lines) {
+        unsigned v;
+        asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p + i * 128) : "memory");
+    }
+}
+
+extern "C" int m3d_cache_touch(const void *p, long long bytes, m3d_stream_t stream)
+{
+    M3D_REQUIRE(p && bytes >= 0, "cache_touch: null pointer");
+    const long long lines = bytes / 128;
+    if (lines == 0) return M3D_OK;
+    M3D_REQUIRE(lines < (1ll << 31) * 256, "cache_touch: range too large");
+    hipLaunchKernelGGL(cache_touch_kernel, dim3((unsigned)cdiv(lines, 256)), dim3(256), 0, (hipStream_t)stream, (const char *)p, lines);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}

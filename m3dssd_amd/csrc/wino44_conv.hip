@@ -33,6 +33,10 @@ struct Wino44Args {
     int N, H, W, Cin, Cout;
     int TH, TW, NT;          // 4x4 output tiles per image (rows, cols), total
     int act, res_mode;
+    int nsl;                 // stages (16 input channels each) per K slice: Cin / 16 / gridDim.z
+    long long ws_slice;      // split-K: floats between the raw partial outputs of consecutive K slices (a.out = slice 0), else 0
+    const char *touch;       // optional: tensor whose 128-byte lines the launch pulls into the memory-side cache (the NEXT
+    int touch_lines;         // F(4x4) layer's U), touch_lines of them
 #ifdef WINO_TRACE
     long long *trace;
 #endif
@@ -112,7 +116,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __shared__ int pixb[16];                                             // first output pixel of each tile (-1: no such tile)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NS = a.Cin >> 4;
+    // split-K (grid.z slices of the input channels, small maps): this workgroup runs stages [s0, s0 + NS) and stores its raw
+    // A^T M A sums to slice blockIdx.z of the workspace (the launcher clears scale / shift / residual / activation for the
+    // launch; m3d_launch_splitk_reduce adds the slices in order and applies the epilogue)
+    const int NS = a.nsl;
+    const int s0 = blockIdx.z * a.nsl;
     W44_TRACE_INIT();
     W44_TRACE();
 
@@ -139,11 +147,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
     const unsigned cs4 = (unsigned)a.in_cs * 4u;
-    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in + s0 * 16, a.in_bytes - (unsigned)s0 * 64u);
     // B fragments of this wave's 16 * NB output channels: [32-channel block][stage][xi][j][lane][4]
     const int cb16 = (blockIdx.y * 4 + wave) * NB;               // first 16-channel block of this wave
     const int cb32 = cb16 >> 1, j0 = cb16 & 1;
-    const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.U + (size_t)cb32 * NS * (36 * 2 * 256), (unsigned)NS * (36u * 2u * 1024u));
+    const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.U + ((size_t)cb32 * (a.Cin >> 4) + s0) * (36 * 2 * 256), (unsigned)NS * (36u * 2u * 1024u));
     const unsigned ulane = (unsigned)lane * 16u + (unsigned)j0 * 1024u;
 
     float d[36];
@@ -206,6 +214,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if constexpr (NB == 2) w44_load_x4(Uf[SL][1], ru, ulane, so + 1024u);
     };
 
+    // ---- cache warm-up for the next F(4x4) layer: its U tensor (2.4-38 MB) is cold in HBM when that layer starts, and the B
+    // fragments run only four positions (~1400 cycles: an L2 / MALL round trip, not an HBM one) ahead of the MFMAs -- measured
+    // on 256 -> 256 @ 24x80: 0.065 ms with U resident, 0.092 ms cold, 0.087 ms in the network.  Every thread of THIS launch
+    // touches a few lines of it before its own first loads: the round trip rides under the patch loads' (same vmcnt(0) below).
+    // (Issued at the end of the kernel instead -- closer to the consumer -- the step measured 6.45 instead of 6.39 ms.) ---------
+    float touched = 0.f;
+    if (a.touch) {
+        const int nwg = gridDim.x * gridDim.y * gridDim.z;
+        const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        for (int i = wg * 256 + tid; i < a.touch_lines; i += nwg * 256)
+            asm volatile("global_load_dword %0, %1, off" : "=v"(touched) : "v"(a.touch + (size_t)i * 128) : "memory");
+    }
     // ---- prologue: stage 0's patch, transform, first B fragments, stage 1's patch ------------------------------------------
     load_patch(0);
     f32x4 acc[36][NB];
@@ -213,7 +233,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int x = 0; x < 36; ++x)
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[x][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(touched) : : "memory");      // (the touch loads' target stays allocated until here)
     tie_patch();
     W44_TRACE();
     transform_store(0);
@@ -310,7 +330,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // floats: the four tile groups of a store instruction land in different banks), read back as (tile k, pixel lane >> 2,
     // channel quad lane & 3): 1 KB contiguous per read, 16 bytes per lane per store, residual fetched in the same shape.
     __syncthreads();                                  // every wave is done with the last stage's V
-    const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out, a.out_bytes);
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out + (size_t)blockIdx.z * a.ws_slice, a.out_bytes);
     const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res ? a.res : a.out, a.res ? a.res_bytes : 0u);
     float *ot = Vs + wave * (16 * 272);               // this wave's slice: 17 KB of the 72 KB
     const int opx = lane >> 2, ocq = lane & 3;        // read-back role: pixel of the 4x4 tile, channel quad
@@ -416,7 +436,31 @@ extern "C" int m3d_wino44_applicable(const m3d_conv_desc *d)
     return 1;
 }
 
-extern "C" int m3d_wino44_conv3x3_forward_ex(const m3d_conv_desc *d, int nb, m3d_stream_t stream)
+// Split-K plan of the F(4x4,3x3) kernel: *splits > 1 when the layer's 16-tile strips x 128-channel blocks do not fill the chip
+// (256 -> 256 @ 24x80 and 512 -> 512 @ 12x40 at bs 8: 120 / 60 workgroups) and the input channels can be cut into slices of at
+// least 64 that do; *ws_bytes = splits * N*H*W * Cout_pad * 4 to pass through splitk_ws.  A layer that needs no split (or that
+// the kernel does not serve) reports 1 / 0.
+extern "C" int m3d_wino44_splitk_plan(const m3d_conv_desc *d, int *splits, long long *ws_bytes)
+{
+    M3D_REQUIRE(d && splits && ws_bytes, "wino44_splitk_plan: null pointer");
+    *splits = 1; *ws_bytes = 0;
+    if (!m3d_wino44_applicable(d) || d->Cout_pad % 128) return M3D_OK;
+    const long long wgs = (long long)cdiv(d->N * (d->H / 4) * (d->W / 4), 16) * (d->Cout_pad / 128);
+    const int ns = d->Cin / 16;
+    if (wgs >= 200) return M3D_OK;
+    for (int sp = 2; sp <= 8; sp *= 2) {
+        if (ns % sp || ns / sp < 4) break;
+        if (wgs * sp >= 200) {
+            const long long need = (long long)sp * d->N * d->H * d->W * d->Cout_pad * 4;
+            if (need / sp < (1ll << 31)) { *splits = sp; *ws_bytes = need; }
+            break;
+        }
+    }
+    return M3D_OK;
+}
+
+extern "C" int m3d_wino44_conv3x3_forward_touch(const m3d_conv_desc *d, int nb, const void *touch, long long touch_bytes,
+                                                m3d_stream_t stream)
 {
     M3D_REQUIRE(d && d->in && d->wgt && d->out, "wino44: null pointer");
     M3D_REQUIRE(m3d_wino44_applicable(d), "wino44: 3x3 / stride 1 / pad 1, H %% 4 == W %% 4 == 0, Cin %% 16 == 0, Cout_pad %% 64 == 0 only");
@@ -432,10 +476,12 @@ extern "C" int m3d_wino44_conv3x3_forward_ex(const m3d_conv_desc *d, int nb, m3d
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
     a.TH = d->H / 4; a.TW = d->W / 4; a.NT = d->N * a.TH * a.TW;
     a.act = d->act; a.res_mode = d->res_mode;
+    a.nsl = d->Cin / 16; a.ws_slice = 0;
+    M3D_REQUIRE(touch_bytes >= 0 && touch_bytes / 128 < (1ll << 31), "wino44: touch range");
+    a.touch = touch_bytes >= 128 ? (const char *)touch : nullptr; a.touch_lines = touch ? (int)(touch_bytes / 128) : 0;
 #ifdef WINO_TRACE
     a.trace = g_w44_trace;
 #endif
-    // 128-channel workgroups (2 blocks of 16 per wave) where they fill the chip, else 64-channel workgroups
 #ifndef WINO_TRACE
     {
         // the main loop counts its outstanding vector-memory instructions by hand: a build in which the compiler spills registers
@@ -452,6 +498,27 @@ extern "C" int m3d_wino44_conv3x3_forward_ex(const m3d_conv_desc *d, int nb, m3d
 #endif
     const int strips = cdiv(a.NT, 16);
     M3D_REQUIRE(nb >= 0 && nb <= 2 && !(nb == 2 && d->Cout_pad % 128), "wino44: nb = 0 (automatic), 1 or 2 (needs Cout_pad %% 128 == 0)");
+    // split-K when the caller provides the workspace the plan asks for (128-channel workgroups only)
+    if (d->splitk_ws && nb != 1) {
+        int splits = 1;
+        long long need = 0;
+        if (const int rc = m3d_wino44_splitk_plan(d, &splits, &need)) return rc;
+        if (splits > 1) {
+            M3D_REQUIRE(need <= d->splitk_ws_bytes && ((uintptr_t)d->splitk_ws & 15) == 0,
+                        "wino44: split-K workspace too small (%lld bytes, see m3d_wino44_splitk_plan) or misaligned", d->splitk_ws_bytes);
+            a.out = d->splitk_ws; a.out_cs = d->Cout_pad; a.out_bytes = (unsigned)(pix * d->Cout_pad * 4);
+            a.ws_slice = pix * d->Cout_pad; a.nsl = d->Cin / 16 / splits;
+            a.scale = a.shift = a.res = nullptr; a.res_bytes = 0; a.act = 0; a.res_mode = 0; a.Cout = d->Cout_pad;
+            hipLaunchKernelGGL(wino44_kernel<2>, dim3(strips, d->Cout_pad / 128, splits), dim3(256), 0, (hipStream_t)stream, a);
+            M3D_LAUNCH_CHECK();
+            SplitkReduceArgs r;
+            r.ws = d->splitk_ws; r.scale = d->scale; r.shift = d->shift; r.res = d->res; r.out = d->out;
+            r.M = (int)pix; r.Cout = d->Cout; r.Cout_pad = d->Cout_pad; r.splits = splits; r.out_cs = d->out_cs;
+            r.res_cs = d->res_cs; r.res_mode = d->res_mode; r.act = d->act; r.sigmoid_from = d->sigmoid_from;
+            return m3d_launch_splitk_reduce(r, (hipStream_t)stream);
+        }
+    }
+    // 128-channel workgroups (2 blocks of 16 per wave) where they fill the chip, else 64-channel workgroups
     const bool nb2 = d->Cout_pad % 128 == 0 && (nb == 2 || (nb == 0 && (long long)strips * (d->Cout_pad / 128) >= 200));
     if (nb2) hipLaunchKernelGGL(wino44_kernel<2>, dim3(strips, d->Cout_pad / 128), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(wino44_kernel<1>, dim3(strips, d->Cout_pad / 64), dim3(256), 0, (hipStream_t)stream, a);
@@ -459,7 +526,12 @@ extern "C" int m3d_wino44_conv3x3_forward_ex(const m3d_conv_desc *d, int nb, m3d
     return M3D_OK;
 }
 
+extern "C" int m3d_wino44_conv3x3_forward_ex(const m3d_conv_desc *d, int nb, m3d_stream_t stream)
+{
+    return m3d_wino44_conv3x3_forward_touch(d, nb, nullptr, 0, stream);
+}
+
 extern "C" int m3d_wino44_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t stream)
 {
-    return m3d_wino44_conv3x3_forward_ex(d, 0, stream);
+    return m3d_wino44_conv3x3_forward_touch(d, 0, nullptr, 0, stream);
 }

@@ -159,8 +159,11 @@ USE_WINO44 = os.environ.get("M3D_WINO44", "1") != "0"
 # F(4x4,3x3) workgroups (16 tiles x 128 or 64 channels, one per CU, 256 CUs): 128-channel workgroups need >= 200 of them; the
 # 64-channel form (half the MFMAs per transformed input) pays from ~2 rounds on: in the network, bs 8, level2 (64 -> 64 @ 96x320,
 # 960 workgroups) gains 10 %, level4 (256 -> 256 @ 24x80, 240 workgroups) loses 5 % against the F(2x2,3x3) wave kernel
+WINO44_TOUCH = os.environ.get("M3D_WINO44_TOUCH", "1") != "0"
+WINO44_TOUCH_SPAN = int(os.environ.get("M3D_WINO44_TOUCH_SPAN", "2"))   # launches between two F(4x4) layers that a folded touch bridges
+USE_WINO44_SPLITK = os.environ.get("M3D_WINO44_SPLITK", "1") != "0"
 WINO44_MIN_WGS = int(os.environ.get("M3D_WINO44_MIN_WGS", "200"))
-WINO44_MIN_WGS_NB1 = int(os.environ.get("M3D_WINO44_MIN_WGS_NB1", "400"))
+WINO44_MIN_WGS_NB1 = int(os.environ.get("M3D_WINO44_MIN_WGS_NB1", "200"))
 
 
 class _Plan:
@@ -170,6 +173,7 @@ class _Plan:
         self.ops = []          # (name, callable)
         self.keep = []         # tensors kept alive
         self.named = {}        # name -> View / tensor (taps for tests)
+        self.w44_prev = None   # (index into ops, touch record) of the latest F(4x4) launch: it warms the cache for the next one
 
 
 class Engine:
@@ -360,16 +364,40 @@ class Engine:
         strips = -(-(x.n * x.h * x.w) // 256)
         nb = 2 if (d.Cout_pad % 128 == 0 and strips * (d.Cout_pad // 128) >= WINO44_MIN_WGS) else \
             (1 if strips * (d.Cout_pad // 64) >= WINO44_MIN_WGS_NB1 else 0)
-        if (pc is not None and wgt_ptr is None and getattr(pc, "_w_cpu", None) is not None and om is None and planar is None
-                and sigmoid_from < 0 and L.m3d_wino44_applicable(ref) == 1 and nb):
+        w44ok = (pc is not None and wgt_ptr is None and getattr(pc, "_w_cpu", None) is not None and om is None and planar is None
+                 and sigmoid_from < 0 and L.m3d_wino44_applicable(ref) == 1)
+        ks44 = 1
+        if w44ok and not nb and USE_WINO44_SPLITK:
+            # small maps (256 -> 256 @ 24x80, 512 -> 512 @ 12x40 at bs 8): K slices as gridDim.z fill the chip, a second launch
+            # adds the partial outputs in slice order
+            ssplits, sbytes = ctypes.c_int(), ctypes.c_longlong()
+            _hip.check(L.m3d_wino44_splitk_plan(ref, ctypes.byref(ssplits), ctypes.byref(sbytes)))
+            if ssplits.value > 1:
+                ws = torch.empty(sbytes.value // 4, device=self.device, dtype=torch.float32)
+                plan.keep.append(ws)
+                d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), sbytes.value
+                nb, ks44 = 2, ssplits.value
+        if w44ok and nb:
             # Winograd F(4x4,3x3): 4x fewer MFMA FLOPs than the direct convolution (F(2x2,3x3): 2.25x) where the layer fills the
             # chip with 16-tile workgroups (csrc/wino44_conv.hip)
             u44 = pc.wino44()
             plan.keep.append(u44)
             d.wgt = u44.data_ptr()
             flops = 2.0 * x.n * d.Ho * d.Wo * d.Cout * 9 * pc.cin
-            plan.ops.append((name, "wino44<16,%d>" % (16 * nb), flops,
-                             lambda st: _hip.check(L.m3d_wino44_conv3x3_forward_ex(ref, nb, st)), d))
+            # U (2.4-38 MB) is cold in HBM when the layer starts and the kernel's B fragments run only ~1400 cycles ahead of the
+            # MFMAs: the PREVIOUS F(4x4) launch touches this layer's U (every thread a few lines, under its own first loads); a
+            # layer with no F(4x4) launch shortly before it gets a touch launch of its own
+            nxt = {"ptr": None, "bytes": 0}
+            if WINO44_TOUCH:
+                nbytes = u44.numel() * 4
+                if plan.w44_prev is not None and len(plan.ops) - plan.w44_prev[0] <= WINO44_TOUCH_SPAN:
+                    plan.w44_prev[1]["ptr"], plan.w44_prev[1]["bytes"] = u44.data_ptr(), nbytes
+                else:
+                    plan.ops.append((name + ".touch", "touch", 0.0,
+                                     lambda st: _hip.check(L.m3d_cache_touch(u44.data_ptr(), nbytes, st)), None))
+            plan.w44_prev = (len(plan.ops), nxt)
+            plan.ops.append((name, "wino44<16,%d%s>" % (16 * nb, ",splitk%d" % ks44 if ks44 > 1 else ""), flops,
+                             lambda st: _hip.check(L.m3d_wino44_conv3x3_forward_touch(ref, nb, nxt["ptr"], nxt["bytes"], st)), d))
             return
         if (pc is not None and wgt_ptr is None and getattr(pc, "wino", None) is not None and kh == 3 and kw == 3
                 and stride == 1 and pad == 1 and om is None and planar is None and x.h % 2 == 0 and x.w % 2 == 0

@@ -260,12 +260,12 @@ class EngineBF16(Engine):
         plan.ops.append((name, kind, flops, lambda st: _hip.check(L.m3d_conv_bf16_forward(ref, st)), d))
 
     def _pconv(self, plan, name, pc, x, out, stride=1, pad=0, act=0, res=None, res_mode=0, sigmoid_from=-1, om=None, out_mode=0,
-               affine=True):
+               affine=True, patch=True):
         self._conv16(plan, name, x, out, wgt=pc.wp, kpad=pc.kpad, cout=pc.cout, cout_pad=pc.cout_pad, kh=pc.kh, kw=pc.kw,
                      stride=stride, pad=pad, scale=pc.scale if (affine and pc.has_affine) else None,
                      shift=pc.shift if (affine and pc.has_affine) else None, act=act, res=res, res_mode=res_mode,
                      sigmoid_from=sigmoid_from, om=om, out_mode=out_mode, cin=pc.cin,
-                     wgt_f16=pc.f16() if om is not None else None)
+                     wgt_f16=pc.f16() if (om is not None and patch) else None)
 
     # ------------------------------------------------------------------ plan construction
     def _build_plan(self, B, H, W):
@@ -465,7 +465,8 @@ class EngineBF16(Engine):
             0, sel_idx.data_ptr(), sel_prob.data_ptr(), 0.5, P["shape.table"].data_ptr(), None, None, None, 0.0, 1.0, 0.0,
             1.0, om_sa.ptr, om_sa.cs, B, A, HW, 9, 0, st)))
         feats = self._buf16(plan, B, fh, fw, 128, name="feats")
-        self._pconv(plan, "shape_align.dcn", P["shape_align"], feats0, feats, 1, 1, act=0, res=feats0, om=om_sa)
+        self._pconv(plan, "shape_align.dcn", P["shape_align"], feats0, feats, 1, 1, act=0, res=feats0, om=om_sa,
+                    patch=False)    # anchor-shaped offsets (up to half an anchor) never fit the LDS window: skip the bound pass
         heads(["bbox_x", "bbox_y"], feats, 0)
         heads(["bbox_x3d", "bbox_y3d"], feats, 4)
 

@@ -78,8 +78,14 @@ def conv_nhwc(v, weight, bias=None, bn=None, stride=1, pad=0, act=0, res=None, r
         d.dcn_offmask, d.dcn_om_cs = om.ptr, om.cs
     ws = None
     if wino44:
+        if wino_splitk:                        # K slices as gridDim.z where the plan asks for them (small maps)
+            splits, ws_bytes = ctypes.c_int(), ctypes.c_longlong()
+            _hip.check(_hip.lib().m3d_wino44_splitk_plan(ctypes.byref(d), ctypes.byref(splits), ctypes.byref(ws_bytes)))
+            if splits.value > 1:
+                ws = torch.empty(ws_bytes.value // 4, device=v.t.device, dtype=torch.float32)
+                d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws_bytes.value
         _hip.check(_hip.lib().m3d_wino44_conv3x3_forward_ex(ctypes.byref(d), wino44_nb, _stream()))
-        return out, (wp, scale, shift, None)
+        return out, (wp, scale, shift, ws)
     if not wino:                               # small-M layers: give the igemm its split-K scratch
         splits, ws_bytes = ctypes.c_int(), ctypes.c_longlong()
         _hip.check(_hip.lib().m3d_conv2d_splitk_plan(ctypes.byref(d), ctypes.byref(splits), ctypes.byref(ws_bytes)))

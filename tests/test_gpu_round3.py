@@ -276,9 +276,19 @@ def test_fp32_forward_is_bit_identical_over_100_runs_at_the_bench_size():
     fused heads) sit next to matrix instructions at 2-3 waves per SIMD like the deformable kernels did when they dropped a
     corner once per 10^5..10^6 states; a wrong select there would show as run-to-run differences at these grid sizes."""
     bad, nbuf, kinds = _soak("f32", 8, (384, 1280), 100)
-    assert {"wino_wave", "conv_wave", "head_mlp", "igemm"} <= kinds, kinds
+    assert {"wino44", "conv_wave", "head_mlp", "igemm"} <= kinds, kinds
     assert not bad, bad[:3]
     assert nbuf > 20
+
+
+def test_fp32_forward_without_f4x4_is_bit_identical_over_40_runs(monkeypatch):
+    """The F(2x2,3x3) wave kernel (and its split-K form) serves the 3x3 layers wherever the F(4x4) kernel does not apply or is
+    switched off (M3D_WINO44=0): same soak on that plan."""
+    import m3dssd_amd.engine as E
+    monkeypatch.setattr(E, "USE_WINO44", False)
+    bad, nbuf, kinds = _soak("f32", 8, (384, 1280), 40)
+    assert "wino_wave" in kinds and "wino44" not in kinds, kinds
+    assert not bad, bad[:3]
 
 
 def test_bf16_forward_is_bit_identical_over_40_runs_at_batch_64():
@@ -350,6 +360,62 @@ def test_winograd_f4x4_conv3x3_matches_torch(case, nb):
         with open(os.path.join(d, "parity_r02.jsonl"), "a") as f:
             f.write(json.dumps({"test": "wino44", "case": list(case), "nb": nb, **errs}) + "\n")
     assert errs["wino44"] < 2e-4, errs
+
+
+@pytest.mark.parametrize("case,want", [((8, 256, 24, 80, 256, True, True, 1, True), 2),      # level4 at bs 8: 120 workgroups -> 240
+                                       ((8, 512, 12, 40, 512, False, True, 1, True), 4),     # level5 at bs 8: 60 -> 240
+                                       ((4, 128, 24, 80, 500, True, True, 0, False), 2),     # Cout 500 (pad 512), 64-channel slices
+                                       ((1, 256, 8, 8, 128, True, False, 1, True), 1)])      # too small to fill the chip: no split
+def test_winograd_f4x4_splitk_matches_torch(case, want):
+    """Split-K form of the F(4x4,3x3) kernel (K slices as gridDim.z + m3d_launch_splitk_reduce in slice order): the plan, the
+    result vs F.conv2d in fp64, and bitwise repeatability (no atomics)."""
+    import ctypes
+    import torch.nn.functional as F
+    from m3dssd_amd import _hip
+    from m3dssd_amd.host import standalone as S
+    dev = _dev()
+    n, ci, h, w, co, bias, bn, act, res = case
+    g = torch.Generator().manual_seed(sum(case) + 5)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5
+    b = torch.randn(co, generator=g) if bias else None
+    ref = F.conv2d(x.double(), wt.double(), None if b is None else b.double(), padding=1)
+    bnm = None
+    if bn:
+        bnm = torch.nn.BatchNorm2d(co).eval()
+        with torch.no_grad():
+            bnm.weight.uniform_(0.5, 1.5, generator=g)
+            bnm.bias.normal_(0, 0.2, generator=g)
+            bnm.running_mean.normal_(0, 0.2, generator=g)
+            bnm.running_var.uniform_(0.5, 1.5, generator=g)
+        ref = bnm.double()(ref)
+        bnm = bnm.float()
+    r = None
+    if res:
+        r = torch.randn(n, co, h, w, generator=g)
+        ref = ref + r.double()
+    if act:
+        ref = F.leaky_relu(ref, 0.01)
+    ref = ref.float()
+    d = _hip.ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.Cout, d.Cout_pad = n, h, w, ci, co, -(-co // 128) * 128
+    d.kh = d.kw = 3
+    d.stride = d.pad = d.dil = 1
+    d.Ho, d.Wo, d.in_cs, d.sigmoid_from = h, w, ci, -1
+    splits, ws_bytes = ctypes.c_int(), ctypes.c_longlong()
+    _hip.check(_hip.lib().m3d_wino44_splitk_plan(ctypes.byref(d), ctypes.byref(splits), ctypes.byref(ws_bytes)))
+    assert splits.value == want and ws_bytes.value == (want * n * h * w * d.Cout_pad * 4 if want > 1 else 0)
+    outs = []
+    with torch.no_grad():
+        v, _ = S._to_nhwc(x.to(dev))
+        rv = S._to_nhwc(r.to(dev))[0] if res else None
+        for _ in range(3):
+            out, keep = S.conv_nhwc(v, wt.to(dev), None if b is None else b.to(dev), None if bnm is None else bnm.to(dev), 1, 1,
+                                    act=act, res=rv, wino44=True, wino44_nb=2, wino_splitk=True)
+            outs.append(S._to_nchw(out, co).cpu())
+    err = ((outs[0] - ref).abs() / (1 + ref.abs())).max().item()
+    assert err < 2e-4, err
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 # ------------------------------------------------------------------------------------ NMS beyond the device reduce's 4096 rows
