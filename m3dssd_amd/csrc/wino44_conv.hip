@@ -120,7 +120,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // A^T M A sums to slice blockIdx.z of the workspace (the launcher clears scale / shift / residual / activation for the
     // launch; m3d_launch_splitk_reduce adds the slices in order and applies the epilogue)
     const int NS = a.nsl;
-    const int s0 = blockIdx.z * a.nsl;
+    // ---- XCD-aware block map for the split-K launches.  Workgroups go round-robin to the 8 XCDs by their linear id; each XCD has
+    // its own 4 MB L2.  All strips of one (channel block, K slice) combination read the same 2.4 MB slice of U: with C = 8, 16, ...
+    // combinations an XCD works through C / 8 of them one after the other, so that its L2 holds one slice at a time instead of
+    // missing on all of them (PMC, 512 -> 512 @ 12x40 split-K 4: 427 MB per launch through the L2s for 115 MB of operands with the
+    // plain map; ~3 % per layer).  Pinning the 2 / 4 channel blocks of an unsplit launch to XCD pairs measured slower (the input
+    // strips are then read through four L2s instead of two): those keep the plain map. ------------------------------------------
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const int X = gridDim.x, C = gridDim.y * gridDim.z;
+        if (gridDim.z > 1 && (C & 7) == 0) {
+            const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * X + blockIdx.x, xcd = lin & 7, idx = lin >> 3;
+            const int combo = xcd * (C >> 3) + idx / X;
+            bx = idx % X;
+            by = combo % (int)gridDim.y;
+            bz = combo / (int)gridDim.y;
+        }
+    }
+    const int s0 = bz * a.nsl;
     W44_TRACE_INIT();
     W44_TRACE();
 
@@ -129,7 +146,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     unsigned vM[6], v0[6], v5[6];    // byte offsets of the patch rows at the tile's first pixel column: columns 1..4 / column 0
                                      // (base one pixel to the left, out of range at the left image border) / column 5 (+ 4 pixels)
     {
-        const int t = blockIdx.x * 16 + ut;
+        const int t = bx * 16 + ut;
         const bool tv = t < a.NT;
         const int tt = tv ? t : 0;
         const int n = tt / (a.TH * a.TW), rem = tt - n * a.TH * a.TW;
@@ -149,7 +166,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned cs4 = (unsigned)a.in_cs * 4u;
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in + s0 * 16, a.in_bytes - (unsigned)s0 * 64u);
     // B fragments of this wave's 16 * NB output channels: [32-channel block][stage][xi][j][lane][4]
-    const int cb16 = (blockIdx.y * 4 + wave) * NB;               // first 16-channel block of this wave
+    const int cb16 = (by * 4 + wave) * NB;                       // first 16-channel block of this wave
     const int cb32 = cb16 >> 1, j0 = cb16 & 1;
     const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.U + ((size_t)cb32 * (a.Cin >> 4) + s0) * (36 * 2 * 256), (unsigned)NS * (36u * 2u * 1024u));
     const unsigned ulane = (unsigned)lane * 16u + (unsigned)j0 * 1024u;
@@ -330,7 +347,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // floats: the four tile groups of a store instruction land in different banks), read back as (tile k, pixel lane >> 2,
     // channel quad lane & 3): 1 KB contiguous per read, 16 bytes per lane per store, residual fetched in the same shape.
     __syncthreads();                                  // every wave is done with the last stage's V
-    const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out + (size_t)blockIdx.z * a.ws_slice, a.out_bytes);
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out + (size_t)bz * a.ws_slice, a.out_bytes);
     const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res ? a.res : a.out, a.res ? a.res_bytes : 0u);
     float *ot = Vs + wave * (16 * 272);               // this wave's slice: 17 KB of the 72 KB
     const int opx = lane >> 2, ocq = lane & 3;        // read-back role: pixel of the 4x4 tile, channel quad
