@@ -203,12 +203,18 @@ typedef struct m3d_conv_bf16_desc {
     const void *wgt_f16;
     void *dcn_ws;
     long long dcn_ws_bytes;
+    /* Plain 3x3 / stride 1 / pad 1, optional (NULL = halo-tile / implicit-GEMM kernels as before): the same weights in the
+     * fragment order of csrc/bf16_conv_wide.hip -- [Cout_pad/128][Cin/32][9 taps][2 K-steps of 16][4 blocks of 32 channels]
+     * [64 lanes][8] with lane = 32 * (k / 8) + (channel % 32) (m3dssd_amd/engine_bf16.py:PackedBf16.wave3x3) -- enable the
+     * 128 x 128 wave-tile kernel on maps with H % 8 == 0, W % 16 == 0, Cin % 32 == 0, Cout_pad % 128 == 0, bf16 NHWC output. */
+    const void *wgt_wave;
 } m3d_conv_bf16_desc;
 int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t stream);
 /* Which kernel m3d_conv_bf16_forward launches for `d` (profiling labels; no launch): 0 = implicit-GEMM tile
  * (bf16_conv_kernel), 1 = 3x3 halo tile of 8 x 16 pixels, 2 = 3x3 halo tile of 8 x 32 pixels (bf16_conv3x3_halo_kernel),
  * 3 / 4 = deformable 3x3 with the sampling window in LDS, 8 x 16 / 16 x 16 pixel patches (bf16_dcn_patch_kernel; the
- * implicit-GEMM kernel is launched behind it and takes over on the device when the launch's offsets do not fit). */
+ * implicit-GEMM kernel is launched behind it and takes over on the device when the launch's offsets do not fit),
+ * 5 = 3x3 with 128 x 128 wave tiles (bf16_conv3x3_wide_kernel; needs wgt_wave). */
 int m3d_conv_bf16_variant(const m3d_conv_bf16_desc *d);
 
 /* Fused 3-layer RPN head of the bf16 path (model/M3d_inference_align.py:77-210): [1x1 128 -> 256, affine, LeakyReLU] ->

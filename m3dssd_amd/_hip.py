@@ -65,6 +65,7 @@ class ConvBf16Desc(ctypes.Structure):
         ("in_group_off", c_ll), ("wgt_group_off", c_ll), ("out_group_off", c_ll),
         ("ss_group_off", c_int),
         ("wgt_f16", c_void_p), ("dcn_ws", c_void_p), ("dcn_ws_bytes", c_ll),
+        ("wgt_wave", c_void_p),
     ]
 
 

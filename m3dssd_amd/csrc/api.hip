@@ -14,7 +14,7 @@ void m3d_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *m3d_last_error(void) { return g_err; }
-extern "C" int m3d_abi_version(void) { return 3; }
+extern "C" int m3d_abi_version(void) { return 4; }
 
 // ------------------------------------------------------------------------------------------
 extern "C" int m3d_event_create(void **ev)

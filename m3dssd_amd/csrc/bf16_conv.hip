@@ -620,6 +620,7 @@ extern "C" int m3d_conv_bf16_variant(const m3d_conv_bf16_desc *d)
         const int pv = dcn_patch_variant(d);
         return pv == 16 ? 4 : (pv == 8 ? 3 : 0);
     }
+    if (conv_wide_applicable(d)) return 5;
     return conv_bf16_variant(d, nullptr);
 }
 
@@ -668,6 +669,7 @@ extern "C" int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t s
     const dim3 grid(a.tiles_m * a.tiles_n, d->groups), block(256);
     hipStream_t st = (hipStream_t)stream;
     const bool deform = d->dcn_offmask != nullptr;
+    if (conv_wide_applicable(d)) return launch_conv_wide(a, d, st);      // 128 x 128 wave tiles (bf16_conv_wide.hip)
     long long htiles = 0;
     const int variant = conv_bf16_variant(d, &htiles);
     a.lane_perm = (halo_env() & 16) ? 0 : 1;

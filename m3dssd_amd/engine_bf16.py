@@ -28,6 +28,7 @@ BF16 = torch.bfloat16
 FUSED_ANAB = os.environ.get("M3D_BF16_FUSED_ANAB", "1") != "0"
 KV_BF16 = os.environ.get("M3D_BF16_KV_BF16", "1") != "0"
 FUSED_HEADS = os.environ.get("M3D_BF16_FUSED_HEADS", "1") != "0"
+USE_WIDE = os.environ.get("M3D_BF16_WIDE", "1") != "0"       # 3x3 layers on the 128 x 128 wave-tile kernel where it applies
 FUSED_FRONT = os.environ.get("M3D_BF16_FUSED_FRONT", "1") != "0"
 
 
@@ -86,6 +87,16 @@ class PackedBf16:
         if getattr(self, "_wp16", None) is None:
             self._wp16 = self.wp.float().to(torch.float16).contiguous()
         return self._wp16
+
+    def wave3x3(self):
+        """The 3x3 weights in the fragment order of csrc/bf16_conv_wide.hip: [Cout_pad/128][Cin/32][9 taps][2 K-steps of 16][4 blocks of
+        32 channels][64 lanes][8], lane = 32 * ((c % 16) / 8) + (channel % 32); None where the kernel does not apply."""
+        if getattr(self, "_wave", None) is None:
+            if self.kh != 3 or self.kw != 3 or self.cin % 32 or self.cout_pad % 128:
+                return None
+            w = self.wp[:, :9 * self.cin].reshape(self.cout_pad // 128, 4, 32, 9, self.cin // 32, 2, 2, 8)   # g, ct, r, tap, ch, ks, h, e
+            self._wave = w.permute(0, 4, 3, 5, 1, 6, 2, 7).contiguous()
+        return self._wave
 
     def __init__(self, eng, weight, bias=None, bn=None, cout_pad=None):
         dev = eng.device
@@ -212,7 +223,7 @@ class EngineBF16(Engine):
 
     def _conv16(self, plan, name, x, out=None, wgt=None, kpad=None, cout=None, cout_pad=None, kh=1, kw=1, stride=1, pad=0,
                 scale=None, shift=None, act=0, res=None, res_mode=0, sigmoid_from=-1, om=None, out_mode=0, planar=None,
-                wgt_img_stride=0, groups=1, in_goff=0, wgt_goff=0, out_goff=0, ss_goff=0, cin=None, flops_cin=None, wgt_f16=None):
+                wgt_img_stride=0, groups=1, in_goff=0, wgt_goff=0, out_goff=0, ss_goff=0, cin=None, flops_cin=None, wgt_f16=None, wgt_wave=None):
         """One m3d_conv_bf16_forward launch appended to the plan.  x: View16 (bf16); out: View16 (bf16 or fp32 NHWC) or
         planar = (tensor, img_stride, channel offset) for the fp32 planar staging of the head outputs."""
         d = ConvBf16Desc()
@@ -245,13 +256,18 @@ class EngineBF16(Engine):
                 ws = torch.zeros(256, device=self.device, dtype=torch.int32)
                 plan.keep += [wgt_f16, ws]
                 d.wgt_f16, d.dcn_ws, d.dcn_ws_bytes = wgt_f16.data_ptr(), ws.data_ptr(), ws.numel() * 4
+        elif wgt_wave is not None:
+            plan.keep.append(wgt_wave)       # 128 x 128 wave-tile kernel (csrc/bf16_conv_wide.hip) where the library finds it applicable
+            d.wgt_wave = wgt_wave.data_ptr()
         d.groups, d.in_group_off, d.wgt_group_off, d.out_group_off, d.ss_group_off = groups, in_goff, wgt_goff, out_goff, ss_goff
         L = self.L
         ref = ctypes.byref(d)
         flops = 2.0 * x.n * d.Ho * d.Wo * cout * kh * kw * (flops_cin if flops_cin is not None else cin) * groups
         bn = 128 if cout_pad % 128 == 0 else (64 if cout_pad % 64 == 0 else 32)
         variant = L.m3d_conv_bf16_variant(ref)          # which kernel the library runs for this descriptor
-        if variant >= 3:
+        if variant == 5:
+            kind = "bf16_wide<128,128>"                           # 3x3 with 128-pixel x 128-channel wave tiles
+        elif variant >= 3:
             kind = "bf16_dcn_patch<%d>" % (8 * (variant - 2))     # LDS-patch DCNv2 (+ the gated implicit-GEMM fallback behind it)
         elif variant:
             kind = "bf16_halo<%d,%d>" % (bn, 16 * variant)
@@ -265,7 +281,9 @@ class EngineBF16(Engine):
                      stride=stride, pad=pad, scale=pc.scale if (affine and pc.has_affine) else None,
                      shift=pc.shift if (affine and pc.has_affine) else None, act=act, res=res, res_mode=res_mode,
                      sigmoid_from=sigmoid_from, om=om, out_mode=out_mode, cin=pc.cin,
-                     wgt_f16=pc.f16() if (om is not None and patch) else None)
+                     wgt_f16=pc.f16() if (om is not None and patch) else None,
+                     wgt_wave=pc.wave3x3() if (USE_WIDE and om is None and stride == 1 and pad == 1 and out_mode == 0
+                                               and sigmoid_from < 0 and x.c == pc.cin) else None)
 
     # ------------------------------------------------------------------ plan construction
     def _build_plan(self, B, H, W):

@@ -60,7 +60,7 @@ def _nhwc16(x, cs=None):
 
 
 def _run_conv(x, wt, bias=None, bn=None, stride=1, pad=0, act=0, res=None, res_mode=0, sigmoid_from=-1, out_mode=0, om=None,
-              in_cs=None, variant=None, patch=False):
+              in_cs=None, variant=None, patch=False, wide=False):
     """Through the C ABI.  Returns [N, Cout, Ho, Wo] fp32 (bf16 outputs widened)."""
     from m3dssd_amd import _hip
     from m3dssd_amd.engine_bf16 import pack_conv_bf16
@@ -92,6 +92,11 @@ def _run_conv(x, wt, bias=None, bn=None, stride=1, pad=0, act=0, res=None, res_m
         d.res, d.res_cs, d.res_mode = r.data_ptr(), r.shape[3], res_mode
         keep.append(r)
     d.act, d.sigmoid_from, d.groups = act, sigmoid_from, 1
+    if wide:                # 128 x 128 wave-tile kernel: the same weights in fragment order (engine_bf16.PackedBf16.wave3x3)
+        cop = wp.shape[0]
+        wv = wp[:, :9 * c].reshape(cop // 128, 4, 32, 9, c // 32, 2, 2, 8).permute(0, 4, 3, 5, 1, 6, 2, 7).contiguous()
+        d.wgt_wave = wv.data_ptr()
+        keep.append(wv)
     if om is not None:
         o = om.to(dev).contiguous()
         d.dcn_offmask, d.dcn_om_cs = o.data_ptr(), o.shape[-1]
@@ -209,6 +214,52 @@ def test_conv_bf16_halo_tile_matches_torch(case):
     got = _run_conv(x, wt, bias, None, 1, 1, act, res, 0, sg, om, in_cs=c + 8, variant=variant)
     assert got.shape == ref.shape
     _check(got, ref, om)
+
+
+WIDE_CASES = [
+    # n, c, h, w, co, act, res, bn
+    (1, 64, 8, 16, 128, 0, False, False),            # one patch, two chunks (the minimum): every patch border is an image border
+    (2, 64, 16, 32, 128, 1, True, True),             # 2 x 2 patches per image, two chunks, residual + BN + LeakyReLU
+    (3, 128, 24, 48, 256, 1, True, True),            # two channel groups, four chunks, 27 patches (ragged last workgroup)
+    (1, 64, 8, 48, 100, 1, False, True),             # Cout 100 (pad 128)
+    (5, 256, 24, 80, 256, 1, True, True),            # level4 geometry
+    (2, 128, 48, 160, 128, 1, True, True),           # level3 geometry
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES)
+def test_conv_bf16_wide_tile_matches_torch(case):
+    """3x3 / stride 1 / pad 1 on the 128-pixel x 128-channel wave-tile kernel (csrc/bf16_conv_wide.hip: per-wave input patch in LDS,
+    weights global -> register in fragment order, K order (chunk of 32, tap, 16)) against torch on the bf16-rounded operands, and
+    bitwise against a second launch."""
+    n, c, h, w, co, act, use_res, use_bn = case
+    g = torch.Generator().manual_seed(sum(case) + 9)
+    x = _r(torch.randn(n, c, h, w, generator=g))
+    wt = _r(torch.randn(co, c, 3, 3, generator=g) / (c * 9) ** 0.5)
+    bias = torch.randn(co, generator=g) * 0.1
+    bn = (torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.1, torch.randn(co, generator=g) * 0.1,
+          torch.rand(co, generator=g) + 0.5) if use_bn else None
+    res = _r(torch.randn(n, co, h, w, generator=g)) if use_res else None
+    ref = F.conv2d(x, wt, bias, padding=1)
+    if bn is not None:
+        ref = F.batch_norm(ref, bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)
+    if res is not None:
+        ref = ref + res
+    if act:
+        ref = F.leaky_relu(ref, 0.01)
+    got = _run_conv(x, wt, bias, bn, 1, 1, act, res, 0, -1, 0, in_cs=c + 8, variant=5, wide=True)
+    assert got.shape == ref.shape
+    _check(got, ref, 0)
+    again = _run_conv(x, wt, bias, bn, 1, 1, act, res, 0, -1, 0, in_cs=c + 8, variant=5, wide=True)
+    assert torch.equal(got, again)
+    # res_mode 1 ((acc + res) * scale + shift): the other place the residual enters
+    if use_res and bn is not None:
+        s = bn[0] / torch.sqrt(bn[3] + 1e-5)
+        ref1 = (F.conv2d(x, wt, None, padding=1) + res) * s.view(1, -1, 1, 1) + ((bias - bn[2]) * s + bn[1]).view(1, -1, 1, 1)
+        if act:
+            ref1 = F.leaky_relu(ref1, 0.01)
+        got1 = _run_conv(x, wt, bias, bn, 1, 1, act, res, 1, -1, 0, in_cs=c + 8, variant=5, wide=True)
+        _check(got1, ref1, 0)
 
 
 def test_dcn_bf16_run_to_run_identical():

@@ -37,7 +37,7 @@ def _relerr(a, b):
 def test_library_loads_and_reports_errors():
     from m3dssd_amd import _hip
     L = _hip.lib()
-    assert L.m3d_abi_version() == 3
+    assert L.m3d_abi_version() == 4
     d = _hip.ConvDesc()
     assert L.m3d_conv2d_forward(d, None) != 0          # null pointers -> M3D_E_ARG, no crash
     assert b"null" in L.m3d_last_error()
