@@ -34,7 +34,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming copy)
 CROP = (384, 1280)
 PER_GPU_BATCH = 8
-MFMA_FAMILIES = ("igemm", "wino", "head_mlp", "conv_wave", "bf16_conv", "bf16_halo", "bf16_anab", "bf16_dcn_patch")
+MFMA_FAMILIES = ("igemm", "wino", "head_mlp", "conv_wave", "bf16_conv", "bf16_halo", "bf16_wide", "bf16_anab", "bf16_dcn_patch")
 
 
 def _cpu_model():
@@ -91,6 +91,8 @@ def kernel_symbol(label):
     if label.startswith("bf16_dcn_patch"):
         th = re.findall(r"\d+", label.split("<", 1)[1])[0]
         return "void bf16_dcn_patch_kernel<%s, %s>(Bf16Args, void const*, unsigned int const*)" % (th, "9, 3" if th == "16" else "6, 1")
+    if label.startswith("bf16_wide"):              # (two instantiations, with / without a residual: the one without stands for the family)
+        return "void bf16_conv3x3_wide_kernel<false>(WideArgs)"
     if label.startswith("bf16_halo"):
         bn, tw = re.findall(r"\d+", label.split("<", 1)[1])[:2]
         return "void bf16_conv3x3_halo_kernel<%s, %s, %d, %d, %d>(Bf16Args)" % (bn, tw, 8 * int(tw), 4 if tw == "16" else 8,
