@@ -100,6 +100,8 @@ def kernel_symbol(label):
     if label.startswith("bf16_conv"):
         return "void bf16_conv_kernel<%s, %s>(Bf16Args)" % (re.findall(r"\d+", label.split("<", 1)[1])[0],
                                                             "true" if "deform" in label else "false")
+    if label.startswith("wino44_c16"):
+        return "wino44_c16_kernel(Wino44C16Args)"
     if label.startswith("wino44"):                 # wino44<16,32[,splitkN]>: 16 tiles x 32 (NB = 2) or 16 (NB = 1) channels per wave
         return "void wino44_kernel<%d>(Wino44Args)" % (int(re.findall(r"\d+", label)[2]) // 16)
     if label.startswith("wino_wave"):

@@ -343,6 +343,11 @@ int m3d_stem_conv7x7_u8(const unsigned char *frames_bgr, int img_h, int img_w, c
  * wgt [(i*3+j)*16 + cin][16 cout], fused affine (folded BN) + LeakyReLU. */
 int m3d_conv3x3_c16(const float *in, int in_cs, const float *wgt, const float *scale, const float *shift, float *out,
                     int out_cs, int N, int H, int W, m3d_stream_t stream);
+/* The same layer as Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32 (csrc/wino44_conv.hip: 4x fewer MFMA FLOPs; fp32 rounding ~7x
+ * that of direct summation, as for m3d_wino44_conv3x3_forward): `U` = G g G^T of the 16 x 16 filters packed [36 xi][64 lanes =
+ * 16 * (cin / 4) + cout][cin % 4] (m3dssd_amd/engine.py:pack_wino44_c16); H % 4 == W % 4 == 0. */
+int m3d_conv3x3_c16_wino(const float *in, int in_cs, const float *U, const float *scale, const float *shift, float *out,
+                         int out_cs, int N, int H, int W, m3d_stream_t stream);
 int m3d_maxpool2x2(const float *in, int in_cs, float *out, int out_cs, int N, int H, int W, int C,
                    m3d_stream_t stream);
 /* out = ConvTranspose2d_depthwise(in, wgt[4][4][C], stride 2, pad 1) + skip ;  in is [N,H,W,C], out/skip [N,2H,2W,C] */

@@ -130,6 +130,7 @@ SIGNATURES = {
     "m3d_stem_conv7x7_u8": (c_int, [P, c_int, c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), P, P, P, P,
                                     c_int, c_int, c_int, c_int, P]),
     "m3d_conv3x3_c16": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "m3d_conv3x3_c16_wino": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "m3d_maxpool2x2": (c_int, [P, c_int, P, c_int] + [c_int] * 4 + [P]),
     "m3d_upsample2x_add": (c_int, [P, c_int, P, P, c_int, P, c_int] + [c_int] * 4 + [P]),
     "m3d_anchor_select": (c_int, [P] + [c_int] * 4 + [P, P, P, P]),

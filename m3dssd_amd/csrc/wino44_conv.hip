@@ -444,6 +444,147 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     W44_TRACE();
 }
 
+// ---- F(4x4,3x3) for the 16 -> 16 full-resolution layer (DLA level0, pose_dla_dcn.py:341-342) -------------------------------------
+// One stage (16 input channels), 16 output channels = exactly the N of v_mfma_f32_16x16x4_f32: no K loop, three phases through LDS.
+//   1. thread (tile, input channel) of a 16-tile strip: 6x6 patch (36 dword loads, borders through the buffer range check), B^T d B,
+//      36 values to V[xi][tile][channel];
+//   2. wave w takes the transform positions 9w .. 9w + 8: A = V[xi] (one ds_read_b128 per lane), B = U[xi] (9 fragments per lane,
+//      held in registers), 4 MFMAs, and M[xi][tile][cout] goes back into the SAME 1 KB of LDS -- V[xi] is read by this wave only;
+//   3. thread (tile, output channel): 36 values, A^T m A, folded BatchNorm + LeakyReLU, 16 pixels x 4 bytes (the 16 channels of a
+//      pixel are 64 contiguous bytes across the lanes).
+// 36 KB of LDS, ~100 registers: four workgroups per CU cover each other's phases.  The direct MFMA kernel (backbone_kernels.hip) is
+// bound by its 576 MFMAs per 256 pixels (144 here) and runs 0.18 ms at bs 8; this one 0.14 ms (~550 VALU / LDS / memory
+// instructions per thread; HBM floor 252 MB in + 252 MB out = 0.063 ms).
+__device__ __forceinline__ void w44_at1(const float m0, const float m1, const float m2, const float m3, const float m4, const float m5,
+                                        float &y0, float &y1, float &y2, float &y3)
+{
+    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+    y0 = m0 + s1 + s2;
+    y1 = fmaf(2.f, d2, d1);
+    y2 = fmaf(4.f, s2, s1);
+    y3 = fmaf(8.f, d2, d1) + m5;
+}
+
+struct Wino44C16Args {
+    const float *in, *U, *scale, *shift;
+    float *out;
+    int in_cs, out_cs;
+    unsigned in_bytes, out_bytes;
+    int H, W, TH, TW, NT;
+};
+
+__global__ __launch_bounds__(256) void wino44_c16_kernel(const Wino44C16Args a)
+{
+    __shared__ __attribute__((aligned(16))) float Vs[36 * 256];          // V[xi][tile][channel], then M[xi][tile][cout]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ut = tid >> 4, uc = tid & 15;
+    // B fragments of this wave's nine positions: U packed [xi][lane = 16 (cin / 4) + cout][cin % 4]
+    f32x4 ub[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ub[k] = *reinterpret_cast<const f32x4 *>(a.U + ((wave * 9 + k) * 64 + lane) * 4);
+
+    // ---- phase 1: patch of (tile ut, channel uc) ----------------------------------------------------------------------------------
+    // (an XCD-aware strip order -- contiguous strip ranges per XCD, for L2 hits on the shared halo rows -- measured the same)
+    const int t = blockIdx.x * 16 + ut;
+    const bool tv = t < a.NT;
+    const int tt = tv ? t : 0;
+    const int n = tt / (a.TH * a.TW), rem = tt - n * a.TH * a.TW;
+    const int ty = rem / a.TW, tx = rem - ty * a.TW;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
+    const unsigned cs4 = (unsigned)a.in_cs * 4u;
+    float d[36];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const int hi = 4 * ty - 1 + r;
+        const bool ok = tv && hi >= 0 && hi < a.H;
+        const unsigned base = ((unsigned)((n * a.H + hi) * a.W + 4 * tx) * (unsigned)a.in_cs + (unsigned)uc) * 4u;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const bool cok = ok && (c > 0 || tx > 0) && (c < 5 || 4 * tx + 4 < a.W);
+            d[r * 6 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, cok ? base + (unsigned)(c - 1) * cs4 : M3D_BUF_OOB, 0, 0));
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        float t0, t1, t2, t3, t4, t5;
+        w44_bt(d[0 * 6 + c], d[1 * 6 + c], d[2 * 6 + c], d[3 * 6 + c], d[4 * 6 + c], d[5 * 6 + c], t0, t1, t2, t3, t4, t5);
+        d[0 * 6 + c] = t0; d[1 * 6 + c] = t1; d[2 * 6 + c] = t2; d[3 * 6 + c] = t3; d[4 * 6 + c] = t4; d[5 * 6 + c] = t5;
+    }
+    float *vb = Vs + ut * 16 + uc;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        float v[6];
+        w44_bt(d[r * 6 + 0], d[r * 6 + 1], d[r * 6 + 2], d[r * 6 + 3], d[r * 6 + 4], d[r * 6 + 5], v[0], v[1], v[2], v[3], v[4], v[5]);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) vb[(r * 6 + c) * 256] = v[c];
+    }
+    __syncthreads();
+
+    // ---- phase 2: positions 9 wave .. 9 wave + 8: M[xi] = V[xi] (16 tiles x 16 channels) x U[xi] (16 x 16), in place -----------------
+    {
+        const int atile = lane & 15, aq = lane >> 4;
+        float *slot = Vs + wave * 9 * 256;
+        f32x4 av[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) av[k] = *reinterpret_cast<const f32x4 *>(slot + k * 256 + atile * 16 + aq * 4);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k][e], ub[k][e], acc, 0, 0, 0);
+            // D: lane = cout (lane & 15), registers = tiles 4 aq + i
+#pragma unroll
+            for (int i = 0; i < 4; ++i) slot[k * 256 + (4 * aq + i) * 16 + atile] = acc[i];
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: A^T m A of (tile ut, cout uc), affine, LeakyReLU, 16 pixels ----------------------------------------------------------
+    {
+        float m[36];
+#pragma unroll
+        for (int x = 0; x < 36; ++x) m[x] = Vs[x * 256 + ut * 16 + uc];
+        float z[4][6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b)
+            w44_at1(m[0 * 6 + b], m[1 * 6 + b], m[2 * 6 + b], m[3 * 6 + b], m[4 * 6 + b], m[5 * 6 + b], z[0][b], z[1][b], z[2][b], z[3][b]);
+        const float sc = a.scale[uc], sh = a.shift[uc];
+        const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out, a.out_bytes);
+        const unsigned obase = tv ? ((unsigned)((n * a.H + 4 * ty) * a.W + 4 * tx) * (unsigned)a.out_cs + (unsigned)uc) * 4u : M3D_BUF_OOB;
+        const unsigned ocs4 = (unsigned)a.out_cs * 4u;
+#pragma unroll
+        for (int yy = 0; yy < 4; ++yy) {
+            float y[4];
+            w44_at1(z[yy][0], z[yy][1], z[yy][2], z[yy][3], z[yy][4], z[yy][5], y[0], y[1], y[2], y[3]);
+#pragma unroll
+            for (int xx = 0; xx < 4; ++xx) {
+                float v = fmaf(y[xx], sc, sh);
+                v = fmaxf(v, v * M3D_LEAKY_SLOPE);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, obase + (unsigned)(yy * a.W + xx) * ocs4, 0, 0);
+            }
+        }
+    }
+}
+
+// level0 on the F(4x4,3x3) kernel: `U` = G g G^T packed [36][64 lanes = 16 (cin / 4) + cout][cin % 4] (m3dssd_amd/engine.py:pack_wino44_c16)
+extern "C" int m3d_conv3x3_c16_wino(const float *in, int in_cs, const float *U, const float *scale, const float *shift, float *out,
+                                    int out_cs, int N, int H, int W, m3d_stream_t stream)
+{
+    M3D_REQUIRE(in && U && scale && shift && out && in_cs >= 16 && out_cs >= 16 && N >= 1, "conv3x3_c16_wino: bad arguments");
+    M3D_REQUIRE(H % 4 == 0 && W % 4 == 0 && H >= 4 && W >= 4, "conv3x3_c16_wino: H and W must be multiples of 4");
+    M3D_REQUIRE(((uintptr_t)U & 15) == 0, "conv3x3_c16_wino: U must be 16-byte aligned");
+    const long long ib = (long long)N * H * W * in_cs * 4, ob = (long long)N * H * W * out_cs * 4;
+    M3D_REQUIRE(ib < (1ll << 31) && ob < (1ll << 31), "conv3x3_c16_wino: views must be < 2 GiB");
+    Wino44C16Args a;
+    a.in = in; a.U = U; a.scale = scale; a.shift = shift; a.out = out; a.in_cs = in_cs; a.out_cs = out_cs;
+    a.in_bytes = (unsigned)ib; a.out_bytes = (unsigned)ob;
+    a.H = H; a.W = W; a.TH = H / 4; a.TW = W / 4; a.NT = N * a.TH * a.TW;
+    hipLaunchKernelGGL(wino44_c16_kernel, dim3(cdiv(a.NT, 16)), dim3(256), 0, (hipStream_t)stream, a);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
 // 1 if the F(4x4,3x3) kernel serves the descriptor (geometry only; the caller passes U44-packed weights in d->wgt)
 extern "C" int m3d_wino44_applicable(const m3d_conv_desc *d)
 {

@@ -149,6 +149,14 @@ def pack_wino44(weight, cout_pad, device):
     return u.to(torch.float32).reshape(-1).to(device)
 
 
+def pack_wino44_c16(weight, device):
+    """[16, 16, 3, 3] -> U = G g G^T for m3d_conv3x3_c16_wino (DLA level0): [36 xi][64 lanes = 16 (cin / 4) + cout][cin % 4], fp64 -> fp32."""
+    g = weight.detach().to("cpu", torch.float64)
+    assert tuple(g.shape) == (16, 16, 3, 3)
+    u = torch.einsum("ai,ocij,bj->abco", _WINO44_G, g, _WINO44_G).reshape(36, 4, 4, 16)      # xi, cin / 4, cin % 4, cout
+    return u.permute(0, 1, 3, 2).contiguous().to(torch.float32).reshape(-1).to(device)
+
+
 WINO_MIN_BLOCKS = int(os.environ.get("M3D_WINO_MIN_BLOCKS", "128"))
 USE_ANAB_WAVE = os.environ.get("M3D_ANAB_WAVE", "1") != "0"
 USE_ANAB_NESTED = os.environ.get("M3D_ANAB_NESTED", "1") != "0"
@@ -221,6 +229,7 @@ class Engine:
         # level0 also as a direct VALU conv: weights [(i*3+j)*16 + cin][cout]
         w0 = sd[b + ".level0.0.weight"].detach().to(dev, torch.float32)
         P["level0.direct"] = w0.permute(2, 3, 1, 0).contiguous() if tuple(w0.shape) == (16, 16, 3, 3) else None
+        P["level0.wino44"] = pack_wino44_c16(w0, self.device) if (USE_WINO44 and tuple(w0.shape) == (16, 16, 3, 3)) else None
         P["level1"] = self._pc(b + ".level1.0", b + ".level1.1")
 
         def block(p):
@@ -490,7 +499,12 @@ class Engine:
                                               P["stem.shift"].data_ptr(), s0.ptr, s0.cs, B, H, W, st))
         self._op(plan, "stem", "stem", stem)
         l0 = self._buf(plan, B, H, W, 16, name="level0")
-        if P["level0.direct"] is not None and os.environ.get("M3D_LEVEL0_IGEMM", "0") != "1":
+        if P.get("level0.wino44") is not None and H % 4 == 0 and W % 4 == 0 and os.environ.get("M3D_LEVEL0_WINO44", "1") != "0":
+            pc0 = P["level0"]       # F(4x4,3x3) on 16x16x4 MFMAs: 144 MFMAs per 256 pixels instead of 576 (csrc/wino44_conv.hip)
+            self._op(plan, "level0", "wino44_c16", lambda st: _hip.check(L.m3d_conv3x3_c16_wino(
+                s0.ptr, s0.cs, P["level0.wino44"].data_ptr(), pc0.scale.data_ptr(), pc0.shift.data_ptr(), l0.ptr, l0.cs,
+                B, H, W, st)))
+        elif P["level0.direct"] is not None and os.environ.get("M3D_LEVEL0_IGEMM", "0") != "1":
             pc0 = P["level0"]
             self._op(plan, "level0", "conv3x3_c16", lambda st: _hip.check(L.m3d_conv3x3_c16(
                 s0.ptr, s0.cs, P["level0.direct"].data_ptr(), pc0.scale.data_ptr(), pc0.shift.data_ptr(), l0.ptr, l0.cs,

@@ -418,6 +418,43 @@ def test_winograd_f4x4_splitk_matches_torch(case, want):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("shape", [(1, 4, 4), (2, 8, 12), (3, 20, 36), (1, 48, 160), (2, 384, 1280)])
+def test_level0_winograd_f4x4_matches_torch(shape):
+    """m3d_conv3x3_c16_wino (DLA level0, 3x3 16 -> 16 + folded BN + LeakyReLU as F(4x4,3x3) in three LDS phases) vs F.conv2d in
+    fp64 and vs the direct kernel m3d_conv3x3_c16 on the same operands; one tile, ragged 16-tile strips, strips that cross image
+    rows / images, the full 1280x384 frame."""
+    import torch.nn.functional as F
+    from m3dssd_amd import _hip
+    from m3dssd_amd.engine import pack_wino44_c16
+    L = _hip.lib()
+    dev = _dev()
+    n, h, w = shape
+    g = torch.Generator().manual_seed(h * 7 + w)
+    x = torch.randn(n, 16, h, w, generator=g)
+    wt = torch.randn(16, 16, 3, 3, generator=g) / 12.0
+    sc = torch.rand(16, generator=g) + 0.5
+    sh = torch.randn(16, generator=g) * 0.2
+    ref = F.leaky_relu(F.conv2d(x.double(), wt.double(), padding=1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1), 0.01).float()
+    xin = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    U = pack_wino44_c16(wt, dev)
+    wd = wt.permute(2, 3, 1, 0).contiguous().to(dev)
+    scd, shd = sc.to(dev), sh.to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for fn, wgt in ((L.m3d_conv3x3_c16_wino, U), (L.m3d_conv3x3_c16, wd)):
+        out = torch.full((n, h, w, 16), 777.0, device=dev)
+        _hip.check(fn(xin.data_ptr(), 16, wgt.data_ptr(), scd.data_ptr(), shd.data_ptr(), out.data_ptr(), 16, n, h, w, st))
+        torch.cuda.synchronize()
+        outs.append(out.permute(0, 3, 1, 2).cpu())
+    e44 = ((outs[0] - ref).abs() / (1 + ref.abs())).max().item()
+    edir = ((outs[1] - ref).abs() / (1 + ref.abs())).max().item()
+    assert e44 < 2e-4 and edir < 2e-5, (e44, edir)
+    again = torch.full((n, h, w, 16), 777.0, device=dev)
+    _hip.check(L.m3d_conv3x3_c16_wino(xin.data_ptr(), 16, U.data_ptr(), scd.data_ptr(), shd.data_ptr(), again.data_ptr(), 16, n, h, w, st))
+    torch.cuda.synchronize()
+    assert torch.equal(again.permute(0, 3, 1, 2).cpu(), outs[0])
+
+
 # ------------------------------------------------------------------------------------ NMS beyond the device reduce's 4096 rows
 @pytest.mark.parametrize("n", [4097, 6000, 12000])
 def test_nms_twin_has_no_row_limit(n):
