@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 //   3. thread (tile, output channel): 36 values, A^T m A, folded BatchNorm + LeakyReLU, 16 pixels x 4 bytes (the 16 channels of a
 //      pixel are 64 contiguous bytes across the lanes).
 // 36 KB of LDS, ~100 registers: four workgroups per CU cover each other's phases.  The direct MFMA kernel (backbone_kernels.hip) is
-// bound by its 576 MFMAs per 256 pixels (144 here) and runs 0.18 ms at bs 8; this one 0.14 ms (~550 VALU / LDS / memory
+// bound by its 576 MFMAs per 256 pixels (144 here) and runs 0.18 ms at bs 8; this one 0.12 ms (~450 VALU / LDS / memory
 // instructions per thread; HBM floor 252 MB in + 252 MB out = 0.063 ms).
 __device__ __forceinline__ void w44_at1(const float m0, const float m1, const float m2, const float m3, const float m4, const float m5,
                                         float &y0, float &y1, float &y2, float &y3)
@@ -494,16 +494,26 @@ __global__ __launch_bounds__(256) void wino44_c16_kernel(const Wino44C16Args a)
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
     const unsigned cs4 = (unsigned)a.in_cs * 4u;
     float d[36];
+    {
+        // lane offsets of the tile's own first pixel (patch row 1, column 1) and of the three border origins (row 0, column 0, the
+        // corner: out of range where the image ends -- the range check looks at the lane offset alone, so it must never wrap); the
+        // (row, column) part of the address rides in the SGPR offset of the load: no per-load integer multiplies
+        const unsigned org = tv ? ((unsigned)((n * a.H + 4 * ty) * a.W + 4 * tx) * (unsigned)a.in_cs + (unsigned)uc) * 4u : M3D_BUF_OOB;
+        const bool r0ok = tv && ty > 0, r5ok = 4 * ty + 4 < a.H, c0ok = tv && tx > 0, c5ok = 4 * tx + 4 < a.W;
+        const unsigned rowb = (unsigned)a.W * cs4;
+        const unsigned orgR = r0ok ? org - rowb : M3D_BUF_OOB, orgC = c0ok ? org - cs4 : M3D_BUF_OOB;
+        const unsigned orgRC = (r0ok && c0ok) ? org - rowb - cs4 : M3D_BUF_OOB;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-        const int hi = 4 * ty - 1 + r;
-        const bool ok = tv && hi >= 0 && hi < a.H;
-        const unsigned base = ((unsigned)((n * a.H + hi) * a.W + 4 * tx) * (unsigned)a.in_cs + (unsigned)uc) * 4u;
+        for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            const bool cok = ok && (c > 0 || tx > 0) && (c < 5 || 4 * tx + 4 < a.W);
-            d[r * 6 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, cok ? base + (unsigned)(c - 1) * cs4 : M3D_BUF_OOB, 0, 0));
-        }
+            for (int c = 0; c < 6; ++c) {
+                unsigned vo = (r == 0 && c == 0) ? orgRC : (r == 0 ? orgR : (c == 0 ? orgC : org));
+                if (r == 5) vo = r5ok ? vo : M3D_BUF_OOB;
+                if (c == 5) vo = c5ok ? vo : M3D_BUF_OOB;
+                const int rr = r == 0 ? 0 : r - 1, cc = c == 0 ? 0 : c - 1;
+                const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(rr * a.W + cc) * cs4;
+                d[r * 6 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, vo, so, 0));
+            }
     }
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
@@ -561,7 +571,8 @@ __global__ __launch_bounds__(256) void wino44_c16_kernel(const Wino44C16Args a)
             for (int xx = 0; xx < 4; ++xx) {
                 float v = fmaf(y[xx], sc, sh);
                 v = fmaxf(v, v * M3D_LEAKY_SLOPE);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, obase + (unsigned)(yy * a.W + xx) * ocs4, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, obase,
+                                                      (unsigned)__builtin_amdgcn_readfirstlane(yy * a.W + xx) * ocs4, 0);
             }
         }
     }
