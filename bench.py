@@ -34,7 +34,12 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming copy)
 CROP = (384, 1280)
 PER_GPU_BATCH = 8
-MFMA_FAMILIES = ("igemm", "wino", "head_mlp", "conv_wave", "bf16_conv", "bf16_halo", "bf16_wide", "bf16_anab", "bf16_dcn_patch")
+MFMA_FAMILIES = ("igemm", "wino", "head_mlp", "conv_wave", "bf16_conv", "bf16_halo", "bf16_wide", "bf16_anab", "bf16_dcn_patch",
+                 "bf16_head_mlp", "bf16_frontend")
+# SURVEY 8d, per image: 105.8 GFLOP; activations 1003.6 MB (fp32) + outputs 21 MB + input 5.9 MB; weights 82.6 MB (fp32) per batch
+ALG_GFLOP_PER_IMAGE = 105.8
+ALG_MB_PER_IMAGE_F32 = 1003.6 + 21.0 + 5.9
+ALG_MB_WEIGHTS_F32 = 82.6
 
 
 def _cpu_model():
@@ -47,40 +52,85 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(sd, budget_s=10.0):
-    """Oracle forward + decode + NMS on the host cores at bs = 1 and at the benched bs = 8 (bounded samples)."""
+def _cpu_worker(spec):
+    """`python bench.py --cpu-worker i,K,threads,budget_s`: one of K oracle processes of the whole-host CPU baseline, pinned to its
+    own core set; prints {"frames": n, "seconds": dt} (frames at bs = 1: K frames are in flight on the host at any time)."""
+    i, K, threads, budget = spec.split(",")
+    i, K, threads, budget = int(i), int(K), int(threads), float(budget)
+    cpus = sorted(os.sched_getaffinity(0))
+    per = max(1, len(cpus) // K)
+    mine = cpus[i * per:(i + 1) * per] or cpus
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        pass
+    torch.set_num_threads(min(threads, len(mine)))
     from m3dssd_amd import synth
     from oracle import detect as odet
     from oracle import model_cpu
-    host = os.cpu_count() or 1
-    threads = min(32, host)                  # torch-CPU conv on these maps stops scaling (and then degrades) past ~32 threads
-    torch.set_num_threads(threads)
-    sd_cpu = {k: v.cpu() for k, v in sd.items()}
-    res = {}
-    for bs in (1, PER_GPU_BATCH):
-        conf_cpu = synth.synth_conf(CROP, 0, batch_size=bs, device="cpu")
-        x = synth.synth_frames(bs, CROP, 99)
+    sd = synth.synth_state_dict(0)
+    conf = synth.synth_conf(CROP, 0, batch_size=1, device="cpu")
+    x = synth.synth_frames(1, CROP, 99 + i)
 
-        def one():
-            with torch.no_grad():
-                cls, prob, b2, b3, fs, rois = model_cpu.rpn_forward(sd_cpu, conf_cpu, x)
-                for i in range(bs):
-                    odet.detect_image(prob[i], b2[i], b3[i], rois, conf_cpu)
-        one()                               # warm-up (also builds liboracle.so if needed)
-        n, t0 = 0, time.perf_counter()
-        while True:
-            one()
-            n += 1
-            dt = time.perf_counter() - t0
-            if dt >= budget_s or n >= 50:
-                break
-        res[bs] = (bs * n / dt, n, dt)
-    v8, n8, t8 = res[PER_GPU_BATCH]
-    v1, n1, t1 = res[1]
-    return {"value": round(v8, 3), "unit": "images/sec", "cores": threads, "host_cores": host, "cpu_model": _cpu_model(),
-            "kind": "port", "value_bs1": round(v1, 3),
-            "sample": "oracle forward+decode+NMS, torch-CPU %d threads of %d host cores: %d batches of bs=%d (%.1f s) -> value; "
-                      "%d frames at bs=1 (%.1f s) -> value_bs1; 1280x384" % (threads, host, n8, PER_GPU_BATCH, t8, n1, t1)}
+    def one():
+        with torch.no_grad():
+            cls, prob, b2, b3, fs, rois = model_cpu.rpn_forward(sd, conf, x)
+            odet.detect_image(prob[0], b2[0], b3[0], rois, conf)
+    one()
+    print(json.dumps({"ready": i}), flush=True)
+    sys.stdin.readline()                                     # all K workers start their timed loop together
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget or n >= 400:
+            break
+    print(json.dumps({"frames": n, "seconds": dt, "cpus": len(mine)}), flush=True)
+
+
+def cpu_baseline(sd, budget_s=12.0):
+    """Oracle forward + decode + NMS on ALL host cores: K = host_threads / 32 oracle processes pinned to disjoint
+    core sets, each with 32 torch threads at bs = 1 (the torch-CPU convolutions on these maps stop scaling past ~32 threads, and
+    one process at bs = 8 is slower per image than at bs = 1: the port's DCN im2col loops per image), all timed over the same
+    window -> `value` = aggregate images/s with K frames in flight; `value_bs1` = one such process alone on the host."""
+    import subprocess
+    host = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = min(32, host)
+    K = max(1, host // threads)
+
+    def run(k_total, budget):
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "%d,%d,%d,%g" % (i, k_total, threads, budget)],
+                                  stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env,
+                                  cwd=ROOT) for i in range(k_total)]
+        try:
+            for p in procs:                                  # wait until every worker has imported, built and warmed up
+                line = p.stdout.readline()
+                if "ready" not in line:
+                    raise RuntimeError("cpu_baseline worker failed to start")
+            for p in procs:
+                p.stdin.write("go\n")
+                p.stdin.flush()
+            res = [json.loads(p.stdout.readline()) for p in procs]
+        finally:
+            for p in procs:
+                try:
+                    p.wait(timeout=60)
+                except Exception:
+                    p.kill()
+        return res
+    alone = run(1, min(budget_s, 6.0))[0] if K > 1 else None
+    res = run(K, budget_s)
+    frames, secs = sum(r["frames"] for r in res), max(r["seconds"] for r in res)
+    out = {"value": round(frames / secs, 3), "unit": "images/sec", "cores": sum(r["cpus"] for r in res), "host_cores": host,
+           "cpu_model": _cpu_model(), "kind": "port", "processes": K, "threads_per_process": threads,
+           "sample": "oracle forward+decode+NMS (torch-CPU + oracle/*.c), 1280x384: %d processes x %d threads pinned to disjoint core "
+                     "sets, bs=1 each (%d frames in flight), %d frames in %.1f s -> value" % (K, threads, K, frames, secs)}
+    if alone is not None:
+        out["value_bs1"] = round(alone["frames"] / alone["seconds"], 3)
+        out["sample"] += "; one such process alone: %d frames in %.1f s -> value_bs1" % (alone["frames"], alone["seconds"])
+    return out
 
 
 def kernel_symbol(label):
@@ -88,6 +138,10 @@ def kernel_symbol(label):
     import re
     if label.startswith("bf16_anab"):
         return "bf16_anab_attend_kernel(AnabArgs)"
+    if label.startswith("bf16_head_mlp"):
+        return "bf16_head_mlp_kernel(HeadArgs)"
+    if label.startswith("bf16_frontend"):
+        return "bf16_frontend_kernel(FrontArgs)"
     if label.startswith("bf16_dcn_patch"):
         th = re.findall(r"\d+", label.split("<", 1)[1])[0]
         return "void bf16_dcn_patch_kernel<%s, %s>(Bf16Args, void const*, unsigned int const*)" % (th, "9, 3" if th == "16" else "6, 1")
@@ -103,7 +157,8 @@ def kernel_symbol(label):
     if label.startswith("wino44_c16"):
         return "wino44_c16_kernel(Wino44C16Args)"
     if label.startswith("wino44"):                 # wino44<16,32[,splitkN]>: 16 tiles x 32 (NB = 2) or 16 (NB = 1) channels per wave
-        return "void wino44_kernel<%d>(Wino44Args)" % (int(re.findall(r"\d+", label)[2]) // 16)
+        nb = int(re.findall(r"\d+", label)[2]) // 16   # (the 64-channel form runs two workgroups per CU unless M3D_W44_OCC2=0)
+        return "void wino44_kernel<%d, %d>(Wino44Args)" % (nb, 2 if (nb == 1 and os.environ.get("M3D_W44_OCC2", "1") != "0") else 1)
     if label.startswith("wino_wave"):
         return "void wino_wave_kernel<%s>(WinoArgs)" % ("true" if "splitk" in label else "false")
     if label.startswith("wino"):
@@ -147,6 +202,10 @@ def algorithmic_bytes(op):
     d = op[4]
     if d is None:
         return None
+    if hasattr(d, "hbm_bytes"):                           # engine.OpCost: a helper launch that states its own byte count
+        return d.hbm_bytes
+    if hasattr(d, "out_group_off") and hasattr(d, "groups") and not hasattr(d, "Kpad"):   # m3d_head_bf16_desc: G heads, one input
+        return (d.M * d.Cin * 2 + d.groups * (d.M * d.Cout * 4 + (d.Cin * 256 + 256 * 256 + 256 * d.Cout_pad) * 2))
     if hasattr(d, "Kpad"):                                # m3d_conv_bf16_desc: bf16 in / weights, bf16 or fp32 out
         g = max(d.groups, 1)
         o = d.N * d.Ho * d.Wo * d.Cout * (2 if d.out_mode == 0 else 4) * g
@@ -174,6 +233,60 @@ def algorithmic_bytes(op):
     return b
 
 
+def step_counter_bytes(families, helpers):
+    """HBM bytes of one step from the committed PMC passes: launches x traffic per launch, per family (None without any pass)."""
+    tot, have = 0.0, False
+    for v in families.values():
+        if v.get("traffic"):
+            tot += v["launches_per_step"] * v["traffic"]
+            have = True
+        elif v.get("algorithmic_bytes_per_launch"):
+            tot += v["launches_per_step"] * v["algorithmic_bytes_per_launch"]
+    for v in helpers.values():
+        if v.get("algorithmic_bytes_per_launch"):
+            tot += v["launches_per_step"] * v["algorithmic_bytes_per_launch"]
+    return int(tot) if have else None
+
+
+def rccl_proof(args, mdist, net, conf, B, rank, world, dev, last_gather):
+    """N > 1 only: evidence that the collective saw `world` distinct devices, what it costs in isolation, and that the gathered
+    block holds every rank's shard where the contract says (rank r's images at rows [r*B, (r+1)*B): rank 0 recomputes each
+    rank's batch -- seed 1234 + r -- on its own GPU and compares)."""
+    import torch.distributed as dist
+    from m3dssd_amd import synth
+    from m3dssd_amd.host.detect import detect_device, select_block
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "device_index": dev.index, "name": props.name, "uuid": str(getattr(props, "uuid", "")),
+          "pci_bus_id": getattr(props, "pci_bus_id", None), "pid": os.getpid()}
+    seen = [None] * world
+    dist.all_gather_object(seen, me)
+    dets, counts = last_gather[0].clone(), last_gather[1].clone()     # (views of the cached receive buffer: the timing loop reuses it)
+    blk = torch.zeros(B, dets.shape[1] + 1, dets.shape[2], device=dev, dtype=torch.float32)
+    for _ in range(10):
+        mdist.gather_block(blk)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(100):
+        mdist.gather_block(blk)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 10.0
+    ok, checked = True, 0
+    if rank == 0:
+        for r in range(world):
+            xr = synth.synth_frames(B, CROP, 1234 + r).to(dev)
+            blk_r, cnt_r = select_block(*detect_device(net, xr, conf), conf)
+            same = torch.equal(blk_r[:, :-1], dets[r * B:(r + 1) * B]) and torch.equal(cnt_r, counts[r * B:(r + 1) * B])
+            ok, checked = ok and bool(same), checked + 1
+    dist.barrier()
+    distinct = len({(d["uuid"], d["pci_bus_id"], d["device_index"]) for d in seen})
+    return {"world_size": world, "backend": mdist.backend_name(), "ranks_seen": seen, "distinct_devices": distinct,
+            "gathered_rows": [int(v) for v in dets.shape], "allgather_us": round(us, 2),
+            "allgather_bytes_per_rank": int(blk.numel() * 4),
+            "shards_recomputed_on_rank0": checked, "shards_match": ok}
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,6 +299,8 @@ def parse_args():
     ap.add_argument("--no-configs2", action="store_true",
                     help="skip the extra configs[2] (bs=64 bf16) measurement that the default N=1 f32 run appends as 'configs2_bf16'")
     ap.add_argument("--configs2-steps", type=int, default=60)
+    ap.add_argument("--no-feed", action="store_true",
+                    help="skip the fed-input leg (uint8 frames from pinned host memory every step) that the default N=1 f32 run appends as 'feed_u8'")
     ap.add_argument("--dump-layers", default=None, help="write the per-launch table of one instrumented step here")
     ap.add_argument("--dump-launches", default=None,
                     help="write the ordered [family label, kernel base name] list of one step's MFMA launches (for tools/pmc_traffic.py)")
@@ -196,6 +311,8 @@ def parse_args():
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-worker":
+        return _cpu_worker(sys.argv[2])
     args = parse_args()
     from m3dssd_amd import dist as mdist
 
@@ -214,8 +331,8 @@ def main():
         os.execv(sys.executable, cmd)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
-    backend = os.environ.get("M3D_DIST_BACKEND") or "nccl"
-    if args.gpus > 1 and backend == "nccl" and torch.cuda.device_count() < args.gpus:
+    backend = os.environ.get("M3D_DIST_BACKEND")          # None: init_from_env's own default (nccl = RCCL when a GPU is visible)
+    if args.gpus > 1 and backend in (None, "nccl") and torch.cuda.device_count() < args.gpus:
         raise SystemExit("--gpus %d with the nccl (RCCL) backend needs %d visible devices, found %d "
                          "(M3D_DIST_BACKEND=gloo lets test ranks share a device)" % (args.gpus, args.gpus, torch.cuda.device_count()))
     rank, world, local = mdist.init_from_env(backend)
@@ -225,7 +342,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    out, sd = run_config(args, args.dtype, args.steps, args.batch, rank, world, dev, mdist, dump_layers=args.dump_layers)
+    out, sd = run_config(args, args.dtype, args.steps, args.batch, rank, world, dev, mdist, dump_layers=args.dump_layers,
+                         feed=(world == 1 and args.dtype == "f32" and args.batch is None and not args.no_feed))
     if rank == 0:
         if world > 1:
             out["dist_backend"] = mdist.backend_name()
@@ -244,7 +362,52 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=None):
+def feed_u8_leg(net, conf, B, dev, steps, resident_ms):
+    """The fed-input form of the same step: raw uint8 BGR frames [B, 375, 1242, 3] -- a DIFFERENT set every step --
+    go from pinned host memory to the device on a copy stream, double buffered against the graph of the previous batch, and the
+    stem reads them directly (Preprocess fused into its loads).  Replaces the reference's per-frame host preprocessing + im.cuda()
+    (lib/rpn_util.py:1427-1429, lib/dataloader.py:934-950, lib/augmentations.py:472-501).  Never part of `value`."""
+    import numpy as np
+    from m3dssd_amd.pipeline import PipelinedDetector
+    fh, fw = 375, 1242                                     # KITTI frame size, padded to the 384 x 1280 crop inside the stem
+    rng = np.random.RandomState(7)
+    pool = [torch.from_numpy(rng.randint(0, 256, size=(B, fh, fw, 3)).astype(np.uint8)).pin_memory() for _ in range(4)]
+    pipe = PipelinedDetector(net, conf, B, CROP[0], CROP[1], u8_frame=(fh, fw))
+    nbytes = pool[0].numel()
+    # raw H2D rate of one frame set, alone on the copy stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dst = torch.empty_like(pool[0], device=dev)
+    dst.copy_(pool[0], non_blocking=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for i in range(8):
+        dst.copy_(pool[i % 4], non_blocking=True)
+    e1.record()
+    torch.cuda.synchronize()
+    h2d_alone_ms = e0.elapsed_time(e1) / 8
+    # warm-up, then the timed loop: upload of batch k + 1 is issued before the graph of batch k
+    pipe.feed(pool[0])
+    for k in range(3):
+        pipe.feed(pool[(k + 1) % 4])
+        pipe.step_fed(as_block=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        pipe.feed(pool[k % 4])
+        pipe.step_fed(as_block=True)
+    pipe.step_fed(as_block=True)                           # the batch fed during warm-up keeps the count at `steps` + 1 submitted;
+    pipe.flush(as_block=True)                              # flush drains the last one
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = 1e3 * dt / (steps + 1)
+    return {"value": round(B * (steps + 1) / dt, 2), "unit": "images/sec", "steps": steps + 1, "ms_per_step": round(ms, 3),
+            "vs_resident": round(resident_ms / ms, 4), "frame": [fw, fh], "input": "uint8 BGR [B, 375, 1242, 3] from pinned host "
+            "memory, 4 distinct frame sets cycled, double-buffered copy stream, Preprocess fused into the stem (m3d_stem_conv7x7_u8)",
+            "h2d_bytes_per_step": int(nbytes), "h2d_gbs_effective": round(nbytes / (ms * 1e-3) / 1e9, 2),
+            "h2d_alone_ms": round(h2d_alone_ms, 4), "h2d_alone_gbs": round(nbytes / (h2d_alone_ms * 1e-3) / 1e9, 2)}
+
+
+def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=None, feed=False):
     """Warm up, instrument, time `steps` steps of one (dtype, batch) configuration; returns (JSON dict or None off rank 0, state dict)."""
     from m3dssd_amd import synth
     from m3dssd_amd.host.detect import detect_device, select_block
@@ -381,7 +544,7 @@ def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=N
     alg = {}
     for op in plan.ops:
         ab = algorithmic_bytes(op)
-        if ab is not None and op[1] in igemm:
+        if ab is not None:
             a = alg.setdefault(op[1], [0.0, 0])
             a[0] += ab
             a[1] += 1
@@ -397,6 +560,29 @@ def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=N
                        "algorithmic_bytes_per_launch": int(alg[k][0] / alg[k][1]) if k in alg else None,
                        "algorithmic_gbs": round(alg[k][0] / (ms * 1e-3) / 1e9, 1) if (k in alg and ms > 0) else None,
                        "traffic": tr, "traffic_source": src}
+
+    rccl = None
+    if world > 1:
+        rccl = rccl_proof(args, mdist, net, conf, B, rank, world, dev, step())
+    # the launches outside the MFMA families (stem, level0's own F(4x4) kernel, pooling, up-sampling, bundling, ...): each against
+    # the roof that bounds it -- HBM bytes it has to move once / HIP-event time, and the arithmetic rate where it executes FLOPs
+    helpers = {}
+    for k, (ms, fl, cnt) in sorted(per_kind.items(), key=lambda kv: -kv[1][0]):
+        if k in igemm:
+            continue
+        div = 4.0 if k.startswith("wino44") else 1.0
+        gbs = alg[k][0] / (ms * 1e-3) / 1e9 if (k in alg and ms > 0) else None
+        tf = fl / (ms * 1e-3) / 1e12 / div if (fl > 0 and ms > 0) else None
+        helpers[k] = {"launches_per_step": cnt, "ms_per_step": round(ms, 3),
+                      "algorithmic_bytes_per_launch": int(alg[k][0] / alg[k][1]) if k in alg else None,
+                      "algorithmic_gbs": round(gbs, 1) if gbs is not None else None,
+                      "hbm_frac_of_peak": round(gbs / PEAK_HBM_GBS, 3) if gbs is not None else None,
+                      "executed_tflops": round(tf, 2) if tf is not None else None,
+                      "frac_of_mfma_peak": round(tf / peak_tf, 3) if (tf is not None and k.startswith("wino44")) else None,
+                      "bound": "hbm" if (gbs is not None and (tf is None or gbs / PEAK_HBM_GBS >= (tf or 0) / peak_tf)) else
+                               ("mfma" if k.startswith("wino44") else ("valu" if tf is not None else "latency"))}
+    mfma_ms = sum(v["ms_per_step"] for v in families.values())
+    mfma_weighted = sum(v["ms_per_step"] * v["frac_of_mfma_peak"] for v in families.values()) / mfma_ms if mfma_ms > 0 else 0.0
 
     if rank == 0:
         value = world * B * steps / dt
@@ -440,10 +626,34 @@ def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=N
                          "share_of_gpu_time": round(igemm[dominant][0] / gpu_ms_all, 3)},
             "gpu_ms_by_kernel_one_step": breakdown,
             "mfma_kernel_families": families,
+            "mfma_time_weighted_frac": round(mfma_weighted, 4),
+            "helper_kernels": helpers,
         }
+        if feed:
+            out["feed_u8"] = feed_u8_leg(net, conf, B, dev, steps, 1e3 * dt / steps)
+        if rccl is not None:
+            out["rccl"] = rccl
+            if not rccl["shards_match"]:
+                raise SystemExit("bench.py: the gathered block does not hold rank r's detections at rows [r*B, (r+1)*B)")
+        step_s = dt / steps
+        if not bf16:
+            # whole-step figures against both roofs.  In fp32 the network is MFMA-bound (~97 FLOP/B vs a ridge of ~20);
+            # algorithmic TFLOP/s may exceed executed TFLOP/s because the Winograd layers execute 1/4 (1/2.25) of their
+            # direct-convolution FLOPs.
+            alg_b = B * ALG_MB_PER_IMAGE_F32 * 1e6 + ALG_MB_WEIGHTS_F32 * 1e6
+            out["step_roofline"] = {
+                "algorithmic_tflops": round(B * ALG_GFLOP_PER_IMAGE * 1e9 / step_s / 1e12, 1),
+                "mfma_frac": round(B * ALG_GFLOP_PER_IMAGE * 1e9 / step_s / 1e12 / peak_tf, 4),
+                "executed_tflops_mfma_families": round(sum(v["executed_tflops"] * v["ms_per_step"] for v in families.values())
+                                                       / (step_s * 1e3), 1),
+                "mfma_time_weighted_frac": round(mfma_weighted, 4),
+                "algorithmic_gbs_f32": round(alg_b / step_s / 1e9, 1), "hbm_frac": round(alg_b / step_s / 1e9 / PEAK_HBM_GBS, 4),
+                "counter_bytes_per_step": step_counter_bytes(families, helpers),
+                "note": "SURVEY 8d algorithmic work per image: 105.8 GFLOP; 1003.6 MB fp32 activations + 21 MB outputs + 5.9 MB input, "
+                        "weights 82.6 MB per batch; counter_bytes_per_step = sum over the kernel families of launches x PMC bytes per "
+                        "launch from the committed passes under profiles/ (families without a pass counted at their algorithmic bytes)"}
         if bf16:
             # whole-step figures against both roofs (in bf16 the network is HBM-bound unless fused)
-            step_s = dt / steps
             out["step_roofline"] = {
                 "algorithmic_tflops": round(B * 105.8e9 / step_s / 1e12, 1), "mfma_frac": round(B * 105.8e9 / step_s / 1e12 / peak_tf, 4),
                 "algorithmic_gbs_bf16": round((B * (501.8e6 + 21e6 + 5.9e6) + 41.3e6) / step_s / 1e9, 1),

@@ -17,6 +17,7 @@
 //     16-byte loads per lane) goes out once per chunk right behind a weight issue and is written to LDS eight positions later.
 //   * Epilogue: bf16_tile.h (folded BatchNorm / bias, residual, LeakyReLU), through the wave's LDS region in whole pixel rows.
 // Weights: m3dssd_amd.engine_bf16.PackedBf16.wave3x3() -- [Cout_pad/128][Cin/32][9 taps][2 K-steps][4 channel blocks][64 lanes][8].
+#include <mutex>
 #include <type_traits>
 
 #include "bf16_tile.h"
@@ -349,8 +350,24 @@ int conv_wide_applicable(const m3d_conv_bf16_desc *d)
     if (!d->wgt_wave || d->dcn_offmask || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1) return 0;
     if (d->groups != 1 || d->wgt_img_stride || d->out_mode != 0 || d->sigmoid_from >= 0) return 0;
     if (d->Cin % 32 || d->Cin < 64 || d->Cout_pad % 128 || d->H % 8 || d->W % 16) return 0;
-    static int on = -1;
-    if (on < 0) { const char *e = getenv("M3D_BF16_WIDE"); on = e ? atoi(e) : 1; }
+    // hand-counted vmcnt: a build in which the compiler spills (scratch loads / stores inside the K loop shift every wait) must not
+    // run -- probed ONCE here, so that the engine routes the layer to the halo-tile kernel instead of failing at launch time
+    // (launch_conv_wide keeps its REQUIRE as the backstop).  No device / probe failure = unknown = served.
+    static std::once_flag once;
+    static int on = 1;
+    std::call_once(once, []() {
+        const char *e = getenv("M3D_BF16_WIDE");
+        on = e ? atoi(e) : 1;
+#ifndef BF16_TRACE
+        hipFuncAttributes fa, fb;
+        if (on && hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&bf16_conv3x3_wide_kernel<true>)) == hipSuccess &&
+            hipFuncGetAttributes(&fb, reinterpret_cast<const void *>(&bf16_conv3x3_wide_kernel<false>)) == hipSuccess) {
+            if (fa.localSizeBytes + fb.localSizeBytes) on = 0;
+        } else {
+            (void)hipGetLastError();
+        }
+#endif
+    });
     return on;
 }
 

@@ -164,6 +164,7 @@ extern "C" void _nms(int *keep_out, int *num_out, const float *boxes_host, int b
 {
     *num_out = 0;
     if (boxes_num <= 0) return;
+    if (boxes_dim < 4) { printf("_nms: boxes_dim = %d, need x1, y1, x2, y2 (>= 4 columns)\n", boxes_dim); return; }
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess || cur != device_id) {
         if (hipSetDevice(device_id) != hipSuccess) { printf("_nms: hipSetDevice(%d) failed\n", device_id); return; }
@@ -172,11 +173,16 @@ extern "C" void _nms(int *keep_out, int *num_out, const float *boxes_host, int b
     void *mask_dev = nullptr;
     int *keep_dev = nullptr, *num_dev = nullptr;
     const size_t bbytes = (size_t)boxes_num * boxes_dim * sizeof(float);
-    bool ok = hipMalloc(&boxes_dev, bbytes) == hipSuccess &&
-              hipMalloc(&mask_dev, (size_t)m3d_nms_workspace_bytes(1, boxes_num)) == hipSuccess &&
-              hipMalloc(&keep_dev, sizeof(int) * boxes_num) == hipSuccess &&
-              hipMalloc(&num_dev, sizeof(int)) == hipSuccess;
-    ok = ok && hipMemcpy(boxes_dev, boxes_host, bbytes, hipMemcpyHostToDevice) == hipSuccess;
+    // every HIP failure records its own message: the report at the end must not print a stale one
+    auto hip_ok = [](hipError_t e, const char *what) {
+        if (e != hipSuccess) m3d_set_error("_nms: %s: %s", what, hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    bool ok = hip_ok(hipMalloc(&boxes_dev, bbytes), "hipMalloc(boxes)") &&
+              hip_ok(hipMalloc(&mask_dev, (size_t)m3d_nms_workspace_bytes(1, boxes_num)), "hipMalloc(mask)") &&
+              hip_ok(hipMalloc(&keep_dev, sizeof(int) * boxes_num), "hipMalloc(keep)") &&
+              hip_ok(hipMalloc(&num_dev, sizeof(int)), "hipMalloc(num)");
+    ok = ok && hip_ok(hipMemcpy(boxes_dev, boxes_host, bbytes, hipMemcpyHostToDevice), "hipMemcpy(boxes -> device)");
     if (ok && boxes_num > 64 * NMS_TPB) {
         // The reference has no row limit (nms_kernel.cu:91-144); the on-device greedy reduce keeps one 64-bit "removed" word per
         // lane (4096 boxes).  Larger inputs take the reference's own route: bitmask tiles on the device, greedy pass on the host
@@ -186,8 +192,9 @@ extern "C" void _nms(int *keep_out, int *num_out, const float *boxes_host, int b
                            boxes_dev, (unsigned long long *)mask_dev);
         unsigned long long *mask_host = (unsigned long long *)malloc((size_t)boxes_num * cb * sizeof(unsigned long long));
         unsigned long long *remv = (unsigned long long *)calloc(cb, sizeof(unsigned long long));
-        ok = mask_host && remv && hipGetLastError() == hipSuccess &&
-             hipMemcpy(mask_host, mask_dev, (size_t)boxes_num * cb * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess;
+        ok = mask_host && remv && hip_ok(hipGetLastError(), "mask kernel launch") &&
+             hip_ok(hipMemcpy(mask_host, mask_dev, (size_t)boxes_num * cb * sizeof(unsigned long long), hipMemcpyDeviceToHost),
+                    "hipMemcpy(mask -> host)");
         int kept = 0;
         for (int i = 0; ok && i < boxes_num; ++i) {
             const int nblock = i / NMS_TPB, inblock = i % NMS_TPB;
@@ -203,8 +210,8 @@ extern "C" void _nms(int *keep_out, int *num_out, const float *boxes_host, int b
     } else {
         ok = ok && m3d_nms_sorted_dev(boxes_dev, 1, boxes_num, boxes_dim, nms_overlap_thresh, mask_dev, keep_dev, num_dev,
                                       nullptr) == M3D_OK;
-        ok = ok && hipMemcpy(num_out, num_dev, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
-        ok = ok && hipMemcpy(keep_out, keep_dev, sizeof(int) * (*num_out), hipMemcpyDeviceToHost) == hipSuccess;
+        ok = ok && hip_ok(hipMemcpy(num_out, num_dev, sizeof(int), hipMemcpyDeviceToHost), "hipMemcpy(num -> host)");
+        ok = ok && hip_ok(hipMemcpy(keep_out, keep_dev, sizeof(int) * (*num_out), hipMemcpyDeviceToHost), "hipMemcpy(keep -> host)");
     }
     if (!ok) { printf("_nms: %s\n", m3d_last_error()); *num_out = 0; }
     (void)hipFree(boxes_dev); (void)hipFree(mask_dev); (void)hipFree(keep_dev); (void)hipFree(num_dev);

@@ -19,6 +19,8 @@
 // of the output scale at Cin = 128, max 1.5e-5; tools/ and DESIGN.md); U = G g G^T is computed in fp64 and rounded once.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include <type_traits>
 
 #include "common.h"
@@ -109,8 +111,13 @@ __device__ __forceinline__ void w44_at(const f32x4 m0, const f32x4 m1, const f32
 
 // NB = 16-channel blocks per wave: 2 (workgroup = 128 output channels) or 1 (64 output channels: Cout = 64 layers, and layers
 // whose 16-tile strips x 128-channel blocks would leave CUs idle -- 256 -> 256 @ 24x80, bs 8: 120 workgroups become 240).
-template <int NB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino44_kernel(const Wino44Args a)
+// OCC = waves per SIMD the build is sized for: 1 = the whole 512-register file (NB = 2 needs it: 288 accumulators); 2 (NB = 1 only:
+// 144 accumulators, <= 256 registers) = TWO workgroups per CU (2 x 73.8 KB of LDS).  Why two: tools/ubench/mfma16_fillers.hip -- a
+// VALU instruction between the v_mfma_f32_16x16x4_f32 of ONE wave costs the stream 12.6 cycles (6-7 each in runs of 4-6), whatever
+// the instruction (v_fma / v_add / packed / v_accvgpr_mov alike); with a second wave on the SIMD the same instruction costs 1.4-4
+// cycles, because the partner's MFMAs issue into the gap -- and the prologue / epilogue of one workgroup run under the other's MFMAs.
+template <int NB, int OCC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void wino44_kernel(const Wino44Args a)
 {
     __shared__ __attribute__((aligned(16))) float Vs[2 * 36 * 256];     // V[buf][xi][tile 16][channel 16]
     __shared__ int pixb[16];                                             // first output pixel of each tile (-1: no such tile)
@@ -596,30 +603,63 @@ extern "C" int m3d_conv3x3_c16_wino(const float *in, int in_cs, const float *U, 
     return M3D_OK;
 }
 
+// The main loop counts its outstanding vector-memory instructions by hand: a build in which the compiler spills registers (scratch
+// loads / stores are vector-memory instructions too) would wait for the wrong loads.  Probed ONCE per process; such a build reports
+// "not applicable" and the engine routes the layers to the F(2x2) / implicit-GEMM kernels instead of failing at launch time (ADVICE
+// r3).  No device / probe failure = unknown = served (the launcher keeps its own REQUIRE as the backstop).
+static int w44_scratch_bytes()
+{
+    static std::once_flag once;
+    static int scratch = 0;
+    std::call_once(once, []() {
+#ifndef WINO_TRACE
+        hipFuncAttributes f1, f2, f3;
+        if (hipFuncGetAttributes(&f1, reinterpret_cast<const void *>(&wino44_kernel<1, 1>)) == hipSuccess &&
+            hipFuncGetAttributes(&f2, reinterpret_cast<const void *>(&wino44_kernel<2, 1>)) == hipSuccess &&
+            hipFuncGetAttributes(&f3, reinterpret_cast<const void *>(&wino44_kernel<1, 2>)) == hipSuccess)
+            scratch = (int)(f1.localSizeBytes + f2.localSizeBytes + f3.localSizeBytes);
+        else
+            (void)hipGetLastError();
+#endif
+    });
+    return scratch;
+}
+static int w44_build_ok() { return w44_scratch_bytes() == 0 ? 1 : 0; }
+
 // 1 if the F(4x4,3x3) kernel serves the descriptor (geometry only; the caller passes U44-packed weights in d->wgt)
 extern "C" int m3d_wino44_applicable(const m3d_conv_desc *d)
 {
     if (!d || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->dil > 1) return 0;
     if (d->dcn_offmask || d->out_nchw || d->wgt_img_stride || d->sigmoid_from >= 0) return 0;
     if (d->H % 4 || d->W % 4 || d->Cin % 16 || d->Cout_pad % 64 || d->in_cs % 4) return 0;
-    return 1;
+    return w44_build_ok();
 }
 
 // Split-K plan of the F(4x4,3x3) kernel: *splits > 1 when the layer's 16-tile strips x 128-channel blocks do not fill the chip
 // (256 -> 256 @ 24x80 and 512 -> 512 @ 12x40 at bs 8: 120 / 60 workgroups) and the input channels can be cut into slices of at
 // least 64 that do; *ws_bytes = splits * N*H*W * Cout_pad * 4 to pass through splitk_ws.  A layer that needs no split (or that
 // the kernel does not serve) reports 1 / 0.
+// Form of the split-K launches: M3D_W44_SPLIT_NB = 2 (128-channel workgroups, one per CU) or 1 (64-channel workgroups, two per CU:
+// `fill` = 480 workgroups); M3D_W44_SPLIT_FILL overrides the number of workgroups a layer must reach to run unsplit.
+static int w44_split_nb() { static const int v = []() { const char *e = getenv("M3D_W44_SPLIT_NB"); return e ? atoi(e) : 1; }(); return v == 2 ? 2 : 1; }
+static int w44_split_fill()
+{
+    static const int v = []() { const char *e = getenv("M3D_W44_SPLIT_FILL"); return e ? atoi(e) : 0; }();
+    return v > 0 ? v : (w44_split_nb() == 1 ? 400 : 200);
+}
+
 extern "C" int m3d_wino44_splitk_plan(const m3d_conv_desc *d, int *splits, long long *ws_bytes)
 {
     M3D_REQUIRE(d && splits && ws_bytes, "wino44_splitk_plan: null pointer");
     *splits = 1; *ws_bytes = 0;
-    if (!m3d_wino44_applicable(d) || d->Cout_pad % 128) return M3D_OK;
-    const long long wgs = (long long)cdiv(d->N * (d->H / 4) * (d->W / 4), 16) * (d->Cout_pad / 128);
-    const int ns = d->Cin / 16;
-    if (wgs >= 200) return M3D_OK;
+    const int cw = w44_split_nb() == 1 ? 64 : 128;
+    if (!m3d_wino44_applicable(d) || d->Cout_pad % cw) return M3D_OK;
+    const long long wgs = (long long)cdiv(d->N * (d->H / 4) * (d->W / 4), 16) * (d->Cout_pad / cw);
+    const int ns = d->Cin / 16, fill = w44_split_fill();
+    if (wgs >= fill) return M3D_OK;
     for (int sp = 2; sp <= 8; sp *= 2) {
         if (ns % sp || ns / sp < 4) break;
-        if (wgs * sp >= 200) {
+        if (wgs * sp >= fill) {
             const long long need = (long long)sp * d->N * d->H * d->W * d->Cout_pad * 4;
             if (need / sp < (1ll << 31)) { *splits = sp; *ws_bytes = need; }
             break;
@@ -651,24 +691,12 @@ extern "C" int m3d_wino44_conv3x3_forward_touch(const m3d_conv_desc *d, int nb, 
 #ifdef WINO_TRACE
     a.trace = g_w44_trace;
 #endif
-#ifndef WINO_TRACE
-    {
-        // the main loop counts its outstanding vector-memory instructions by hand: a build in which the compiler spills registers
-        // (scratch loads / stores are vector-memory instructions too) would wait for the wrong loads -- refuse to run such a build
-        static int scratch = -1;
-        if (scratch < 0) {
-            hipFuncAttributes f1, f2;
-            M3D_HIP(hipFuncGetAttributes(&f1, reinterpret_cast<const void *>(&wino44_kernel<1>)));
-            M3D_HIP(hipFuncGetAttributes(&f2, reinterpret_cast<const void *>(&wino44_kernel<2>)));
-            scratch = (int)(f1.localSizeBytes + f2.localSizeBytes);
-        }
-        M3D_REQUIRE(scratch == 0, "wino44: this build of the kernel uses %d bytes of scratch memory per lane (register spills)", scratch);
-    }
-#endif
+    M3D_REQUIRE(w44_scratch_bytes() == 0, "wino44: this build of the kernel uses %d bytes of scratch memory per lane (register spills)",
+                w44_scratch_bytes());
     const int strips = cdiv(a.NT, 16);
     M3D_REQUIRE(nb >= 0 && nb <= 2 && !(nb == 2 && d->Cout_pad % 128), "wino44: nb = 0 (automatic), 1 or 2 (needs Cout_pad %% 128 == 0)");
-    // split-K when the caller provides the workspace the plan asks for (128-channel workgroups only)
-    if (d->splitk_ws && nb != 1) {
+    // split-K when the caller provides the workspace the plan asks for (the form -- 128- or 64-channel workgroups -- is the plan's)
+    if (d->splitk_ws && (nb == 0 || nb == w44_split_nb())) {
         int splits = 1;
         long long need = 0;
         if (const int rc = m3d_wino44_splitk_plan(d, &splits, &need)) return rc;
@@ -678,7 +706,10 @@ extern "C" int m3d_wino44_conv3x3_forward_touch(const m3d_conv_desc *d, int nb, 
             a.out = d->splitk_ws; a.out_cs = d->Cout_pad; a.out_bytes = (unsigned)(pix * d->Cout_pad * 4);
             a.ws_slice = pix * d->Cout_pad; a.nsl = d->Cin / 16 / splits;
             a.scale = a.shift = a.res = nullptr; a.res_bytes = 0; a.act = 0; a.res_mode = 0; a.Cout = d->Cout_pad;
-            hipLaunchKernelGGL(wino44_kernel<2>, dim3(strips, d->Cout_pad / 128, splits), dim3(256), 0, (hipStream_t)stream, a);
+            if (w44_split_nb() == 1)
+                hipLaunchKernelGGL((wino44_kernel<1, 2>), dim3(strips, d->Cout_pad / 64, splits), dim3(256), 0, (hipStream_t)stream, a);
+            else
+                hipLaunchKernelGGL((wino44_kernel<2, 1>), dim3(strips, d->Cout_pad / 128, splits), dim3(256), 0, (hipStream_t)stream, a);
             M3D_LAUNCH_CHECK();
             SplitkReduceArgs r;
             r.ws = d->splitk_ws; r.scale = d->scale; r.shift = d->shift; r.res = d->res; r.out = d->out;
@@ -687,10 +718,13 @@ extern "C" int m3d_wino44_conv3x3_forward_touch(const m3d_conv_desc *d, int nb, 
             return m3d_launch_splitk_reduce(r, (hipStream_t)stream);
         }
     }
-    // 128-channel workgroups (2 blocks of 16 per wave) where they fill the chip, else 64-channel workgroups
-    const bool nb2 = d->Cout_pad % 128 == 0 && (nb == 2 || (nb == 0 && (long long)strips * (d->Cout_pad / 128) >= 200));
-    if (nb2) hipLaunchKernelGGL(wino44_kernel<2>, dim3(strips, d->Cout_pad / 128), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(wino44_kernel<1>, dim3(strips, d->Cout_pad / 64), dim3(256), 0, (hipStream_t)stream, a);
+    // 64-channel workgroups, two per CU (round 4: faster than the 128-channel form on every layer measured); nb = 2 asks for the
+    // 128-channel form (one per CU, the whole register file) explicitly
+    const bool nb2 = d->Cout_pad % 128 == 0 && nb == 2;
+    static const int occ2 = []() { const char *e = getenv("M3D_W44_OCC2"); return e ? atoi(e) : 1; }();
+    if (nb2) hipLaunchKernelGGL((wino44_kernel<2, 1>), dim3(strips, d->Cout_pad / 128), dim3(256), 0, (hipStream_t)stream, a);
+    else if (occ2) hipLaunchKernelGGL((wino44_kernel<1, 2>), dim3(strips, d->Cout_pad / 64), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((wino44_kernel<1, 1>), dim3(strips, d->Cout_pad / 64), dim3(256), 0, (hipStream_t)stream, a);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
 }

@@ -31,9 +31,10 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = os.environ.get("M3D_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        if backend not in ("nccl", "gloo"):
-            raise ValueError("M3D_DIST_BACKEND must be 'nccl' or 'gloo' (got %r)" % (backend,))
+            backend = os.environ.get("M3D_DIST_BACKEND")
+            if backend is not None and backend not in ("nccl", "gloo"):      # only the env var is policed: an explicit argument
+                raise ValueError("M3D_DIST_BACKEND must be 'nccl' or 'gloo' (got %r)" % (backend,))   # may be anything torch knows
+            backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             n_dev = torch.cuda.device_count()
             if local >= n_dev:

@@ -170,8 +170,19 @@ USE_WINO44 = os.environ.get("M3D_WINO44", "1") != "0"
 WINO44_TOUCH = os.environ.get("M3D_WINO44_TOUCH", "1") != "0"
 WINO44_TOUCH_SPAN = int(os.environ.get("M3D_WINO44_TOUCH_SPAN", "2"))   # launches between two F(4x4) layers that a folded touch bridges
 USE_WINO44_SPLITK = os.environ.get("M3D_WINO44_SPLITK", "1") != "0"
-WINO44_MIN_WGS = int(os.environ.get("M3D_WINO44_MIN_WGS", "200"))
+W44_SPLIT_NB = 2 if os.environ.get("M3D_W44_SPLIT_NB", "1") == "2" else 1    # form of the split-K launches (csrc/wino44_conv.hip)
+# Round 4: the 64-channel form runs TWO workgroups per CU (wino44_kernel<1, 2>) and beats the 128-channel form on every layer
+# (128 -> 128 @ 48x160: 0.056 vs 0.065 ms, 128 -> 256: 0.114 vs 0.130); the 128-channel form is kept for experiments
+# (M3D_WINO44_MIN_WGS=200 restores the round-3 choice).
+WINO44_MIN_WGS = int(os.environ.get("M3D_WINO44_MIN_WGS", "1000000"))
 WINO44_MIN_WGS_NB1 = int(os.environ.get("M3D_WINO44_MIN_WGS_NB1", "200"))
+
+
+class OpCost:
+    """Algorithmic HBM bytes of a helper launch (the `desc` slot of a plan op that has no conv / head descriptor)."""
+
+    def __init__(self, hbm_bytes):
+        self.hbm_bytes = int(hbm_bytes)
 
 
 class _Plan:
@@ -385,7 +396,7 @@ class Engine:
                 ws = torch.empty(sbytes.value // 4, device=self.device, dtype=torch.float32)
                 plan.keep.append(ws)
                 d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), sbytes.value
-                nb, ks44 = 2, ssplits.value
+                nb, ks44 = W44_SPLIT_NB, ssplits.value
         if w44ok and nb:
             # Winograd F(4x4,3x3): 4x fewer MFMA FLOPs than the direct convolution (F(2x2,3x3): 2.25x) where the layer fills the
             # chip with 16-tile workgroups (csrc/wino44_conv.hip)
@@ -403,7 +414,7 @@ class Engine:
                     plan.w44_prev[1]["ptr"], plan.w44_prev[1]["bytes"] = u44.data_ptr(), nbytes
                 else:
                     plan.ops.append((name + ".touch", "touch", 0.0,
-                                     lambda st: _hip.check(L.m3d_cache_touch(u44.data_ptr(), nbytes, st)), None))
+                                     lambda st: _hip.check(L.m3d_cache_touch(u44.data_ptr(), nbytes, st)), OpCost(nbytes)))
             plan.w44_prev = (len(plan.ops), nxt)
             plan.ops.append((name, "wino44<16,%d%s>" % (16 * nb, ",splitk%d" % ks44 if ks44 > 1 else ""), flops,
                              lambda st: _hip.check(L.m3d_wino44_conv3x3_forward_touch(ref, nb, nxt["ptr"], nxt["bytes"], st)), d))
@@ -472,8 +483,10 @@ class Engine:
         flops = 2.0 * x.n * d.Ho * d.Wo * d.Cout * kh * kw * cin_true
         plan.ops.append((name, kind, flops, lambda st: _hip.check(L.m3d_conv2d_forward(ref, st)), d))
 
-    def _op(self, plan, name, kind, fn):
-        plan.ops.append((name, kind, 0.0, fn, None))
+    def _op(self, plan, name, kind, fn, flops=0.0, nbytes=None):
+        """A launch outside the conv / head descriptors: `flops` = arithmetic it executes, `nbytes` = the HBM bytes it has to
+        move once (inputs + outputs), so that bench.py can hold it against its own roof (HBM for the element-wise helpers)."""
+        plan.ops.append((name, kind, float(flops), fn, OpCost(nbytes) if nbytes is not None else None))
 
     # ------------------------------------------------------------------ plan construction
     def _build_plan(self, B, H, W):
@@ -497,18 +510,19 @@ class Engine:
             else:
                 _hip.check(L.m3d_stem_conv7x7(in_ptr[0], P["stem.w"].data_ptr(), P["stem.scale"].data_ptr(),
                                               P["stem.shift"].data_ptr(), s0.ptr, s0.cs, B, H, W, st))
-        self._op(plan, "stem", "stem", stem)
+        # (bytes: the fp32 NCHW image; with uint8 frames the input is 4x smaller)
+        self._op(plan, "stem", "stem", stem, flops=2.0 * B * H * W * 16 * 147, nbytes=B * H * W * (3 + 16) * 4)
         l0 = self._buf(plan, B, H, W, 16, name="level0")
         if P.get("level0.wino44") is not None and H % 4 == 0 and W % 4 == 0 and os.environ.get("M3D_LEVEL0_WINO44", "1") != "0":
             pc0 = P["level0"]       # F(4x4,3x3) on 16x16x4 MFMAs: 144 MFMAs per 256 pixels instead of 576 (csrc/wino44_conv.hip)
             self._op(plan, "level0", "wino44_c16", lambda st: _hip.check(L.m3d_conv3x3_c16_wino(
                 s0.ptr, s0.cs, P["level0.wino44"].data_ptr(), pc0.scale.data_ptr(), pc0.shift.data_ptr(), l0.ptr, l0.cs,
-                B, H, W, st)))
+                B, H, W, st)), flops=2.0 * B * H * W * 16 * 144, nbytes=B * H * W * 32 * 4)
         elif P["level0.direct"] is not None and os.environ.get("M3D_LEVEL0_IGEMM", "0") != "1":
             pc0 = P["level0"]
             self._op(plan, "level0", "conv3x3_c16", lambda st: _hip.check(L.m3d_conv3x3_c16(
                 s0.ptr, s0.cs, P["level0.direct"].data_ptr(), pc0.scale.data_ptr(), pc0.shift.data_ptr(), l0.ptr, l0.cs,
-                B, H, W, st)))
+                B, H, W, st)), flops=2.0 * B * H * W * 16 * 144, nbytes=B * H * W * 32 * 4)
         else:
             self._conv(plan, "level0", P["level0"], s0, l0, 1, 1, act=1)
         l1 = self._buf(plan, B, H // 2, W // 2, 32, name="level1")
@@ -516,7 +530,7 @@ class Engine:
 
         def maxpool(name, x, out):
             self._op(plan, name, "maxpool", lambda st: _hip.check(L.m3d_maxpool2x2(
-                x.ptr, x.cs, out.ptr, out.cs, x.n, x.h, x.w, x.c, st)))
+                x.ptr, x.cs, out.ptr, out.cs, x.n, x.h, x.w, x.c, st)), nbytes=x.n * x.h * x.w * x.c * 5)
 
         def block(p, x, res, out, stride):
             co = P[p + ".conv1"].cout
@@ -592,7 +606,8 @@ class Engine:
             summed = self._buf(plan, B, 2 * x.h, 2 * x.w, co)
             upw = P["%s.up_%d" % (p, i)]
             self._op(plan, "%s.up_%d" % (p, i), "upsample", lambda st: _hip.check(L.m3d_upsample2x_add(
-                proj.ptr, proj.cs, upw.data_ptr(), skip.ptr, skip.cs, summed.ptr, summed.cs, B, proj.h, proj.w, co, st)))
+                proj.ptr, proj.cs, upw.data_ptr(), skip.ptr, skip.cs, summed.ptr, summed.cs, B, proj.h, proj.w, co, st)),
+                flops=2.0 * B * 4 * proj.h * proj.w * co * 4, nbytes=B * proj.h * proj.w * co * 4 * (1 + 4 + 4))
             node = self._buf(plan, B, 2 * x.h, 2 * x.w, co)
             deform("%s.node_%d" % (p, i), summed, node)
             return node
@@ -661,7 +676,8 @@ class Engine:
         plan.keep += [sel_idx, sel_prob]
         plan.named["sel_idx"], plan.named["sel_prob"] = sel_idx, sel_prob
         self._op(plan, "anchor_select", "select", lambda st: _hip.check(L.m3d_anchor_select(
-            cls_pl.data_ptr(), B, A, NC, HW, sel_idx.data_ptr(), sel_prob.data_ptr(), None, st)))
+            cls_pl.data_ptr(), B, A, NC, HW, sel_idx.data_ptr(), sel_prob.data_ptr(), None, st)),
+            nbytes=B * HW * (A * NC + 2) * 4)
 
         means = np.asarray(self.conf.bbox_means, dtype=np.float32).reshape(-1)
         stds = np.asarray(self.conf.bbox_stds, dtype=np.float32).reshape(-1)
@@ -676,7 +692,7 @@ class Engine:
         om_sa = self._buf(plan, B, fh, fw, 27, 28)
         self._op(plan, "shape_align.offsets", "align", lambda st: _hip.check(L.m3d_align_offsets(
             0, sel_idx.data_ptr(), sel_prob.data_ptr(), 0.5, P["shape.table"].data_ptr(), None, None, None, 0.0, 1.0, 0.0,
-            1.0, om_sa.ptr, om_sa.cs, B, A, HW, 9, 0, st)))
+            1.0, om_sa.ptr, om_sa.cs, B, A, HW, 9, 0, st)), nbytes=B * HW * (2 + 28) * 4)
         feats = self._buf(plan, B, fh, fw, 128, name="feats")
         self._conv(plan, "shape_align.dcn", P["shape_align"], feats0, feats, 1, 1, act=0, res=feats0, om=om_sa)
         # heads are grouped by the feature map they read (M3d_inference_align.py:139-176): the four centre heads first,
@@ -689,7 +705,7 @@ class Engine:
             self._op(plan, p + ".offsets", "align", lambda st: _hip.check(L.m3d_align_offsets(
                 1, sel_idx.data_ptr(), sel_prob.data_ptr(), 0.5, None, box_ptr(kx), box_ptr(ky),
                 P["anchor_wh"].data_ptr(), float(means[mi]), float(stds[mi]), float(means[mi + 1]),
-                float(stds[mi + 1]), om.ptr, om.cs, B, A, HW, 1, 11 * A * HW, st)))
+                float(stds[mi + 1]), om.ptr, om.cs, B, A, HW, 1, 11 * A * HW, st)), nbytes=B * HW * (2 + 2 + 4) * 4)
             self._conv(plan, p + ".dcn", P[p], x, out, 1, 0, act=0, res=x, om=om)
 
         f2d = self._buf(plan, B, fh, fw, 128, name="feats_align2d")
@@ -715,7 +731,7 @@ class Engine:
         assert NC == 4, "bundle kernel is written for 4 classes (bg + 3)"
         self._op(plan, "bundle_outputs", "bundle", lambda st: _hip.check(L.m3d_bundle_outputs(
             cls_pl.data_ptr(), box_pl.data_ptr(), cls.data_ptr(), prob.data_ptr(), b2.data_ptr(), b3.data_ptr(),
-            key.data_ptr(), B, A, HW, st)))
+            key.data_ptr(), B, A, HW, st)), nbytes=B * R * (NC + 11 + 2 * NC + 4 + 7 + 1) * 4)
         plan.feat = (fh, fw)
         return plan
 
@@ -756,7 +772,7 @@ class Engine:
             plan.keep.append(scratch)
             self._op(plan, "anab.pool_nested", "anab_pool", lambda st: _hip.check(L.m3d_anab_pool_nested(
                 kvv.ptr, kvv.cs, sv.ptr, sv.cs, B, fh, fw, self.ck, self.cv, scratch.data_ptr(), khat.data_ptr(), keys_pad,
-                self.ck_pad, vhatT.data_ptr(), frag, st)))
+                self.ck_pad, vhatT.data_ptr(), frag, st)), nbytes=B * HW * (ckv + self.ns) * 4)
         else:
             self._op(plan, "anab.pool_partial", "anab_pool", lambda st: _hip.check(L.m3d_anab_pool_partial(
                 kvv.ptr, kvv.cs, sv.ptr, sv.cs, d_items.data_ptr(), items.shape[0], d_bscale.data_ptr(), n_bins,
@@ -770,7 +786,7 @@ class Engine:
                    wgt_img_stride=keys_pad * self.ck_pad, cout=n_bins, cout_pad=keys_pad, kh=1, kw=1, cin_true=self.ck,
                    wgt_frag=wave_logits)
         self._op(plan, "anab.softmax", "softmax", lambda st: _hip.check(L.m3d_softmax_rows(
-            logits.ptr, B * HW, n_bins, keys_pad, st)))
+            logits.ptr, B * HW, n_bins, keys_pad, st)), nbytes=B * HW * n_bins * 8)
         self._conv(plan, "anab.pv", None, logits, out, 1, 0, act=act, res=x, res_mode=res_mode,
                    wgt_ptr=vhatT.data_ptr(), wgt_img_stride=self.cv * keys_pad, cout=self.cv,
                    cout_pad=_rup(self.cv, 32), kh=1, kw=1, scale=scale, shift=shift, cin_true=n_bins, wgt_frag=wave_pv)

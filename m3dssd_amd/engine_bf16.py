@@ -22,7 +22,7 @@ import torch
 
 from . import _hip
 from ._hip import ConvBf16Desc, HeadBf16Desc
-from .engine import BN_EPS, PSP_SIZES, Engine, _Plan, _rup
+from .engine import BN_EPS, PSP_SIZES, Engine, OpCost, _Plan, _rup
 
 BF16 = torch.bfloat16
 FUSED_ANAB = os.environ.get("M3D_BF16_FUSED_ANAB", "1") != "0"
@@ -308,7 +308,9 @@ class EngineBF16(Engine):
                     P["stem.scale"].data_ptr(), P["stem.shift"].data_ptr(), fwts[1].data_ptr(), p0.scale.data_ptr(),
                     p0.shift.data_ptr(), fwts[2].data_ptr(), p1.scale.data_ptr(), p1.shift.data_ptr(), l1.ptr, l1.cs, B, H, W, st))
             flops = 2.0 * B * H * W * (147 * 16 + 144 * 16) + 2.0 * B * (H // 2) * (W // 2) * 144 * 32
-            plan.ops.append(("stem+level0+level1", "bf16_frontend", flops, front, None))
+            # (bytes: the fp32 NCHW image in, the 32-channel half-resolution bf16 map out)
+            plan.ops.append(("stem+level0+level1", "bf16_frontend", flops, front,
+                             OpCost(B * H * W * 3 * 4 + B * (H // 2) * (W // 2) * 32 * 2)))
         else:
             s0 = self._buf16(plan, B, H, W, 16)
 
@@ -317,14 +319,14 @@ class EngineBF16(Engine):
                 _hip.check(L.m3d_stem_conv7x7_bf16(in_u8[0] if u8 else in_ptr[0], u8, in_u8[1], in_u8[2], mean3, stds3,
                                                    P["stem.w"].data_ptr(), P["stem.scale"].data_ptr(), P["stem.shift"].data_ptr(),
                                                    s0.ptr, s0.cs, B, H, W, st))
-            self._op(plan, "stem", "stem_bf16", stem)
+            self._op(plan, "stem", "stem_bf16", stem, flops=2.0 * B * H * W * 16 * 147, nbytes=B * H * W * (3 * 4 + 16 * 2))
             l0 = self._buf16(plan, B, H, W, 16, name="level0")
             self._pconv(plan, "level0", P["level0"], s0, l0, 1, 1, act=1)
             self._pconv(plan, "level1", P["level1"], l0, l1, 2, 1, act=1)
 
         def maxpool(name, x, out):
             self._op(plan, name, "maxpool_bf16", lambda st: _hip.check(L.m3d_maxpool2x2_bf16(
-                x.ptr, x.cs, out.ptr, out.cs, x.n, x.h, x.w, x.c, st)))
+                x.ptr, x.cs, out.ptr, out.cs, x.n, x.h, x.w, x.c, st)), nbytes=x.n * x.h * x.w * x.c * 5 // 2)
 
         def block(p, x, res, out, stride):
             co = P[p + ".conv1"].cout
@@ -394,7 +396,8 @@ class EngineBF16(Engine):
             summed = self._buf16(plan, B, 2 * x.h, 2 * x.w, co)
             upw = P["%s.up_%d" % (p, i)]
             self._op(plan, "%s.up_%d" % (p, i), "upsample_bf16", lambda st: _hip.check(L.m3d_upsample2x_add_bf16(
-                proj.ptr, proj.cs, upw.data_ptr(), skip.ptr, skip.cs, summed.ptr, summed.cs, B, proj.h, proj.w, co, st)))
+                proj.ptr, proj.cs, upw.data_ptr(), skip.ptr, skip.cs, summed.ptr, summed.cs, B, proj.h, proj.w, co, st)),
+                flops=2.0 * B * 4 * proj.h * proj.w * co * 4, nbytes=B * proj.h * proj.w * co * 2 * (1 + 4 + 4))
             node = self._buf16(plan, B, 2 * x.h, 2 * x.w, co)
             deform("%s.node_%d" % (p, i), summed, node)
             return node
@@ -471,7 +474,8 @@ class EngineBF16(Engine):
         plan.keep += [sel_idx, sel_prob]
         plan.named["sel_idx"], plan.named["sel_prob"] = sel_idx, sel_prob
         self._op(plan, "anchor_select", "select", lambda st: _hip.check(L.m3d_anchor_select(
-            cls_pl.data_ptr(), B, A, NC, HW, sel_idx.data_ptr(), sel_prob.data_ptr(), None, st)))
+            cls_pl.data_ptr(), B, A, NC, HW, sel_idx.data_ptr(), sel_prob.data_ptr(), None, st)),
+            nbytes=B * HW * (A * NC + 2) * 4)
         means = np.asarray(self.conf.bbox_means, dtype=np.float32).reshape(-1)
         stds = np.asarray(self.conf.bbox_stds, dtype=np.float32).reshape(-1)
 
@@ -515,7 +519,7 @@ class EngineBF16(Engine):
         plan.named.update(cls=cls, prob=prob, bbox_2d=b2, bbox_3d=b3, score_bits=key)
         self._op(plan, "bundle_outputs", "bundle", lambda st: _hip.check(L.m3d_bundle_outputs(
             cls_pl.data_ptr(), box_pl.data_ptr(), cls.data_ptr(), prob.data_ptr(), b2.data_ptr(), b3.data_ptr(),
-            key.data_ptr(), B, A, HW, st)))
+            key.data_ptr(), B, A, HW, st)), nbytes=B * R * (NC + 11 + 2 * NC + 4 + 7 + 1) * 4)
         return plan
 
     def _anab_bf16(self, plan, x, out):

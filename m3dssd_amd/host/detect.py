@@ -78,12 +78,14 @@ def detect_device(net, im, conf, top_post=None, scale=None):
     if im.dim() == 3:
         im = im[None]
     dev = next(net.parameters()).device
-    im = im.to(dev, torch.float32)
+    u8 = im.dtype == torch.uint8 and im.shape[-1] == 3       # raw BGR frames [B, h, w, 3]: Preprocess runs inside the stem kernel
+    im = im.to(dev) if u8 else im.to(dev, torch.float32)
     with torch.no_grad():
         net.eval()
         cls, prob, bbox_2d, bbox_3d, feat_size, rois = net(im)
         eng = net.engine()
-        plan = eng.plan_for(prob.shape[0], im.shape[2], im.shape[3])
+        H, W = (int(v) for v in conf.crop_size) if u8 else (im.shape[2], im.shape[3])
+        plan = eng.plan_for(prob.shape[0], H, W)
         return detect_from_outputs(eng, plan, prob, bbox_2d, bbox_3d, rois, conf, _scale_tensor(scale, prob.shape[0], dev))
 
 

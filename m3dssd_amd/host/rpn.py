@@ -88,6 +88,7 @@ class RPN(nn.Module):
     def refresh_engine(self):
         self._engine = None
         self._param_sig = None
+        self.__dict__.pop("_device_engines", None)
         return self
 
     def _apply(self, fn, *args, **kwargs):
@@ -109,15 +110,38 @@ class RPN(nn.Module):
         return super().load_state_dict(state_dict, *args, **kwargs)
 
     def _replicate_for_data_parallel(self):
-        """nn.DataParallel (the reference's scripts/test_rpn_3d.py:50-51) replicates the module per device: a replica must not
-        share the packed engine (its plans live on the source device).  Each replica packs its own on first use; with ONE
-        visible device DataParallel calls the module itself and nothing is replicated.  For throughput use one process per
-        GPU (m3dssd_amd.dist) instead -- replicas are rebuilt by DataParallel on EVERY forward."""
+        """nn.DataParallel (the reference's scripts/test_rpn_3d.py:50-51) replicates the module per device on EVERY forward.  A
+        real replica has no parameters (torch.nn.parallel.replicate hangs the broadcast copies on it as plain attributes and
+        leaves `_parameters` empty), so it cannot pack an engine of its own: it asks the SOURCE module, which keeps one packed
+        engine per device (`_engine_for`) built from its own state_dict moved there -- packed once, not per forward.  With ONE
+        visible device DataParallel calls the module itself and nothing is replicated.  For throughput use one process per GPU
+        (m3dssd_amd.dist) instead."""
         replica = super()._replicate_for_data_parallel()
         replica._engine = None
         replica._param_sig = None
         replica._is_replica = True
+        object.__setattr__(replica, "_src", getattr(self, "_src", None) or self)      # (not registered as a sub-module)
         return replica
+
+    def _engine_for(self, dev):
+        """The packed engine of this (source) module on device `dev`: its own for the device its parameters live on, else a
+        per-device engine packed from the state_dict moved to `dev` (cached; dropped by refresh_engine / load_state_dict / .to)."""
+        dev = torch.device(dev)
+        own = next(self.parameters()).device
+        if dev == own:
+            return self.engine()
+        cache = self.__dict__.setdefault("_device_engines", {})
+        key = (str(dev), self.compute_dtype)
+        if key not in cache:
+            if dev.type != "cuda":
+                raise NotImplementedError("RPN.forward runs on a ROCm device only (replica on %s)" % (dev,))
+            sd = {k: v.to(dev) for k, v in self.state_dict().items()}
+            if self.compute_dtype == "bf16":
+                from ..engine_bf16 import EngineBF16
+                cache[key] = EngineBF16(sd, self._conf, device=dev)
+            else:
+                cache[key] = Engine(sd, self._conf, device=dev)
+        return cache[key]
 
     def _signature(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters()) + \
@@ -130,7 +154,19 @@ class RPN(nn.Module):
             self._engine = None
         return self
 
-    def engine(self):
+    def engine(self, device=None):
+        if getattr(self, "_is_replica", False):     # a DataParallel replica: the source module owns the per-device engines
+            if device is None:
+                held = [t for t in self.__dict__.values() if torch.is_tensor(t) and t.is_cuda]
+                former = list(getattr(self, "_former_parameters", {}).values())
+                for m in self.modules():
+                    former += list(getattr(m, "_former_parameters", {}).values())
+                    if former:
+                        break
+                device = (former or held)[0].device if (former or held) else None
+            if device is None:
+                raise RuntimeError("RPN replica: cannot tell its device (no replicated parameters); call engine(device)")
+            return self._src._engine_for(device)
         if self._engine is not None and os.environ.get("M3D_CHECK_PARAMS", "0") == "1" and self._param_sig != self._signature():
             raise RuntimeError("RPN: parameters changed in place since the engine packed them; call net.refresh_engine()")
         if self._engine is None:
@@ -160,9 +196,9 @@ class RPN(nn.Module):
             assert feat_h == self.feat_size[0], "x.shape is {}".format(x.shape)
         with torch.no_grad():
             if u8:
-                cls, prob, bbox_2d, bbox_3d = self.engine().forward_u8(x, size)
+                cls, prob, bbox_2d, bbox_3d = self.engine(x.device).forward_u8(x, size)
             else:
-                cls, prob, bbox_2d, bbox_3d = self.engine().forward(x.float())
+                cls, prob, bbox_2d, bbox_3d = self.engine(x.device).forward(x.float())
         key = (feat_h, feat_w, x.device)
         if getattr(self, "_feat_size_key", None) != key:       # cached: a fresh host->device copy per call would
             self._feat_size_t = torch.tensor([feat_h, feat_w], dtype=torch.float, device=x.device)  # break graph capture

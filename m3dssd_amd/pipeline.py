@@ -11,6 +11,13 @@ the forward of the NEXT batch: one captured hipGraph per input shape whose two b
 so each ``step(x)`` returns the detections of the PREVIOUS batch (one batch of pipeline latency) and ``flush()``
 drains the last one.  Results are identical to ``lib.rpn_util.detect_batch`` (tests/test_gpu_parity.py).
 
+``u8_frame=(h, w)`` is the fed-input form (the reference pays ``im.cuda()`` per frame, lib/rpn_util.py:1427-1429,
+and preprocesses on the host, lib/dataloader.py:934-950, lib/augmentations.py:472-501): raw uint8 BGR frames [B, h, w, 3] arrive
+from PINNED host memory by ``feed()`` on a copy stream into one of TWO device buffers while the graph of the previous batch runs;
+the stem reads the uint8 frames directly (``m3d_stem_conv7x7_u8``: padding to the crop size, /255, -mean, /stds, BGR->RGB in its
+loads).  Two graphs are captured, one per input buffer; events order "upload k+1" behind "graph k-1 done" and "graph k" behind
+"upload k done".
+
 ``refine=True`` appends the post-NMS 3-D refinement of ``test_kitti_3d`` (lib/rpn_util.py:1796-1847: back to the original image
 scale, clipping, alpha -> ry, hill climbing, back-projection; ``m3d_refine_3d_ex``) to branch B, reading the selected rows where
 ``m3d_select_post`` left them: a replay then yields the rows of the KITTI result files of batch k-1.
@@ -27,8 +34,10 @@ from .host.refine import p2_arrays
 
 
 class PipelinedDetector:
-    def __init__(self, net, conf, batch, height, width, refine=False, score_thresh=0.75, step_r_init=0.3 * math.pi, r_lim=0.01):
+    def __init__(self, net, conf, batch, height, width, refine=False, score_thresh=0.75, step_r_init=0.3 * math.pi, r_lim=0.01,
+                 u8_frame=None):
         self.net, self.conf = net, conf
+        self.u8_frame = None if u8_frame is None else (int(u8_frame[0]), int(u8_frame[1]))
         self.refine = bool(refine)
         self._rargs = (float(score_thresh), 1 if bool(getattr(conf, "hill_climbing", True)) else 0, float(step_r_init), float(r_lim))
         dev = next(net.parameters()).device
@@ -37,7 +46,20 @@ class PipelinedDetector:
         self.dev = dev
         self.eng = net.engine()
         self.plan = self.eng.plan_for(batch, height, width)
-        self.input = torch.zeros(batch, 3, height, width, device=dev, dtype=torch.float32)
+        if self.u8_frame is None:
+            self.input = torch.zeros(batch, 3, height, width, device=dev, dtype=torch.float32)
+        else:
+            fh, fw = self.u8_frame
+            if fh > height or fw > width:
+                raise RuntimeError("u8_frame %dx%d does not fit the padded size %dx%d" % (fh, fw, height, width))
+            self.inputs_u8 = [torch.zeros(batch, fh, fw, 3, device=dev, dtype=torch.uint8) for _ in range(2)]
+            self.input = self.inputs_u8[0]
+            self._copy_stream = torch.cuda.Stream(dev)
+            self._ready = [torch.cuda.Event(), torch.cuda.Event()]     # upload into buffer i finished (copy stream)
+            self._done = [torch.cuda.Event(), torch.cuda.Event()]      # the graph that read buffer i finished (main stream)
+            self._fed = []                                             # buffers holding an uploaded, not yet submitted batch
+            self._next_buf = 0
+            self._used = [False, False]
         self.n_fwd = len(self.plan.ops) - 1
         assert self.plan.ops[-1][0] == "bundle_outputs"
         n = self.plan.named
@@ -72,9 +94,28 @@ class PipelinedDetector:
                                                *self._rargs, out.data_ptr(), st))
         return block, counts, out
 
-    def _forward(self, start, end):
-        self.plan.named["input_ptr"][0] = self.input.data_ptr()
-        self.eng.run_plan(self.plan, start, end)
+    def _forward(self, start, end, buf=0):
+        if self.u8_frame is None:
+            self.plan.named["input_ptr"][0] = self.input.data_ptr()
+            self.eng.run_plan(self.plan, start, end)
+            return
+        # the stem launch reads (pointer, h, w) of the uint8 frames when it is ISSUED: capture bakes buffer `buf` into the graph
+        self.plan.named["input_u8"][:] = [self.inputs_u8[buf].data_ptr(), self.u8_frame[0], self.u8_frame[1]]
+        try:
+            self.eng.run_plan(self.plan, start, end)
+        finally:
+            self.plan.named["input_u8"][0] = 0
+
+    def _capture_step(self, cap, side, buf):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=cap):
+            side.wait_stream(cap)                    # fork
+            with torch.cuda.stream(side):
+                outs = self._detect()                # batch k-1
+            self._forward(0, self.n_fwd, buf)        # batch k, everything but the bundling
+            cap.wait_stream(side)                    # join: outputs may now be overwritten
+            self._forward(self.n_fwd, None, buf)
+        return g, outs
 
     def _build(self):
         cap, side = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
@@ -83,14 +124,11 @@ class PipelinedDetector:
             self._forward(0, None)                       # warm-up outside capture: plan buffers, allocator pools,
             self._detect()                               # kernel attributes, zero page
             torch.cuda.synchronize(self.dev)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=cap):
-                side.wait_stream(cap)                    # fork
-                with torch.cuda.stream(side):
-                    self._block, self._counts, self._refined = self._detect()      # batch k-1
-                self._forward(0, self.n_fwd)             # batch k, everything but the bundling
-                cap.wait_stream(side)                    # join: outputs may now be overwritten
-                self._forward(self.n_fwd, None)
+            self.graph, (self._block, self._counts, self._refined) = self._capture_step(cap, side, 0)
+            if self.u8_frame is not None:                # second input buffer: its own graph, its own result tensors
+                self._graphs = [self.graph, None]
+                self._results = [(self._block, self._counts, self._refined), None]
+                self._graphs[1], self._results[1] = self._capture_step(cap, side, 1)
             # tail graph for flush(): detect only
             self.tail = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.tail, stream=cap):
@@ -112,12 +150,56 @@ class PipelinedDetector:
         self._clip.copy_(torch.from_numpy(np.zeros((B, 2), np.float32) if clip is None
                                           else np.asarray(clip, np.float32).reshape(B, 2)))
 
+    # ---- fed-input form ---------------------------------------------------------------------------------------------------------
+    def feed(self, frames):
+        """Upload one batch of uint8 BGR frames [B, h, w, 3] (pinned host memory for a truly asynchronous copy; a device tensor
+        works too) into the free input buffer on the copy stream.  At most two batches can be fed ahead of their step()."""
+        if self.u8_frame is None:
+            raise RuntimeError("feed() needs PipelinedDetector(..., u8_frame=(h, w))")
+        if len(self._fed) >= 2:
+            raise RuntimeError("feed(): both input buffers hold batches that were not submitted yet; call step()")
+        if frames.dtype != torch.uint8 or tuple(frames.shape) != tuple(self.inputs_u8[0].shape):
+            raise RuntimeError("feed(): uint8 frames of shape %s expected, got %s %s"
+                               % (tuple(self.inputs_u8[0].shape), frames.dtype, tuple(frames.shape)))
+        i = self._next_buf
+        self._next_buf ^= 1
+        with torch.cuda.stream(self._copy_stream):
+            if self._used[i]:
+                self._copy_stream.wait_event(self._done[i])      # the graph that read this buffer last has finished
+            self.inputs_u8[i].copy_(frames, non_blocking=True)
+            self._ready[i].record(self._copy_stream)
+        self._fed.append(i)
+
+    def step_fed(self, as_block=False):
+        """Submit the oldest fed batch; returns (dets, counts) of the batch submitted before it (None for the first call).  The
+        returned tensors belong to the graph of that input buffer and are overwritten two steps later."""
+        if not self._fed:
+            raise RuntimeError("step_fed(): no batch was fed")
+        i = self._fed.pop(0)
+        main = torch.cuda.current_stream(self.dev)
+        main.wait_event(self._ready[i])
+        had = self._pending
+        self._graphs[i].replay()
+        self._done[i].record(main)
+        self._used[i] = True
+        self._pending = True
+        if not had:
+            return None
+        block, counts, _ = self._results[i]
+        return (block if as_block else block[:, :-1], counts)
+
     def step(self, x=None, as_block=False, meta=None):
         """Submit batch k (copied into ``self.input`` unless x is None = already written there); returns
         (dets, counts) of batch k-1, or None for the first call.  Returned tensors are overwritten by the next step.
         as_block: return the [B, nms_topN_post + 1, 14] gather block (m3dssd_amd.dist.gather_block) instead of dets.
         refine mode: meta = {"p2": [B, 4, 4] (or [4, 4]), "scale": [B] or None, "clip_wh": [B, 2] or None} of batch k; the
         return value gains a third element, the refined rows [B, nms_topN_post, 16] (float64) of batch k-1."""
+        if self.u8_frame is not None:
+            if self.refine:
+                raise NotImplementedError("refine=True with fed uint8 frames: use step() with float frames")
+            if x is not None:
+                self.feed(x)
+            return self.step_fed(as_block)
         if x is not None:
             self.input.copy_(x)
         had = self._pending

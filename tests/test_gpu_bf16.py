@@ -37,7 +37,7 @@ def _dev():
 def _log(name, payload):
     d = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(d):
-        with open(os.path.join(d, "parity_r02.jsonl"), "a") as f:
+        with open(os.path.join(d, "parity_r04.jsonl"), "a") as f:
             f.write(json.dumps({"test": name, **payload}) + "\n")
 
 
@@ -788,7 +788,7 @@ def test_bf16_network_matches_fp32_oracle_within_stated_tolerance(crop, B, pad):
 
 # What the bf16 path means for the DECODED boxes (pixels / metres / radians), measured on the rows the fp32 oracle keeps: the
 # normalised regression outputs above go through exp() for the sizes and are scaled by anchor sizes for the centres.
-# Measured (2 frames of 1280x384, synthetic weights; gpurun_out/parity_r02.jsonl "bf16_physical_units"): rows kept after NMS --
+# Measured (2 frames of 1280x384, synthetic weights; gpurun_out/parity_r04.jsonl "bf16_physical_units"): rows kept after NMS --
 # 2-D corners median 1.5 px / max 5.4 px (boxes are hundreds of pixels wide: exp() of the size regression), projected 3-D centre
 # 0.31 / 0.82 px, depth 0.9 / 2.8 mm, w / h / l 1.1 % / 2.7 %, rotation 0.0025 / 0.007 rad; over the 3000 pre-NMS rows the
 # maxima are 21.7 px, 1.8 px, 9 mm, 6.3 %, 0.058 rad.  The bounds below are (median, max) with a 2x margin.

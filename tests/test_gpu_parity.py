@@ -387,7 +387,7 @@ def _parity_log(name, payload):
     import json
     d = os.path.join(os.path.dirname(GOLDEN.rstrip("/")), "..", "gpurun_out")
     if os.path.isdir(d):
-        with open(os.path.join(d, "parity_r02.jsonl"), "a") as f:
+        with open(os.path.join(d, "parity_r04.jsonl"), "a") as f:
             f.write(json.dumps({"test": name, **payload}) + "\n")
 
 

@@ -29,10 +29,10 @@ def _dev():
 
 
 def _log(name, payload):
-    """Measured margins of the parity tests, merged back from the GPU box (gpurun_out/parity_r02.jsonl)."""
+    """Measured margins of the parity tests, merged back from the GPU box (gpurun_out/parity_r04.jsonl)."""
     d = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(d):
-        with open(os.path.join(d, "parity_r02.jsonl"), "a") as f:
+        with open(os.path.join(d, "parity_r04.jsonl"), "a") as f:
             f.write(json.dumps({"test": name, **payload}) + "\n")
 
 

@@ -93,13 +93,20 @@ def test_data_parallel_wrapper_on_the_leased_device_equals_the_module():
     assert len(got) == 6
     for a, b in zip(got, ref):
         assert torch.equal(a, b)
-    rep = net._replicate_for_data_parallel()
+    # a REAL replica (torch.nn.parallel.replicate: `_parameters` is empty, the broadcast copies hang on it as plain attributes
+    # and every child is a replica too) must run: it asks the source module for the engine of its device
+    from torch.nn.parallel import replicate
+    rep = replicate(net, [0])[0]
+    assert rep is not net and len(list(rep.parameters())) == 0 and getattr(rep, "_is_replica", False)
     assert rep._engine is None and net._engine is not None
-    # the replica shares the parameters (DataParallel would have broadcast them): it packs its OWN engine and agrees
-    rep._parameters, rep._buffers, rep._modules = net._parameters, net._buffers, net._modules
     for a, b in zip(rep(x)[:4], ref[:4]):
         assert torch.equal(a, b)
-    assert rep._engine is not net._engine
+    assert rep.engine(x.device) is net._engine          # same device: the source's own packed engine, not a second copy
+    # a replica "on another device" packs a per-device engine once, from the source's state_dict, and keeps it across replicas
+    e1 = net._engine_for("cuda:0")
+    assert e1 is net._engine
+    net.refresh_engine()
+    assert "_device_engines" not in net.__dict__ and net._engine is None
 
 
 # ------------------------------------------------------------------------------------ bench.py, N > 1 branch
@@ -141,6 +148,15 @@ def test_bench_two_ranks_gloo_emits_one_parseable_line():
     assert r["value"] > 0 and abs(r["value"] - 16 * 3 / (r["ms_per_step"] * 3e-3)) / r["value"] < 0.01
     assert "configs2_bf16" not in r and "cpu_baseline" not in r          # N = 1 only
     assert r["roofline"]["frac"] > 0
+    # the N > 1 line proves what the collective saw and isolates its cost (VERDICT r3 #4d)
+    c = r["rccl"]
+    assert c["world_size"] == 2 and c["backend"] == "gloo" and len(c["ranks_seen"]) == 2
+    assert sorted(d["rank"] for d in c["ranks_seen"]) == [0, 1] and len({d["pid"] for d in c["ranks_seen"]}) == 2
+    assert c["distinct_devices"] == 1                   # both test ranks share the leased GPU (RCCL would need 2: see below)
+    assert c["gathered_rows"][0] == 16 and c["gathered_rows"][2] == 14 and c["allgather_us"] > 0
+    assert c["shards_recomputed_on_rank0"] == 2 and c["shards_match"] is True
+    assert r["step_roofline"]["mfma_frac"] > 0 and 0 < r["mfma_time_weighted_frac"] < 1
+    assert r["helper_kernels"]["bundle"]["algorithmic_gbs"] > 0
 
 
 def test_bench_nccl_refuses_more_ranks_than_devices():
@@ -357,7 +373,7 @@ def test_winograd_f4x4_conv3x3_matches_torch(case, nb):
         errs[kind] = ((got - ref).abs() / (1 + ref.abs())).max().item()
     d = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(d):
-        with open(os.path.join(d, "parity_r02.jsonl"), "a") as f:
+        with open(os.path.join(d, "parity_r04.jsonl"), "a") as f:
             f.write(json.dumps({"test": "wino44", "case": list(case), "nb": nb, **errs}) + "\n")
     assert errs["wino44"] < 2e-4, errs
 

@@ -77,7 +77,17 @@ def test_data_parallel_replica_does_not_share_the_engine(net_and_sd):
     net._engine = _Sentinel()
     rep = net._replicate_for_data_parallel()
     assert rep._engine is None and net._engine is not None
+    assert rep._src is net and "_src" not in rep._modules          # the source is referenced, not registered as a child
+    assert rep._replicate_for_data_parallel()._src is net          # a replica of a replica still points at the source
     net._engine = None
+    # what torch.nn.parallel.replicate makes of the module: no parameters, children replaced by replicas -- asking such a
+    # replica for its engine must reach the source's per-device cache (here: a CPU "device", refused with the CPU message)
+    rep._parameters, rep._former_parameters = {}, {"w": next(net.parameters()).detach()}
+    import pytest
+    with pytest.raises(NotImplementedError):
+        rep.engine()
+    with pytest.raises(NotImplementedError):
+        rep.engine("cpu")
     copy.deepcopy(net)                             # the post-hook must not break copying / pickling
     import pickle
     pickle.dumps(net._load_state_dict_post_hooks)

@@ -24,7 +24,10 @@ for cin, cout, H, W, B in SHAPES:
     ref = F.conv2d(xf[:1].double(), wf.double(), padding=1).float().permute(0, 2, 3, 1)
     fl = 2.0 * B * H * W * cout * 9 * cin
     line = "%3d->%3d %3dx%3d bs%d:" % (cin, cout, H, W, B)
-    for kind in ("F(2x2)", "F(4x4)", "F(4x4)+splitk"):
+    kinds = ("F(2x2)", "F(4x4)", "F(4x4)+splitk")
+    if "--nb" in sys.argv:                      # both workgroup forms of the F(4x4) kernel (M3D_W44_OCC2 picks the 64-channel build)
+        kinds = ("F(4x4)nb1", "F(4x4)nb2")
+    for kind in kinds:
         U = (pack_wino if kind == "F(2x2)" else pack_wino44)(wf, cout, dev)
         out = torch.zeros(B, H, W, cout, device=dev)
         d = _hip.ConvDesc()
@@ -43,6 +46,10 @@ for cin, cout, H, W, B in SHAPES:
             kind += "%d" % sp.value
         fn = (lambda: L.m3d_wino_conv3x3_forward_ex(ctypes.byref(d), 1, st)) if kind == "F(2x2)" else \
             (lambda: L.m3d_wino44_conv3x3_forward(ctypes.byref(d), st))
+        if kind.startswith("F(4x4)nb"):
+            if kind.endswith("2") and cout % 128:
+                continue
+            fn = lambda nbv=int(kind[-1]): L.m3d_wino44_conv3x3_forward_ex(ctypes.byref(d), nbv, st)    # noqa: E731
         if kind == "F(2x2)":                                 # the wave kernel's own split-K form where it plans one
             sp, wb = ctypes.c_int(), ctypes.c_longlong()
             _hip.check(L.m3d_wino_conv3x3_splitk_plan(ctypes.byref(d), ctypes.byref(sp), ctypes.byref(wb)))
