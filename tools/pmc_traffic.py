@@ -2,8 +2,11 @@
 """HBM traffic per launch from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
 
 Follows /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
-reports exactly half of the bytes of a wide (16 B/lane) coalesced streaming read -> doubled here (the igemm and
-MLP loaders are 16 B/lane); WRITE_SIZE is taken as is (uncalibrated per the guide -- ratios are reliable).
+reports exactly half of the bytes read -> doubled here; WRITE_SIZE is taken as is.  Round 4 calibrated both on known byte
+counts per ACCESS WIDTH (tools/ubench/pmc_calib.hip, profiles/r04_pmc_calibration.txt: 1 GiB through a buffer 4x the
+Infinity Cache): FETCH_SIZE x 2.000 for 4 / 8 / 16 B per lane, for 64-byte segments (the F(4x4) patch loads), for the
+8-lanes-per-line gather map and for LDS-DMA loads alike; WRITE_SIZE x 1.000 for 4 / 16 B per lane and 64-byte segments --
+one correction serves every kernel.  (FETCH_SIZE still counts Infinity-Cache hits: it is fabric traffic, an upper bound of HBM.)
 usage: python tools/pmc_traffic.py gpurun_out/pmc3 profiles/r01_hbm_traffic.json [launches.json]
 
 launches.json (``bench.py --dump-launches``: the ordered [family label, kernel base name] list of the MFMA launches of ONE
@@ -71,7 +74,7 @@ def main(d, out, launches=None):
                       "hbm_bytes_per_launch": int((2.0 * f[k] + w[k]) * 1024)}
     json.dump({"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs of "
                          "`bench.py --steps 3 --warmup 2 --no-graph`; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB "
-                         "(gfx950 wide-read correction of MI355X_MICROARCH.md); `families` = the same rows averaged per "
+                         "(factors calibrated per access width in profiles/r04_pmc_calibration.txt: 2.000 / 1.000 for every width); `families` = the same rows averaged per "
                          "engine family label (aligned with bench.py --dump-launches by dispatch order)",
                "families": fam, "kernels": res},
               open(out, "w"), indent=1)
