@@ -173,7 +173,8 @@ def kernel_symbol(label):
         return "wino44_c16_kernel(Wino44C16Args)"
     if label.startswith("wino44"):                 # wino44<16,32[,splitkN]>: 16 tiles x 32 (NB = 2) or 16 (NB = 1) channels per wave
         nb = int(re.findall(r"\d+", label)[2]) // 16   # (the 64-channel form runs two workgroups per CU unless M3D_W44_OCC2=0)
-        return "void wino44_kernel<%d, %d>(Wino44Args)" % (nb, 2 if (nb == 1 and os.environ.get("M3D_W44_OCC2", "1") != "0") else 1)
+        occ = 2 if (nb == 1 and os.environ.get("M3D_W44_OCC2", "1") != "0") else 1
+        return "void wino44_kernel<%d, %d, %d>(Wino44Args)" % (nb, occ, 2 if "kpair" in label else 1)
     if label.startswith("wino_wave"):
         return "void wino_wave_kernel<%s>(WinoArgs)" % ("true" if "splitk" in label else "false")
     if label.startswith("wino"):

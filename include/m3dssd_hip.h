@@ -138,11 +138,14 @@ int m3d_wino_conv3x3_forward_ex(const m3d_conv_desc *d, int variant, m3d_stream_
  * Cin = 128). */
 int m3d_wino44_applicable(const m3d_conv_desc *d);
 int m3d_wino44_conv3x3_forward(const m3d_conv_desc *d, m3d_stream_t stream);
-/* nb = 16-channel blocks per wave: 2 (128-channel workgroups; needs Cout_pad % 128 == 0), 1 (64-channel workgroups), 0 = 2 where
- * the 16-tile strips x 128-channel blocks give >= 200 workgroups, else 1 (tests, tuning). */
+/* nb = 16-channel blocks per wave: 1 or 0 = 64-channel workgroups, two per CU (round 4: the faster form on every layer); 2 =
+ * 128-channel workgroups, one per CU with the whole register file (needs Cout_pad % 128 == 0; round 3's form, kept for A/B runs).
+ * Layers whose 64-channel workgroups would fill less than ~60 % of the 512 CU slots run "K-pair" workgroups (512 threads: the two
+ * halves of the input channels side by side, accumulators traded through LDS at the end): m3d_wino44_kpair() says whether. */
 int m3d_wino44_conv3x3_forward_ex(const m3d_conv_desc *d, int nb, m3d_stream_t stream);
-/* Split-K for maps whose 16-tile strips x 128-channel blocks do not fill the chip (256 -> 256 @ 24x80, 512 -> 512 @ 12x40 at
- * bs 8): *splits slices of >= 64 input channels run as gridDim.z, raw partial outputs go to splitk_ws ([splits][N*H*W][Cout_pad]
+int m3d_wino44_kpair(const m3d_conv_desc *d);
+/* Split-K for maps whose 16-tile strips x 64-channel blocks do not fill the chip (512 -> 512 @ 12x40 at bs 8):
+ * *splits slices of >= 64 input channels run as gridDim.z, raw partial outputs go to splitk_ws ([splits][N*H*W][Cout_pad]
  * fp32, *ws_bytes), a second launch adds them in slice order and applies the epilogue.  *splits = 1 / *ws_bytes = 0: no split.
  * m3d_wino44_conv3x3_forward[_ex with nb != 1] splits when the descriptor carries a workspace of at least *ws_bytes. */
 int m3d_wino44_splitk_plan(const m3d_conv_desc *d, int *splits, long long *ws_bytes);

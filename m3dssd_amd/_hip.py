@@ -108,6 +108,7 @@ SIGNATURES = {
     "m3d_wino44_applicable": (c_int, [ctypes.POINTER(ConvDesc)]),
     "m3d_wino44_conv3x3_forward": (c_int, [ctypes.POINTER(ConvDesc), P]),
     "m3d_wino44_conv3x3_forward_ex": (c_int, [ctypes.POINTER(ConvDesc), c_int, P]),
+    "m3d_wino44_kpair": (c_int, [ctypes.POINTER(ConvDesc)]),
     "m3d_wino44_conv3x3_forward_touch": (c_int, [ctypes.POINTER(ConvDesc), c_int, P, c_ll, P]),
     "m3d_cache_touch": (c_int, [P, c_ll, P]),
     "m3d_wino44_splitk_plan": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int), ctypes.POINTER(c_ll)]),

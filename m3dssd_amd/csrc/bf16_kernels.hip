@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(const void *__restrict__
                 f[2 * e] = leaky(acc2[o][0] * scale[2 * o] + shift[2 * o]);
                 f[2 * e + 1] = leaky(acc2[o][1] * scale[2 * o + 1] + shift[2 * o + 1]);
             }
-            *reinterpret_cast<u32x4 *>(op + o8 * 8) = pack8(f);
+            global_store_u32x4_nop(op + o8 * 8, pack8(f));    // (store-data hazard found here by tools/check_isa_hazards.py: common.h)
         }
     }
 }

@@ -70,6 +70,22 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, un
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
 }
+// ---- the ">64-bit store data" hazard of gfx950 --------------------------------------------------------------------------------
+// A 12- / 16-byte buffer / global store reads its data registers AFTER it has issued: a VALU write of those registers within the
+// next 1 (buffer store, SGPR soffset) or 2 (global store, literal soffset) instructions lands in the stored data (element 1 of
+// lanes 12-15 / 28-31 / 44-47 / 60-63 first; tools/ubench/vmem_war_hazards.hip reproduces it: 5 % wrong dwords at 0 wait states).
+// hipcc (ROCm 7.2) does not insert the wait states for gfx950 -- round 4 found `buffer_store_dwordx4 v[4:7]` directly followed by
+// `v_pk_fma_f32 v[4:5]` in the K-pair F(4x4) epilogue.  tools/check_isa_hazards.py scans every kernel's ISA for the pattern (part
+// of the build check); where it fires, the store goes through these helpers: the wait states sit inside the same asm statement.
+__device__ __forceinline__ void buf_store_f32x4_nop(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voffset, unsigned soffset)
+{
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" : : "v"(v), "v"(voffset), "s"(r), "s"(soffset) : "memory");
+}
+__device__ __forceinline__ void global_store_u32x4_nop(void *p, u32x4 v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ f32x4 buf_load_f32x4(__amdgpu_buffer_rsrc_t r, unsigned voffset, unsigned soffset)
 {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voffset, soffset, 0));

@@ -99,10 +99,11 @@ __device__ __forceinline__ void w44_bt(const float x0, const float x1, const flo
 }
 // y = A^T m: A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]; on f32x4 = the four tiles of a lane at once (four
 // independent chains per instruction: the epilogue runs with one wave per SIMD and nothing else to hide a dependent add behind)
-__device__ __forceinline__ void w44_at(const f32x4 m0, const f32x4 m1, const f32x4 m2, const f32x4 m3, const f32x4 m4, const f32x4 m5,
-                                       f32x4 &y0, f32x4 &y1, f32x4 &y2, f32x4 &y3)
+template <typename VT>
+__device__ __forceinline__ void w44_at(const VT m0, const VT m1, const VT m2, const VT m3, const VT m4, const VT m5,
+                                       VT &y0, VT &y1, VT &y2, VT &y3)
 {
-    const f32x4 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+    const VT s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
     y0 = m0 + s1 + s2;
     y1 = d2 * 2.f + d1;
     y2 = s2 * 4.f + s1;
@@ -116,12 +117,22 @@ __device__ __forceinline__ void w44_at(const f32x4 m0, const f32x4 m1, const f32
 // VALU instruction between the v_mfma_f32_16x16x4_f32 of ONE wave costs the stream 12.6 cycles (6-7 each in runs of 4-6), whatever
 // the instruction (v_fma / v_add / packed / v_accvgpr_mov alike); with a second wave on the SIMD the same instruction costs 1.4-4
 // cycles, because the partner's MFMAs issue into the gap -- and the prologue / epilogue of one workgroup run under the other's MFMAs.
-template <int NB, int OCC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void wino44_kernel(const Wino44Args a)
+// KS = 2 (NB = 1, OCC = 2): the "K-pair" workgroup for layers whose 16-tile strips x 64-channel blocks leave half the CU slots
+// empty (256 -> 256 @ 24x80 at bs 8: 240 workgroups for 512 slots -- one wave per SIMD, every transform instruction at the
+// 12.6-cycle price): 512 threads, waves 0-3 run the first half of the slice's input channels, waves 4-7 the second half, each
+// half with its own V double buffer (2 x 73.7 KB: what two co-resident workgroups would hold) -- two waves per SIMD again without
+// a global workspace; at the end the halves trade half of their accumulators through the (free) V buffers (half 0 keeps tiles
+// {0, 1} of every lane's four, half 1 tiles {2, 3}), add, and EACH runs the output transform / epilogue of its 8 tiles.
+template <int NB, int OCC, int KS = 1>
+__global__ __launch_bounds__(256 * KS) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void wino44_kernel(const Wino44Args a)
 {
-    __shared__ __attribute__((aligned(16))) float Vs[2 * 36 * 256];     // V[buf][xi][tile 16][channel 16]
+    static_assert(KS == 1 || (KS == 2 && NB == 1 && OCC == 2), "K-pair form: 64-channel waves, two per SIMD");
+    __shared__ __attribute__((aligned(16))) float Vs_all[KS * 2 * 36 * 256];   // V[K half][buf][xi][tile 16][channel 16]
     __shared__ int pixb[16];                                             // first output pixel of each tile (-1: no such tile)
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid8 = threadIdx.x, lane = tid8 & 63;
+    const int kh = KS == 2 ? __builtin_amdgcn_readfirstlane(tid8 >> 8) : 0;      // K half of this wave
+    const int tid = tid8 & 255;                                          // thread within its half: transform unit, wave = channel block
+    float *const Vs = Vs_all + kh * (2 * 36 * 256);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // split-K (grid.z slices of the input channels, small maps): this workgroup runs stages [s0, s0 + NS) and stores its raw
     // A^T M A sums to slice blockIdx.z of the workspace (the launcher clears scale / shift / residual / activation for the
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             bz = combo / (int)gridDim.y;
         }
     }
-    const int s0 = bz * a.nsl;
+    const int s0 = (bz * KS + kh) * a.nsl;             // (a.nsl = stages per wave: Cin / 16 / (gridDim.z * KS))
     W44_TRACE_INIT();
     W44_TRACE();
 
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         const int tt = tv ? t : 0;
         const int n = tt / (a.TH * a.TW), rem = tt - n * a.TH * a.TW;
         const int ty = rem / a.TW, tx = rem - ty * a.TW;
-        if (uc == 0) pixb[ut] = tv ? (n * a.H + 4 * ty) * a.W + 4 * tx : -1;
+        if (uc == 0 && kh == 0) pixb[ut] = tv ? (n * a.H + 4 * ty) * a.W + 4 * tx : -1;
         const bool c5ok = 4 * tx + 4 < a.W;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
@@ -247,7 +258,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     if (a.touch) {
         const int nwg = gridDim.x * gridDim.y * gridDim.z;
         const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        for (int i = wg * 256 + tid; i < a.touch_lines; i += nwg * 256)
+        for (int i = wg * (256 * KS) + tid8; i < a.touch_lines; i += nwg * (256 * KS))
             asm volatile("global_load_dword %0, %1, off" : "=v"(touched) : "v"(a.touch + (size_t)i * 128) : "memory");
     }
     // ---- prologue: stage 0's patch, transform, first B fragments, stage 1's patch ------------------------------------------
@@ -354,47 +365,83 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     // floats: the four tile groups of a store instruction land in different banks), read back as (tile k, pixel lane >> 2,
     // channel quad lane & 3): 1 KB contiguous per read, 16 bytes per lane per store, residual fetched in the same shape.
     __syncthreads();                                  // every wave is done with the last stage's V
+    // K-pair form: trade accumulator halves.  A lane's f32x4 accumulator covers tiles 4 aq + {0, 1, 2, 3}; half 0 finishes tiles
+    // {0, 1}, half 1 tiles {2, 3}: each writes the pair the OTHER half finishes ([half][xi][thread] f32x2: 2 x 73.7 KB = the V
+    // buffers), then adds what it receives to the pair it kept (own + other: the two halves add the same two numbers).
+    constexpr int NI = KS == 2 ? 2 : 4;               // tiles of a lane this wave finishes
+    constexpr int NTW = KS == 2 ? 8 : 16;             // ... of the strip's 16
+    using VT = std::conditional_t<KS == 2, f32x2, f32x4>;
+    const int ioff = KS == 2 ? 2 * kh : 0;
+    VT accv[36][NB];
+    if constexpr (KS == 2) {
+        f32x2 *xb = reinterpret_cast<f32x2 *>(Vs_all);
+#pragma unroll
+        for (int x = 0; x < 36; ++x) {
+            const f32x4 v = acc[x][0];
+            xb[(kh * 36 + x) * 256 + tid] = kh == 0 ? f32x2{v[2], v[3]} : f32x2{v[0], v[1]};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < 36; ++x) {
+            const f32x4 v = acc[x][0];
+            const f32x2 o = xb[((kh ^ 1) * 36 + x) * 256 + tid];
+            accv[x][0] = (kh == 0 ? f32x2{v[0], v[1]} : f32x2{v[2], v[3]}) + o;
+            // (all 36 reads hoisted in front of the adds = 72 more live registers next to the 144 accumulators: spills)
+            if (x % 6 == 5) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                              // the traded values are consumed: the LDS takes the output tiles now
+    } else {
+#pragma unroll
+        for (int x = 0; x < 36; ++x)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) accv[x][j] = __builtin_bit_cast(VT, acc[x][j]);
+    }
+    // ---- A^T M A in registers (lane = channel co0 + 16 j + (lane & 15), tiles 4 (lane >> 4) + i), then through the wave's slice
+    // of the (now free) V buffers so that the stores are 16 bytes per lane: a lane holds ONE channel of 4 tiles x 16 pixels -- written
+    // out directly that is 128 four-byte stores per lane, 64 bytes contiguous per pixel, and took 18000 of the workgroup's 131000
+    // cycles (tools/wino44_trace.py).  Per 16-channel block: [tiles][16 pixels + pad][16 channels] in LDS (tile stride 272
+    // floats: the four tile groups of a store instruction land in different banks), read back as (tile k, pixel lane >> 2,
+    // channel quad lane & 3): 1 KB contiguous per read, 16 bytes per lane per store, residual fetched in the same shape.
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out + (size_t)bz * a.ws_slice, a.out_bytes);
     const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res ? a.res : a.out, a.res ? a.res_bytes : 0u);
-    float *ot = Vs + wave * (16 * 272);               // this wave's slice: 17 KB of the 72 KB
+    float *ot = Vs_all + (kh * 4 + wave) * (NTW * 272);   // this wave's slice: 17 KB (K-pair: 8.5 KB) of the V buffers
     const int opx = lane >> 2, ocq = lane & 3;        // read-back role: pixel of the 4x4 tile, channel quad
     const unsigned pixoff = (unsigned)((opx >> 2) * a.W + (opx & 3));
+    // slot lt of the wave's slice holds tile tile_of(lt) of the strip
+    auto tile_of = [&](int lt) __attribute__((always_inline)) { return KS == 2 ? 4 * (lt >> 1) + ioff + (lt & 1) : lt; };
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        // the residual of the whole block is fetched in one go (16 loads in flight under the second transform pass; fetched inside
+        // the residual of the whole block is fetched in one go (loads in flight under the second transform pass; fetched inside
         // the store loop every iteration waited out its own memory round trip)
         const int c0 = (cb16 + j) * 16 + ocq * 4;     // first of this lane's four channels
         const bool blockfull = (cb16 + j) * 16 + 16 <= a.Cout;
         const unsigned ovoff = (pixoff * (unsigned)a.out_cs + (unsigned)c0) * 4u, rvoff = (pixoff * (unsigned)a.res_cs + (unsigned)c0) * 4u;
-        f32x4 rvv[16];
+        f32x4 rvv[NTW];
         {
-            f32x4 z[4][6];                         // A^T M: rows yy, columns b; the vector runs over the lane's four tiles
+            VT z[4][6];                            // A^T M: rows yy, columns b; the vector runs over the lane's tiles
 #pragma unroll
             for (int b = 0; b < 6; ++b)
-                w44_at(acc[0 * 6 + b][j], acc[1 * 6 + b][j], acc[2 * 6 + b][j], acc[3 * 6 + b][j], acc[4 * 6 + b][j], acc[5 * 6 + b][j],
+                w44_at(accv[0 * 6 + b][j], accv[1 * 6 + b][j], accv[2 * 6 + b][j], accv[3 * 6 + b][j], accv[4 * 6 + b][j], accv[5 * 6 + b][j],
                        z[0][b], z[1][b], z[2][b], z[3][b]);
             // the block's accumulators are dead now: their registers take the residual, fetched under the second pass (earlier --
             // before the first pass -- the kernel needed more than its 512 registers, and a compiler-inserted spill is a vector
             // memory instruction that breaks the hand-counted vmcnt of the main loop)
             if (a.res && blockfull) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int pb = __builtin_amdgcn_readfirstlane(pixb[k]);
+                for (int k = 0; k < NTW; ++k) {
+                    const int pb = __builtin_amdgcn_readfirstlane(pixb[tile_of(k)]);
                     rvv[k] = buf_load_f32x4(rres, rvoff, pb >= 0 ? (unsigned)pb * (unsigned)a.res_cs * 4u : M3D_BUF_OOB);
                 }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) rvv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            float *op = ot + (4 * aq) * 272 + atile;
+            }                                      // (no residual: rvv stays unread -- zero-filled, the K-pair build spilled the zeros)
+            float *op = ot + (NI * aq) * 272 + atile;
 #pragma unroll
             for (int yy = 0; yy < 4; ++yy) {
-                f32x4 y[4];
+                VT y[4];
                 w44_at(z[yy][0], z[yy][1], z[yy][2], z[yy][3], z[yy][4], z[yy][5], y[0], y[1], y[2], y[3]);
 #pragma unroll
                 for (int xx = 0; xx < 4; ++xx)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) op[i * 272 + (yy * 4 + xx) * 16] = y[xx][i];
+                    for (int i = 0; i < NI; ++i) op[i * 272 + (yy * 4 + xx) * 16] = y[xx][i];
             }
         }
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -408,26 +455,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         // stores, channels past Cout into the lane offset (the buffer range check drops the access).  Only a 16-channel block
         // that straddles Cout (wave-uniform test) takes the element-wise path.
         if (blockfull) {
-            // LeakyReLU as max(v, slope v) with slope 1 = none; without a residual rvv is zero
+            // LeakyReLU as max(v, slope v) with slope 1 = none
             const float slope = a.act == 1 ? M3D_LEAKY_SLOPE : 1.f;
-            auto body = [&](auto rm_tag) __attribute__((always_inline)) {
-                constexpr bool RM1 = decltype(rm_tag)::value;
+            auto body = [&](auto mode_tag) __attribute__((always_inline)) {
+                constexpr int MODE = decltype(mode_tag)::value;          // 0: no residual, 1: (v * sc + sh) + r, 2: (v + r) * sc + sh
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int pb = __builtin_amdgcn_readfirstlane(pixb[k]);
+                for (int k = 0; k < NTW; ++k) {
+                    const int pb = __builtin_amdgcn_readfirstlane(pixb[tile_of(k)]);
                     const unsigned osoff = pb >= 0 ? (unsigned)pb * (unsigned)a.out_cs * 4u : M3D_BUF_OOB;
                     f32x4 v = *reinterpret_cast<const f32x4 *>(ot + k * 272 + lane * 4);
-                    const f32x4 rv = rvv[k];
-                    if constexpr (RM1) v = (v + rv) * sc + sh;
-                    else v = v * sc + sh + rv;
+                    if constexpr (MODE == 2) v = (v + rvv[k]) * sc + sh;
+                    else if constexpr (MODE == 1) v = v * sc + sh + rvv[k];
+                    else v = v * sc + sh;
                     v = __builtin_elementwise_max(v, v * slope);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, ovoff, osoff, 0);
+                    buf_store_f32x4_nop(v, rout, ovoff, osoff);      // (+ the store-data wait states: common.h)
                 }
             };
-            if (a.res_mode) body(std::true_type{}); else body(std::false_type{});
+            if (!a.res) body(std::integral_constant<int, 0>{});
+            else if (a.res_mode) body(std::integral_constant<int, 2>{});
+            else body(std::integral_constant<int, 1>{});
         } else {
-            for (int k = 0; k < 16; ++k) {
-                const int pb = __builtin_amdgcn_readfirstlane(pixb[k]);
+            for (int k = 0; k < NTW; ++k) {
+                const int pb = __builtin_amdgcn_readfirstlane(pixb[tile_of(k)]);
                 const unsigned osoff = pb >= 0 ? (unsigned)pb * (unsigned)a.out_cs * 4u : M3D_BUF_OOB;
                 const unsigned rsoff = pb >= 0 ? (unsigned)pb * (unsigned)a.res_cs * 4u : M3D_BUF_OOB;
                 const f32x4 v0 = *reinterpret_cast<const f32x4 *>(ot + k * 272 + lane * 4);
@@ -613,11 +662,12 @@ static int w44_scratch_bytes()
     static int scratch = 0;
     std::call_once(once, []() {
 #ifndef WINO_TRACE
-        hipFuncAttributes f1, f2, f3;
+        hipFuncAttributes f1, f2, f3, f4;
         if (hipFuncGetAttributes(&f1, reinterpret_cast<const void *>(&wino44_kernel<1, 1>)) == hipSuccess &&
             hipFuncGetAttributes(&f2, reinterpret_cast<const void *>(&wino44_kernel<2, 1>)) == hipSuccess &&
-            hipFuncGetAttributes(&f3, reinterpret_cast<const void *>(&wino44_kernel<1, 2>)) == hipSuccess)
-            scratch = (int)(f1.localSizeBytes + f2.localSizeBytes + f3.localSizeBytes);
+            hipFuncGetAttributes(&f3, reinterpret_cast<const void *>(&wino44_kernel<1, 2>)) == hipSuccess &&
+            hipFuncGetAttributes(&f4, reinterpret_cast<const void *>(&wino44_kernel<1, 2, 2>)) == hipSuccess)
+            scratch = (int)(f1.localSizeBytes + f2.localSizeBytes + f3.localSizeBytes + f4.localSizeBytes);
         else
             (void)hipGetLastError();
 #endif
@@ -641,7 +691,8 @@ extern "C" int m3d_wino44_applicable(const m3d_conv_desc *d)
 // the kernel does not serve) reports 1 / 0.
 // Form of the split-K launches: M3D_W44_SPLIT_NB = 2 (128-channel workgroups, one per CU) or 1 (64-channel workgroups, two per CU:
 // `fill` = 480 workgroups); M3D_W44_SPLIT_FILL overrides the number of workgroups a layer must reach to run unsplit.
-static int w44_split_nb() { static const int v = []() { const char *e = getenv("M3D_W44_SPLIT_NB"); return e ? atoi(e) : 1; }(); return v == 2 ? 2 : 1; }
+// 3 = K-pair workgroups (64-channel, 512 threads, one per CU) inside every global slice: half the slices, half the workspace.
+static int w44_split_nb() { static const int v = []() { const char *e = getenv("M3D_W44_SPLIT_NB"); return e ? atoi(e) : 1; }(); return (v == 2 || v == 3) ? v : 1; }
 static int w44_split_fill()
 {
     static const int v = []() { const char *e = getenv("M3D_W44_SPLIT_FILL"); return e ? atoi(e) : 0; }();
@@ -652,11 +703,12 @@ extern "C" int m3d_wino44_splitk_plan(const m3d_conv_desc *d, int *splits, long 
 {
     M3D_REQUIRE(d && splits && ws_bytes, "wino44_splitk_plan: null pointer");
     *splits = 1; *ws_bytes = 0;
-    const int cw = w44_split_nb() == 1 ? 64 : 128;
+    const int cw = w44_split_nb() == 2 ? 128 : 64;
     if (!m3d_wino44_applicable(d) || d->Cout_pad % cw) return M3D_OK;
     const long long wgs = (long long)cdiv(d->N * (d->H / 4) * (d->W / 4), 16) * (d->Cout_pad / cw);
-    const int ns = d->Cin / 16, fill = w44_split_fill();
-    if (wgs >= fill) return M3D_OK;
+    const int kp = w44_split_nb() == 3 ? 2 : 1;       // K-pair: every slice is halved again inside its workgroups
+    const int ns = d->Cin / 16 / kp, fill = w44_split_fill();
+    if (wgs >= fill || (d->Cin / 16) % kp) return M3D_OK;
     for (int sp = 2; sp <= 8; sp *= 2) {
         if (ns % sp || ns / sp < 4) break;
         if (wgs * sp >= fill) {
@@ -666,6 +718,18 @@ extern "C" int m3d_wino44_splitk_plan(const m3d_conv_desc *d, int *splits, long 
         }
     }
     return M3D_OK;
+}
+
+// 1 if the unsplit 64-channel launch of the layer runs K-pair workgroups (512 threads, the two halves of the input channels side
+// by side): the 64-channel workgroups would leave more than ~40 % of the 512 CU slots empty and each half still runs >= 4 stages
+extern "C" int m3d_wino44_kpair(const m3d_conv_desc *d)
+{
+    if (!d || !m3d_wino44_applicable(d)) return 0;
+    static const int kpair_max = []() { const char *e = getenv("M3D_W44_KPAIR_MAX"); return e ? atoi(e) : 300; }();
+    static const int occ2 = []() { const char *e = getenv("M3D_W44_OCC2"); return e ? atoi(e) : 1; }();
+    const int ns = d->Cin / 16;
+    const long long wgs = (long long)cdiv(d->N * (d->H / 4) * (d->W / 4), 16) * (d->Cout_pad / 64);
+    return (occ2 && wgs <= kpair_max && ns % 2 == 0 && ns / 2 >= 4) ? 1 : 0;
 }
 
 extern "C" int m3d_wino44_conv3x3_forward_touch(const m3d_conv_desc *d, int nb, const void *touch, long long touch_bytes,
@@ -696,7 +760,7 @@ extern "C" int m3d_wino44_conv3x3_forward_touch(const m3d_conv_desc *d, int nb, 
     const int strips = cdiv(a.NT, 16);
     M3D_REQUIRE(nb >= 0 && nb <= 2 && !(nb == 2 && d->Cout_pad % 128), "wino44: nb = 0 (automatic), 1 or 2 (needs Cout_pad %% 128 == 0)");
     // split-K when the caller provides the workspace the plan asks for (the form -- 128- or 64-channel workgroups -- is the plan's)
-    if (d->splitk_ws && (nb == 0 || nb == w44_split_nb())) {
+    if (d->splitk_ws && (nb == 0 || nb == (w44_split_nb() == 2 ? 2 : 1))) {
         int splits = 1;
         long long need = 0;
         if (const int rc = m3d_wino44_splitk_plan(d, &splits, &need)) return rc;
@@ -708,7 +772,10 @@ extern "C" int m3d_wino44_conv3x3_forward_touch(const m3d_conv_desc *d, int nb, 
             a.scale = a.shift = a.res = nullptr; a.res_bytes = 0; a.act = 0; a.res_mode = 0; a.Cout = d->Cout_pad;
             if (w44_split_nb() == 1)
                 hipLaunchKernelGGL((wino44_kernel<1, 2>), dim3(strips, d->Cout_pad / 64, splits), dim3(256), 0, (hipStream_t)stream, a);
-            else
+            else if (w44_split_nb() == 3) {       // K-pair workgroups inside every global K slice (half the slices, half the workspace)
+                a.nsl = d->Cin / 16 / (splits * 2);
+                hipLaunchKernelGGL((wino44_kernel<1, 2, 2>), dim3(strips, d->Cout_pad / 64, splits), dim3(512), 0, (hipStream_t)stream, a);
+            } else
                 hipLaunchKernelGGL((wino44_kernel<2, 1>), dim3(strips, d->Cout_pad / 128, splits), dim3(256), 0, (hipStream_t)stream, a);
             M3D_LAUNCH_CHECK();
             SplitkReduceArgs r;
@@ -722,6 +789,14 @@ extern "C" int m3d_wino44_conv3x3_forward_touch(const m3d_conv_desc *d, int nb, 
     // 128-channel form (one per CU, the whole register file) explicitly
     const bool nb2 = d->Cout_pad % 128 == 0 && nb == 2;
     static const int occ2 = []() { const char *e = getenv("M3D_W44_OCC2"); return e ? atoi(e) : 1; }();
+    // K-pair workgroups (512 threads, the two halves of the input channels side by side) where the 64-channel workgroups would
+    // leave more than ~40 % of the 512 CU slots empty and each half still runs >= 4 stages
+    if (!nb2 && m3d_wino44_kpair(d)) {
+        a.nsl = d->Cin / 16 / 2;
+        hipLaunchKernelGGL((wino44_kernel<1, 2, 2>), dim3(strips, d->Cout_pad / 64), dim3(512), 0, (hipStream_t)stream, a);
+        M3D_LAUNCH_CHECK();
+        return M3D_OK;
+    }
     if (nb2) hipLaunchKernelGGL((wino44_kernel<2, 1>), dim3(strips, d->Cout_pad / 128), dim3(256), 0, (hipStream_t)stream, a);
     else if (occ2) hipLaunchKernelGGL((wino44_kernel<1, 2>), dim3(strips, d->Cout_pad / 64), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((wino44_kernel<1, 1>), dim3(strips, d->Cout_pad / 64), dim3(256), 0, (hipStream_t)stream, a);

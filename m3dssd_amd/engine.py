@@ -171,6 +171,7 @@ WINO44_TOUCH = os.environ.get("M3D_WINO44_TOUCH", "1") != "0"
 WINO44_TOUCH_SPAN = int(os.environ.get("M3D_WINO44_TOUCH_SPAN", "2"))   # launches between two F(4x4) layers that a folded touch bridges
 USE_WINO44_SPLITK = os.environ.get("M3D_WINO44_SPLITK", "1") != "0"
 W44_SPLIT_NB = 2 if os.environ.get("M3D_W44_SPLIT_NB", "1") == "2" else 1    # form of the split-K launches (csrc/wino44_conv.hip)
+W44_SPLIT_KPAIR = os.environ.get("M3D_W44_SPLIT_NB", "1") == "3"             # ... K-pair workgroups inside every slice
 # Round 4: the 64-channel form runs TWO workgroups per CU (wino44_kernel<1, 2>) and beats the 128-channel form on every layer
 # (128 -> 128 @ 48x160: 0.056 vs 0.065 ms, 128 -> 256: 0.114 vs 0.130); the 128-channel form is kept for experiments
 # (M3D_WINO44_MIN_WGS=200 restores the round-3 choice).
@@ -416,7 +417,8 @@ class Engine:
                     plan.ops.append((name + ".touch", "touch", 0.0,
                                      lambda st: _hip.check(L.m3d_cache_touch(u44.data_ptr(), nbytes, st)), OpCost(nbytes)))
             plan.w44_prev = (len(plan.ops), nxt)
-            plan.ops.append((name, "wino44<16,%d%s>" % (16 * nb, ",splitk%d" % ks44 if ks44 > 1 else ""), flops,
+            kp = ",kpair" if (nb == 1 and ((ks44 == 1 and L.m3d_wino44_kpair(ref) == 1) or (ks44 > 1 and W44_SPLIT_KPAIR))) else ""
+            plan.ops.append((name, "wino44<16,%d%s%s>" % (16 * nb, ",splitk%d" % ks44 if ks44 > 1 else "", kp), flops,
                              lambda st: _hip.check(L.m3d_wino44_conv3x3_forward_touch(ref, nb, nxt["ptr"], nxt["bytes"], st)), d))
             return
         if (pc is not None and wgt_ptr is None and getattr(pc, "wino", None) is not None and kh == 3 and kw == 3

@@ -204,8 +204,9 @@ def test_bench_config_batch8_wave_plan_matches_oracle_directly():
         cls, prob, b2, b3 = (t.cpu() for t in net(x.to(dev))[:4])
     plan = net.engine().plan_for(B, *crop)
     kinds = {op[1] for op in plan.ops}
-    # (round 3: the 3x3 stride-1 layers of level2..5 and cls.0 run on the F(4x4,3x3) kernel, level5 in its split-K form)
-    assert any(k.startswith("wino44<16,32,splitk") for k in kinds) and "wino44<16,16>" in kinds and "wino44<16,32>" in kinds, kinds
+    # (round 3: the 3x3 stride-1 layers of level2..5 and cls.0 run on the F(4x4,3x3) kernel, level5 in its split-K form; round 4:
+    # all of them on the 64-channel form at two workgroups per CU, level4 -- 240 workgroups for 512 slots -- as K-pair workgroups)
+    assert any(k.startswith("wino44<16,16,splitk") for k in kinds) and "wino44<16,16>" in kinds and "wino44<16,16,kpair>" in kinds, kinds
     assert any(k.startswith("conv_wave<deform") for k in kinds), kinds
     fh, fw = crop[0] // 8, crop[1] // 8
     ind = plan.named["sel_idx"].view(B, 1, fh, fw).long().cpu()

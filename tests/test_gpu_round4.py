@@ -118,6 +118,32 @@ def test_winograd_f4x4_two_workgroups_per_cu_matches_float64(case):
         assert torch.equal(out, first)
 
 
+@pytest.mark.parametrize("case", [(128, 128, 16, 48, 2, True), (256, 256, 24, 80, 2, False), (512, 64, 8, 12, 1, True)])
+def test_winograd_f4x4_kpair_workgroups_match_float64_and_the_plain_form(case):
+    """Layers too small to fill the CU slots run K-pair workgroups (512 threads, the two halves of the input channels side by
+    side, accumulators traded through LDS): against float64, against the plain 64-channel form (summation order differs:
+    tolerance), and run to run bit-identical."""
+    cin, cout, H, W, B, res = case
+    L = _hip.lib()
+    d, out, ref, keep = _w44_case(cin, cout, H, W, B, res=res)
+    assert L.m3d_wino44_kpair(ctypes.byref(d)) == 1
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _hip.check(L.m3d_wino44_conv3x3_forward_ex(ctypes.byref(d), 1, st))
+    torch.cuda.synchronize()
+    got = out.clone()
+    err = ((got.cpu() - ref).abs() / (1 + ref.abs())).max().item()
+    assert err < 2e-4, err
+    for _ in range(10):
+        out.zero_()
+        _hip.check(L.m3d_wino44_conv3x3_forward_ex(ctypes.byref(d), 1, st))
+        torch.cuda.synchronize()
+        assert torch.equal(out, got)
+    if cout % 128 == 0:
+        _hip.check(L.m3d_wino44_conv3x3_forward_ex(ctypes.byref(d), 2, st))      # the 128-channel form: one K chain
+        torch.cuda.synchronize()
+        assert ((out - got).abs() / (1 + got.abs())).max().item() < 1e-4
+
+
 def test_winograd_f4x4_occupancy_builds_agree_bit_for_bit():
     """M3D_W44_OCC2=0 selects the one-workgroup-per-CU build of the 64-channel form: same arithmetic in the same order, so the two
     builds must produce identical bits (read once per process: a child process runs the other build)."""
@@ -139,7 +165,7 @@ torch.save(out.cpu(), sys.argv[1])
     with tempfile.TemporaryDirectory() as td:
         for occ in ("0", "1"):
             path = os.path.join(td, "o%s.pt" % occ)
-            env = dict(os.environ, M3D_W44_OCC2=occ)
+            env = dict(os.environ, M3D_W44_OCC2=occ, M3D_W44_KPAIR_MAX="0")      # (K-pair workgroups add the two K halves: not this test)
             r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
             assert r.returncode == 0, r.stderr[-2000:]
             outs.append(torch.load(path))
