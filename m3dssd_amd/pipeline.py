@@ -35,9 +35,10 @@ from .host.refine import p2_arrays
 
 class PipelinedDetector:
     def __init__(self, net, conf, batch, height, width, refine=False, score_thresh=0.75, step_r_init=0.3 * math.pi, r_lim=0.01,
-                 u8_frame=None):
+                 u8_frame=None, u8_zero_copy=False):
         self.net, self.conf = net, conf
         self.u8_frame = None if u8_frame is None else (int(u8_frame[0]), int(u8_frame[1]))
+        self.u8_zero_copy = bool(u8_zero_copy) and u8_frame is not None
         self.refine = bool(refine)
         self._rargs = (float(score_thresh), 1 if bool(getattr(conf, "hill_climbing", True)) else 0, float(step_r_init), float(r_lim))
         dev = next(net.parameters()).device
@@ -52,7 +53,13 @@ class PipelinedDetector:
             fh, fw = self.u8_frame
             if fh > height or fw > width:
                 raise RuntimeError("u8_frame %dx%d does not fit the padded size %dx%d" % (fh, fw, height, width))
-            self.inputs_u8 = [torch.zeros(batch, fh, fw, 3, device=dev, dtype=torch.uint8) for _ in range(2)]
+            if self.u8_zero_copy:
+                # the two input buffers live in PINNED HOST memory and the stem kernel reads them over PCIe (11 MB per batch of 8:
+                # ~0.2 ms at 54 GB/s, spread under the stem's own arithmetic): no copy engine, no second stream -- on this
+                # platform an asynchronous H2D copy next to the graph cost MORE than a serial one (tools/feed_probe.py)
+                self.inputs_u8 = [torch.zeros(batch, fh, fw, 3, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            else:
+                self.inputs_u8 = [torch.zeros(batch, fh, fw, 3, device=dev, dtype=torch.uint8) for _ in range(2)]
             self.input = self.inputs_u8[0]
             self._copy_stream = torch.cuda.Stream(dev)
             self._ready = [torch.cuda.Event(), torch.cuda.Event()]     # upload into buffer i finished (copy stream)
@@ -163,6 +170,12 @@ class PipelinedDetector:
                                % (tuple(self.inputs_u8[0].shape), frames.dtype, tuple(frames.shape)))
         i = self._next_buf
         self._next_buf ^= 1
+        if self.u8_zero_copy:
+            if self._used[i]:
+                self._done[i].synchronize()                      # (host) the graph that read this buffer last has finished
+            self.inputs_u8[i].copy_(frames)                      # host -> pinned host; a decoder would write here directly
+            self._fed.append(i)
+            return
         with torch.cuda.stream(self._copy_stream):
             if self._used[i]:
                 self._copy_stream.wait_event(self._done[i])      # the graph that read this buffer last has finished
@@ -177,7 +190,8 @@ class PipelinedDetector:
             raise RuntimeError("step_fed(): no batch was fed")
         i = self._fed.pop(0)
         main = torch.cuda.current_stream(self.dev)
-        main.wait_event(self._ready[i])
+        if not self.u8_zero_copy:
+            main.wait_event(self._ready[i])
         had = self._pending
         self._graphs[i].replay()
         self._done[i].record(main)

@@ -82,3 +82,25 @@ def serial():
     j[0] += 1
     pu._graphs[0].replay()
 print("(e) upload on the main stream, serial:    %.3f ms" % timed(serial, steps), flush=True)
+
+# (f) zero-copy: the two input buffers are pinned host memory, the stem reads them over PCIe
+pz = PipelinedDetector(net, conf, B, CROP[0], CROP[1], u8_frame=(fh, fw), u8_zero_copy=True)
+pz.inputs_u8[0].copy_(pool[0]); pz.inputs_u8[1].copy_(pool[1])
+kz = [0]
+
+
+def altz():
+    pz._graphs[kz[0] & 1].replay()
+    kz[0] += 1
+print("(f) zero-copy, graphs alternate, no host write: %.3f ms" % timed(altz, steps), flush=True)
+torch.cuda.synchronize()
+pz._fed, pz._next_buf, pz._pending, pz._used = [], 0, False, [False, False]
+pz.feed(pool[0])
+jz = [0]
+
+
+def fedz():
+    pz.feed(pool[jz[0] & 3])
+    jz[0] += 1
+    pz.step_fed(as_block=True)
+print("(g) zero-copy fed (host memcpy of a fresh frame set every step): %.3f ms" % timed(fedz, steps), flush=True)
