@@ -409,7 +409,7 @@ def feed_u8_leg(net, conf, B, dev, steps, resident_ms):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(steps):
-        pipe.feed(pool[k % 4])
+        pipe.feed(pool[k % 4])                             # queued: graph k uploads it (a kernel on its side branch) for step k + 1
         pipe.step_fed(as_block=True)
     pipe.step_fed(as_block=True)                           # the batch fed during warm-up keeps the count at `steps` + 1 submitted;
     pipe.flush(as_block=True)                              # flush drains the last one
@@ -418,7 +418,7 @@ def feed_u8_leg(net, conf, B, dev, steps, resident_ms):
     ms = 1e3 * dt / (steps + 1)
     return {"value": round(B * (steps + 1) / dt, 2), "unit": "images/sec", "steps": steps + 1, "ms_per_step": round(ms, 3),
             "vs_resident": round(resident_ms / ms, 4), "frame": [fw, fh], "input": "uint8 BGR [B, 375, 1242, 3] from pinned host "
-            "memory, 4 distinct frame sets cycled, double-buffered copy stream, Preprocess fused into the stem (m3d_stem_conv7x7_u8)",
+            "memory, 4 distinct frame sets cycled, uploaded by a kernel on the side branch of the previous batch's graph (m3d_upload_indirect), Preprocess fused into the stem (m3d_stem_conv7x7_u8)",
             "h2d_bytes_per_step": int(nbytes), "h2d_gbs_effective": round(nbytes / (ms * 1e-3) / 1e9, 2),
             "h2d_alone_ms": round(h2d_alone_ms, 4), "h2d_alone_gbs": round(nbytes / (h2d_alone_ms * 1e-3) / 1e9, 2)}
 

@@ -158,6 +158,11 @@ int m3d_wino44_conv3x3_forward_touch(const m3d_conv_desc *d, int nb, const void 
 /* Touches one dword of every 128-byte line of [p, p + bytes): warms the memory-side cache with a weight tensor ahead of a
  * kernel whose operand lookahead does not cover an HBM round trip (the engine issues it before the F(4x4,3x3) layers). */
 int m3d_cache_touch(const void *p, long long bytes, m3d_stream_t stream);
+/* Fed-input upload as a kernel (replaces the per-frame im.cuda() of lib/rpn_util.py:1427-1429 for the pipelined detector):
+ * copies `bytes` from the 16-byte-aligned pinned-host buffer whose address the 8-byte word *src_slot holds -- src_slot itself
+ * lives in pinned host memory and is read when the kernel RUNS, so one captured graph serves a different frame set every replay
+ * -- to dst (device, 16-byte aligned).  *src_slot == NULL: no copy. */
+int m3d_upload_indirect(const void *const *src_slot, void *dst, long long bytes, m3d_stream_t stream);
 
 /* Average launch geometry chosen for a descriptor (for roofline bookkeeping / tests). */
 int m3d_conv2d_tile(const m3d_conv_desc *d, int *bm, int *bn, int *bk, int *grid);

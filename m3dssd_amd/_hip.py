@@ -111,6 +111,7 @@ SIGNATURES = {
     "m3d_wino44_kpair": (c_int, [ctypes.POINTER(ConvDesc)]),
     "m3d_wino44_conv3x3_forward_touch": (c_int, [ctypes.POINTER(ConvDesc), c_int, P, c_ll, P]),
     "m3d_cache_touch": (c_int, [P, c_ll, P]),
+    "m3d_upload_indirect": (c_int, [P, P, c_ll, P]),
     "m3d_wino44_splitk_plan": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int), ctypes.POINTER(c_ll)]),
     "m3d_conv_wave_applicable": (c_int, [ctypes.POINTER(ConvDesc)]),
     "m3d_conv_wave_splitk_plan": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int), ctypes.POINTER(c_ll)]),

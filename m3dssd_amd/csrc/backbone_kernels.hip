@@ -555,6 +555,41 @@ __global__ __launch_bounds__(256) void cache_touch_kernel(const char *p, long lo
     }
 }
 
+// Fed-input upload as a KERNEL (round 4): the frames of the NEXT batch sit in pinned host memory; `*src_slot` (an 8-byte word,
+// itself in pinned host memory, written by the host before the graph is replayed) names them.  a few workgroups stream them over
+// PCIe with 16-byte loads -- exactly once, no halo re-reads -- into the device buffer the next replay's stem reads.  Inside the
+// captured graph on the side branch it needs no copy engine, no second stream and no events: on this platform an asynchronous
+// hipMemcpyAsync next to the graph cost MORE step time than a serial one (tools/feed_probe.py).
+__global__ __launch_bounds__(256) void upload_indirect_kernel(const void *const *src_slot, u32x4 *__restrict__ dst, long long bytes)
+{
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(__builtin_nontemporal_load(src_slot));
+    if (!src) return;
+    const long long n16 = bytes >> 4, stride = (long long)gridDim.x * 256;
+    if (blockIdx.x == 0 && threadIdx.x < (bytes & 15))          // the last < 16 bytes
+        reinterpret_cast<unsigned char *>(dst)[n16 * 16 + threadIdx.x] = reinterpret_cast<const unsigned char *>(src)[n16 * 16 + threadIdx.x];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += 4 * stride) {
+        u32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + k * stride < n16) v[k] = __builtin_nontemporal_load(src + i + k * stride);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + k * stride < n16) dst[i + k * stride] = v[k];
+    }
+}
+
+extern "C" int m3d_upload_indirect(const void *const *src_slot, void *dst, long long bytes, m3d_stream_t stream)
+{
+    M3D_REQUIRE(src_slot && dst && bytes >= 0 && ((uintptr_t)dst & 15) == 0, "upload_indirect: null pointer or misaligned destination");
+    if (bytes == 0) return M3D_OK;
+    // 8 workgroups (measured, tools/feed_probe.py, step = 6.07 ms resident): 1 -> 6.98 ms (the upload outlasts the forward),
+    // 2 -> 6.39, 4 -> 6.19, 16 -> 6.19, 64 -> 6.24: a few workgroups keep enough loads in flight for PCIe and leave the CUs alone
+    static const int wgs = []() { const char *e = getenv("M3D_UPLOAD_WGS"); const int v = e ? atoi(e) : 8; return v > 0 ? v : 8; }();
+    hipLaunchKernelGGL(upload_indirect_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, src_slot, (u32x4 *)dst, bytes);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
 extern "C" int m3d_cache_touch(const void *p, long long bytes, m3d_stream_t stream)
 {
     M3D_REQUIRE(p && bytes >= 0, "cache_touch: null pointer");

@@ -12,11 +12,13 @@ so each ``step(x)`` returns the detections of the PREVIOUS batch (one batch of p
 drains the last one.  Results are identical to ``lib.rpn_util.detect_batch`` (tests/test_gpu_parity.py).
 
 ``u8_frame=(h, w)`` is the fed-input form (the reference pays ``im.cuda()`` per frame, lib/rpn_util.py:1427-1429,
-and preprocesses on the host, lib/dataloader.py:934-950, lib/augmentations.py:472-501): raw uint8 BGR frames [B, h, w, 3] arrive
-from PINNED host memory by ``feed()`` on a copy stream into one of TWO device buffers while the graph of the previous batch runs;
-the stem reads the uint8 frames directly (``m3d_stem_conv7x7_u8``: padding to the crop size, /255, -mean, /stds, BGR->RGB in its
-loads).  Two graphs are captured, one per input buffer; events order "upload k+1" behind "graph k-1 done" and "graph k" behind
-"upload k done".
+and preprocesses on the host, lib/dataloader.py:934-950, lib/augmentations.py:472-501): raw uint8 BGR frames [B, h, w, 3] sit in
+PINNED host memory; the graph of batch k carries, on its side branch, an upload KERNEL (``m3d_upload_indirect``) that streams
+the frames of batch k + 1 over PCIe into the second of TWO device buffers while the forward of batch k runs on the first, and the
+stem reads uint8 frames directly (``m3d_stem_conv7x7_u8``: padding to the crop size, /255, -mean, /stds, BGR->RGB in its loads).
+Two graphs are captured, one per input buffer; which host buffer a replay uploads is named by an 8-byte word in pinned host
+memory that the host writes before the replay (no copy engine, no copy stream, no events: a hipMemcpyAsync next to the graph
+cost more step time than a serial copy on this platform, tools/feed_probe.py).
 
 ``refine=True`` appends the post-NMS 3-D refinement of ``test_kitti_3d`` (lib/rpn_util.py:1796-1847: back to the original image
 scale, clipping, alpha -> ry, hill climbing, back-projection; ``m3d_refine_3d_ex``) to branch B, reading the selected rows where
@@ -35,10 +37,9 @@ from .host.refine import p2_arrays
 
 class PipelinedDetector:
     def __init__(self, net, conf, batch, height, width, refine=False, score_thresh=0.75, step_r_init=0.3 * math.pi, r_lim=0.01,
-                 u8_frame=None, u8_zero_copy=False):
+                 u8_frame=None):
         self.net, self.conf = net, conf
         self.u8_frame = None if u8_frame is None else (int(u8_frame[0]), int(u8_frame[1]))
-        self.u8_zero_copy = bool(u8_zero_copy) and u8_frame is not None
         self.refine = bool(refine)
         self._rargs = (float(score_thresh), 1 if bool(getattr(conf, "hill_climbing", True)) else 0, float(step_r_init), float(r_lim))
         dev = next(net.parameters()).device
@@ -53,20 +54,19 @@ class PipelinedDetector:
             fh, fw = self.u8_frame
             if fh > height or fw > width:
                 raise RuntimeError("u8_frame %dx%d does not fit the padded size %dx%d" % (fh, fw, height, width))
-            if self.u8_zero_copy:
-                # the two input buffers live in PINNED HOST memory and the stem kernel reads them over PCIe (11 MB per batch of 8:
-                # ~0.2 ms at 54 GB/s, spread under the stem's own arithmetic): no copy engine, no second stream -- on this
-                # platform an asynchronous H2D copy next to the graph cost MORE than a serial one (tools/feed_probe.py)
-                self.inputs_u8 = [torch.zeros(batch, fh, fw, 3, dtype=torch.uint8).pin_memory() for _ in range(2)]
-            else:
-                self.inputs_u8 = [torch.zeros(batch, fh, fw, 3, device=dev, dtype=torch.uint8) for _ in range(2)]
+            nbytes = batch * fh * fw * 3
+            self._u8_bytes = nbytes
+            self._u8_flat = [torch.zeros(-(-nbytes // 16) * 16, device=dev, dtype=torch.uint8) for _ in range(2)]
+            self.inputs_u8 = [t[:nbytes].view(batch, fh, fw, 3) for t in self._u8_flat]
             self.input = self.inputs_u8[0]
-            self._copy_stream = torch.cuda.Stream(dev)
-            self._ready = [torch.cuda.Event(), torch.cuda.Event()]     # upload into buffer i finished (copy stream)
-            self._done = [torch.cuda.Event(), torch.cuda.Event()]      # the graph that read buffer i finished (main stream)
-            self._fed = []                                             # buffers holding an uploaded, not yet submitted batch
-            self._next_buf = 0
+            # slot i: address of the pinned-host frames that the graph reading buffer i uploads into buffer i ^ 1 (0 = nothing)
+            self._slots = torch.zeros(2, dtype=torch.int64).pin_memory()
+            self._done = [torch.cuda.Event(), torch.cuda.Event()]      # the last replay of graph i finished (main stream)
             self._used = [False, False]
+            self._queue = []                                           # fed, not yet submitted frame sets (kept alive here)
+            self._cur = 0                                              # buffer the next submitted batch is read from
+            self._primed = False                                       # buffer _cur holds the head of the queue
+            self._inflight = [None, None]                              # frames a replay of graph i is uploading (kept alive)
         self.n_fwd = len(self.plan.ops) - 1
         assert self.plan.ops[-1][0] == "bundle_outputs"
         n = self.plan.named
@@ -119,6 +119,10 @@ class PipelinedDetector:
             side.wait_stream(cap)                    # fork
             with torch.cuda.stream(side):
                 outs = self._detect()                # batch k-1
+                if self.u8_frame is not None:        # frames of batch k+1: pinned host -> the OTHER input buffer, as a kernel
+                    _hip.check(_hip.lib().m3d_upload_indirect(
+                        ctypes.c_void_p(self._slots.data_ptr() + 8 * buf), ctypes.c_void_p(self._u8_flat[buf ^ 1].data_ptr()),
+                        self._u8_bytes, ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
             self._forward(0, self.n_fwd, buf)        # batch k, everything but the bundling
             cap.wait_stream(side)                    # join: outputs may now be overwritten
             self._forward(self.n_fwd, None, buf)
@@ -159,44 +163,44 @@ class PipelinedDetector:
 
     # ---- fed-input form ---------------------------------------------------------------------------------------------------------
     def feed(self, frames):
-        """Upload one batch of uint8 BGR frames [B, h, w, 3] (pinned host memory for a truly asynchronous copy; a device tensor
-        works too) into the free input buffer on the copy stream.  At most two batches can be fed ahead of their step()."""
+        """Queue one batch of uint8 BGR frames [B, h, w, 3] in PINNED host memory (a device tensor works too).  Nothing is copied
+        here: the graph of the batch submitted BEFORE this one uploads it (the first batch is uploaded right away).  The tensor
+        must stay unchanged until the step_fed() that submits it has been called.  At most two batches can be queued."""
         if self.u8_frame is None:
             raise RuntimeError("feed() needs PipelinedDetector(..., u8_frame=(h, w))")
-        if len(self._fed) >= 2:
-            raise RuntimeError("feed(): both input buffers hold batches that were not submitted yet; call step()")
-        if frames.dtype != torch.uint8 or tuple(frames.shape) != tuple(self.inputs_u8[0].shape):
-            raise RuntimeError("feed(): uint8 frames of shape %s expected, got %s %s"
+        if len(self._queue) >= 2:
+            raise RuntimeError("feed(): two batches are queued already; call step_fed()")
+        if frames.dtype != torch.uint8 or tuple(frames.shape) != tuple(self.inputs_u8[0].shape) or not frames.is_contiguous():
+            raise RuntimeError("feed(): contiguous uint8 frames of shape %s expected, got %s %s"
                                % (tuple(self.inputs_u8[0].shape), frames.dtype, tuple(frames.shape)))
-        i = self._next_buf
-        self._next_buf ^= 1
-        if self.u8_zero_copy:
-            if self._used[i]:
-                self._done[i].synchronize()                      # (host) the graph that read this buffer last has finished
-            self.inputs_u8[i].copy_(frames)                      # host -> pinned host; a decoder would write here directly
-            self._fed.append(i)
-            return
-        with torch.cuda.stream(self._copy_stream):
-            if self._used[i]:
-                self._copy_stream.wait_event(self._done[i])      # the graph that read this buffer last has finished
-            self.inputs_u8[i].copy_(frames, non_blocking=True)
-            self._ready[i].record(self._copy_stream)
-        self._fed.append(i)
+        if not (frames.is_cuda or frames.is_pinned()):
+            raise RuntimeError("feed(): the frames must be in pinned host memory (tensor.pin_memory()) or on the device")
+        self._queue.append(frames)
+        if not self._primed:                                     # nothing in flight names this batch: upload it now
+            self.inputs_u8[self._cur].copy_(frames, non_blocking=True)
+            self._primed = True
 
     def step_fed(self, as_block=False):
-        """Submit the oldest fed batch; returns (dets, counts) of the batch submitted before it (None for the first call).  The
-        returned tensors belong to the graph of that input buffer and are overwritten two steps later."""
-        if not self._fed:
+        """Submit the oldest queued batch; its graph also uploads the next queued batch (if any) into the other buffer.  Returns
+        (dets, counts) of the batch submitted before it (None for the first call).  The returned tensors belong to the graph of
+        that input buffer and are overwritten two steps later."""
+        if not self._queue:
             raise RuntimeError("step_fed(): no batch was fed")
-        i = self._fed.pop(0)
+        i = self._cur
+        self._queue.pop(0)
+        nxt = self._queue[0] if self._queue else None
+        if self._used[i]:
+            self._done[i].synchronize()          # (host) the previous replay of this graph has read its slot
+        self._slots[i] = nxt.data_ptr() if nxt is not None else 0
+        self._inflight[i] = nxt
         main = torch.cuda.current_stream(self.dev)
-        if not self.u8_zero_copy:
-            main.wait_event(self._ready[i])
         had = self._pending
         self._graphs[i].replay()
         self._done[i].record(main)
         self._used[i] = True
         self._pending = True
+        self._cur ^= 1
+        self._primed = nxt is not None           # the replay uploads it into the buffer the next step reads
         if not had:
             return None
         block, counts, _ = self._results[i]

@@ -1,6 +1,8 @@
 """Where does the fed-input leg lose time against the resident one?   python tools/feed_probe.py [steps]
-(a) resident fp32 frames, one graph; (b) resident uint8 frames, the two graphs alternating, nothing uploaded; (c) the event
-protocol of feed() / step_fed() without the copy; (d) the full fed form (bench.py's feed_u8 leg)."""
+(a) resident fp32 frames, one graph; (b) resident uint8 frames, the two graphs alternating, nothing uploaded; (d) the full fed
+form (bench.py's feed_u8 leg: the upload of batch k + 1 is a kernel on the side branch of graph k); (e) a serial hipMemcpyAsync
+in front of every replay.  Round 4, first version (hipMemcpyAsync on a copy stream, events both ways): (d) was 6.47-6.60 ms against
+6.13 / 6.06 resident and 6.36-6.44 serial -- the asynchronous copy cost MORE than the serial one."""
 import sys
 import time
 
@@ -49,58 +51,23 @@ def alt():
     k[0] += 1
 print("(b) resident uint8, two graphs alternate: %.3f ms" % timed(alt, steps), flush=True)
 print("    resident uint8, graph 0 only:         %.3f ms" % timed(lambda: pu._graphs[0].replay(), steps), flush=True)
-main = torch.cuda.current_stream(dev)
-
-
-def proto():
-    i = k[0] & 1
-    k[0] += 1
-    with torch.cuda.stream(pu._copy_stream):
-        pu._copy_stream.wait_event(pu._done[i])
-        pu._ready[i].record(pu._copy_stream)
-    main.wait_event(pu._ready[i ^ 1])
-    pu._graphs[i ^ 1].replay()
-    pu._done[i ^ 1].record(main)
-pu._done[0].record(main); pu._done[1].record(main); pu._ready[0].record(main); pu._ready[1].record(main)
-print("(c) event protocol, no copy:              %.3f ms" % timed(proto, steps), flush=True)
-pu._fed, pu._next_buf, pu._pending = [], 0, False
-pu.feed(pool[0])
 j = [0]
+pu.feed(pool[0])
 
 
 def fed():
-    pu.feed(pool[j[0] & 3])
+    pu.feed(pool[(j[0] + 1) & 3])
     j[0] += 1
     pu.step_fed(as_block=True)
-print("(d) fed uint8 (upload k+1 || graph k):    %.3f ms" % timed(fed, steps), flush=True)
-# (e) the same with the upload issued on the MAIN stream in front of the graph (serial, no events)
+print("(d) fed uint8 (in-graph upload kernel of batch k+1 || forward k): %.3f ms" % timed(fed, steps), flush=True)
+torch.cuda.synchronize()
+# (e) the same frames by hipMemcpyAsync on the MAIN stream in front of the graph (serial)
 buf = pu.inputs_u8[0]
+pu._slots.zero_()
 
 
 def serial():
     buf.copy_(pool[j[0] & 3], non_blocking=True)
     j[0] += 1
     pu._graphs[0].replay()
-print("(e) upload on the main stream, serial:    %.3f ms" % timed(serial, steps), flush=True)
-
-# (f) zero-copy: the two input buffers are pinned host memory, the stem reads them over PCIe
-pz = PipelinedDetector(net, conf, B, CROP[0], CROP[1], u8_frame=(fh, fw), u8_zero_copy=True)
-pz.inputs_u8[0].copy_(pool[0]); pz.inputs_u8[1].copy_(pool[1])
-kz = [0]
-
-
-def altz():
-    pz._graphs[kz[0] & 1].replay()
-    kz[0] += 1
-print("(f) zero-copy, graphs alternate, no host write: %.3f ms" % timed(altz, steps), flush=True)
-torch.cuda.synchronize()
-pz._fed, pz._next_buf, pz._pending, pz._used = [], 0, False, [False, False]
-pz.feed(pool[0])
-jz = [0]
-
-
-def fedz():
-    pz.feed(pool[jz[0] & 3])
-    jz[0] += 1
-    pz.step_fed(as_block=True)
-print("(g) zero-copy fed (host memcpy of a fresh frame set every step): %.3f ms" % timed(fedz, steps), flush=True)
+print("(e) hipMemcpyAsync on the main stream, serial:    %.3f ms" % timed(serial, steps), flush=True)
