@@ -31,6 +31,7 @@ struct ConvWaveArgs {
     int kh, kw, stride, pad, dil;
     int M, KG, tiles_n;
     int act, res_mode, sigmoid_from;
+    int chunk_major;               // DEFORM: K loop order (1 = 32-channel chunks outer, taps inner; 0 = taps outer: A/B runs)
     int vec_out;                   // out / res / scale / shift views allow 16-byte accesses: epilogue through the LDS transpose
     long long w_img_stride;        // floats between the per-image weight sets (0: shared weights)
     unsigned in_bytes, out_bytes, res_bytes, w_bytes;
@@ -60,7 +61,12 @@ template <bool DEFORM, int NT>      // register bound: 3 waves per SIMD for the 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFORM ? 2 : 3))) void conv_wave_kernel(const ConvWaveArgs a)
 {
     __shared__ __attribute__((aligned(16))) float tileA[32 * 32];     // [pixel][8 slots of 4 channels], swizzled
-    __shared__ __attribute__((aligned(16))) float tapst[32 * 8];      // [pixel][4 corner offsets (as bits), 4 weights]
+    // [tap][pixel][4 corner offsets (as bits), 4 weights]: DEFORM keeps the sampling state of all (<= 9) taps here, built once in
+    // the prologue, because its K loop runs CHUNK-major (32 input channels outer, taps inner): the input lines a wave gathers for
+    // one channel chunk are re-used by the 9 taps x 4 corners within 9 steps and the chunk's share of the in-flight pixels
+    // (8192 px x 128 B per XCD) fits the 4 MB L2 -- tap-major, every (tap, chunk) visit found its lines evicted: 178 MB of fabric
+    // traffic per full-size launch against 84 MB algorithmic (PMC, profiles/r03r, r04a)
+    __shared__ __attribute__((aligned(16))) float tapst[(DEFORM ? 9 : 1) * 32 * 8];
     const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
     const int gp = lane >> 3, gc = lane & 7;                         // gather map: pixel-in-group, chunk
     TRACE_INIT();
@@ -124,40 +130,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFORM ? 2 :
 
     unsigned doff[4][DEFORM ? 4 : 1];          // [pixel group][corner]: byte offset incl. the chunk sub-offset 16*gc
     float bw[DEFORM ? 4 : 1][4];
-    float raw[3] = {0.f, 0.f, 0.f};
-    auto load_raw = [&](int tap) {
-        if constexpr (DEFORM) {
-            const int tp = min(tap, KK - 1);
-            raw[0] = o_om[2 * tp];
-            raw[1] = o_om[2 * tp + 1];
-            raw[2] = o_om[2 * KK + tp];
-        }
-    };
-    auto setup_tap = [&](int tap) {
-        const int ti = tap / a.kw, tj = tap - ti * a.kw;
-        if constexpr (DEFORM) {
-            const float mk = raw[2];
-            const float h_im = (float)(o_hi0 + ti * a.dil) + raw[0];
-            const float w_im = (float)(o_wi0 + tj * a.dil) + raw[1];
-            float wq[4];
-            int oq[4], drop[4];
-            dcn_corners(h_im, w_im, a.H, a.W, o_inv, wq, oq, drop);      // no SGPR lane masks in here: see common.h
-            const float w1 = wq[0], w2 = wq[1], w3 = wq[2], w4 = wq[3];
-            u32x4 ob;
+    // DEFORM prologue: sampling state of every tap (offsets / mask of all taps fetched in one go: 27 loads in flight per lane)
+    if constexpr (DEFORM) {
+        float raws[9][3];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const unsigned off = ((unsigned)o_pix + (unsigned)oq[q]) * (unsigned)a.in_cs * 4u;    // garbage where dropped: masked next
-                ob[q] = (off & ~(unsigned)drop[q]) | (M3D_BUF_OOB & (unsigned)drop[q]);     // dropped corner: the load reads 0
+        for (int t = 0; t < 9; ++t) {
+            const int tp = min(t, KK - 1);
+            raws[t][0] = o_om[2 * tp];
+            raws[t][1] = o_om[2 * tp + 1];
+            raws[t][2] = o_om[2 * KK + tp];
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t < KK) {                          // wave-uniform
+                const int ti = t / a.kw, tj = t - ti * a.kw;
+                const float mk = raws[t][2];
+                const float h_im = (float)(o_hi0 + ti * a.dil) + raws[t][0];
+                const float w_im = (float)(o_wi0 + tj * a.dil) + raws[t][1];
+                float wq[4];
+                int oq[4], drop[4];
+                dcn_corners(h_im, w_im, a.H, a.W, o_inv, wq, oq, drop);      // no SGPR lane masks in here: see common.h
+                u32x4 ob;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned off = ((unsigned)o_pix + (unsigned)oq[q]) * (unsigned)a.in_cs * 4u;    // garbage where dropped: masked next
+                    ob[q] = (off & ~(unsigned)drop[q]) | (M3D_BUF_OOB & (unsigned)drop[q]);     // dropped corner: the load reads 0
+                }
+                if (h == 0) {
+                    *reinterpret_cast<u32x4 *>(&tapst[t * 256 + l31 * 8]) = ob;
+                    *reinterpret_cast<f32x4 *>(&tapst[t * 256 + l31 * 8 + 4]) = f32x4{wq[0] * mk, wq[1] * mk, wq[2] * mk, wq[3] * mk};
+                }
             }
-            if (h == 0) {
-                *reinterpret_cast<u32x4 *>(&tapst[l31 * 8]) = ob;
-                *reinterpret_cast<f32x4 *>(&tapst[l31 * 8 + 4]) = f32x4{w1 * mk, w2 * mk, w3 * mk, w4 * mk};
-            }
-            // single wave: the LDS writes above are ordered before the reads below by the wave's own lgkmcnt
+        }
+        // single wave: the LDS writes above are ordered before the reads below by the wave's own lgkmcnt
+    }
+    auto setup_tap = [&](int tap) {
+        if constexpr (DEFORM) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const u32x4 ov = *reinterpret_cast<const u32x4 *>(&tapst[(8 * g + gp) * 8]);
-                const f32x4 wv = *reinterpret_cast<const f32x4 *>(&tapst[(8 * g + gp) * 8 + 4]);
+                const u32x4 ov = *reinterpret_cast<const u32x4 *>(&tapst[tap * 256 + (8 * g + gp) * 8]);
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(&tapst[tap * 256 + (8 * g + gp) * 8 + 4]);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     doff[g][q] = ov[q] + (unsigned)gc * 16u;          // OOB marker + < 128 stays out of range
@@ -165,6 +177,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFORM ? 2 :
                 }
             }
         } else {
+            const int ti = tap / a.kw, tj = tap - ti * a.kw;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int hi = g_hi0[g] + ti * a.dil, wi = g_wi0[g] + tj * a.dil;
@@ -196,12 +209,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFORM ? 2 :
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
-    int tap = ss0 / C32, c32 = ss0 - tap * C32;                  // position of the step being computed
-    load_raw(tap);
+    // step s of the K loop: plain = tap-major (s = tap * C32 + c32), DEFORM = chunk-major (s = c32 * KK + tap); the weights are
+    // packed tap-major either way: k-group of a step = (tap * C32 + c32) * 4
+    int tap, c32;
+    const bool cmaj = DEFORM && a.chunk_major;
+    if (cmaj) { c32 = ss0 / KK; tap = ss0 - c32 * KK; }
+    else { tap = ss0 / C32; c32 = ss0 - tap * C32; }
     setup_tap(tap);
-    load_raw(tap + 1);
     issue_gather(c32);
-    issue_b(ss0 * 4, bfA);
+    issue_b((tap * C32 + c32) * 4, bfA);
 
     // LDS slots: pixel row r, 16-byte slot s lives at r*128 + ((s ^ ((r >> 1) & 7)) * 16) bytes
     unsigned wr_off[4], rd_off[4];
@@ -214,8 +230,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFORM ? 2 :
     for (int j = 0; j < 4; ++j) rd_off[j] = (unsigned)(l31 * 32 + (((2 * j + h) ^ ((l31 >> 1) & 7)) * 4));
 
     TRACE();
-    for (int kg0 = ss0 * 4; kg0 < ss1 * 4; kg0 += 4) {
+    for (int st = ss0; st < ss1; ++st) {
         TRACE();
+        const int kg0 = (tap * C32 + c32) * 4;
         // ---- combine (gather layout) and transpose through LDS into the A-operand layout ---------------------------
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -226,22 +243,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFORM ? 2 :
                 v = cr[g][0];
             *reinterpret_cast<f32x4 *>(&tileA[wr_off[g]]) = v;
         }
-        // ---- next step: move to the next tap first if this was the tap's last channel block --------------------------
-        if (++c32 == C32) {                     // wave-uniform
-            c32 = 0;
-            ++tap;
-            setup_tap(min(tap, KK - 1));
-            load_raw(tap + 1);
+        // ---- next step ----------------------------------------------------------------------------------------------------
+        if (cmaj) {
+            if (++tap == KK) { tap = 0; ++c32; }        // wave-uniform; past the last step: clamped, a redundant in-range reload
+            setup_tap(tap);                              // 8 x ds_read_b128: the state of every tap was built in the prologue
+            issue_gather(min(c32, C32 - 1));
+        } else {
+            if (++c32 == C32) {                          // wave-uniform
+                c32 = 0;
+                ++tap;
+                setup_tap(min(tap, KK - 1));
+            }
+            issue_gather(c32);                           // after the last step: a redundant in-range reload, never used
         }
-        issue_gather(c32);                      // after the last step: a redundant in-range reload, never used
+        const int kgn = (min(tap, KK - 1) * C32 + min(c32, C32 - 1)) * 4;       // first k-group of the next step
         TRACE();
         f32x4 A[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) A[j] = *reinterpret_cast<const f32x4 *>(&tileA[rd_off[j]]);
         __builtin_amdgcn_sched_barrier(0);
         // ---- 4 k-groups x 16 MFMAs; the B fragments of the next group are in flight meanwhile --------------------------
-        auto group = [&](int j, f32x4 (&bf)[NT], f32x4 (&bfn)[NT]) {
-            issue_b(kg0 + j + 1, bfn);
+        auto group = [&](int j, int kg_next, f32x4 (&bf)[NT], f32x4 (&bfn)[NT]) {
+            issue_b(kg_next, bfn);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -250,10 +273,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFORM ? 2 :
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[j][t], bf[nt][t], acc[nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         };
-        group(0, bfA, bfB);
-        group(1, bfB, bfA);
-        group(2, bfA, bfB);
-        group(3, bfB, bfA);
+        group(0, kg0 + 1, bfA, bfB);
+        group(1, kg0 + 2, bfB, bfA);
+        group(2, kg0 + 3, bfA, bfB);
+        group(3, kgn, bfB, bfA);
     }
 
     TRACE();
@@ -398,6 +421,7 @@ static int conv_wave_plan(const m3d_conv_desc *d, bool enforce_min, int *splits,
     *splits = 1;
     *ss_per = d->kh * d->kw * (d->Cin / 32);
     if (d->out_nchw) return 0;
+    if (d->dcn_offmask && d->kh * d->kw > 9) return 0;        // the sampling state of every tap lives in LDS (9 KB per wave)
     if (d->Cin % 32 != 0 || d->Cout_pad % 64 != 0) return 0;
     const int cw = d->Cout_pad % 128 == 0 ? 128 : 64;      // channels per wave
     if (d->wgt_img_stride && (d->Ho * d->Wo) % 32 != 0) return 0;
@@ -471,6 +495,8 @@ extern "C" int m3d_conv_wave_forward(const m3d_conv_desc *d, m3d_stream_t stream
     const int cw = d->Cout_pad % 128 == 0 ? 128 : 64;
     a.M = (int)M; a.KG = d->kh * d->kw * d->Cin / 8; a.tiles_n = d->Cout_pad / cw;
     a.act = d->act; a.res_mode = d->res_mode; a.sigmoid_from = d->sigmoid_from; a.w_img_stride = d->wgt_img_stride;
+    static const int cmaj = []() { const char *e = getenv("M3D_DCN_CHUNK_MAJOR"); return e ? atoi(e) : 1; }();
+    a.chunk_major = cmaj;
     static int vec_epi = -1;       // M3D_WAVE_VEC_EPILOGUE=0: 4-byte stores straight from the accumulators (A/B)
     if (vec_epi < 0) { const char *e = getenv("M3D_WAVE_VEC_EPILOGUE"); vec_epi = e ? atoi(e) : 1; }
     a.vec_out = vec_epi && d->out_cs % 4 == 0 && ((uintptr_t)d->out & 15) == 0 &&
