@@ -83,10 +83,15 @@ def pack_conv_bf16(weight, cout_pad=None, cin_pad=None, device=None):
 
 class PackedBf16:
     def f16(self):
-        """fp16 copy of the packed weights for the LDS-patch DCNv2 kernel (exact for |w| in [6.1e-5, 65504]; made on first use)."""
+        """fp16 copy of the packed weights for the LDS-patch DCNv2 kernel (exact for |w| in [6.1e-5, 65504]; made on first use).
+        None when a weight exceeds the fp16 range (it would become inf): the layer then stays on the implicit-GEMM kernel."""
         if getattr(self, "_wp16", None) is None:
-            self._wp16 = self.wp.float().to(torch.float16).contiguous()
-        return self._wp16
+            w = self.wp.float()
+            if not bool(torch.isfinite(w).all()) or float(w.abs().max()) > 65504.0:
+                self._wp16 = False
+            else:
+                self._wp16 = w.to(torch.float16).contiguous()
+        return self._wp16 if self._wp16 is not False else None
 
     def wave3x3(self):
         """The 3x3 weights in the fragment order of csrc/bf16_conv_wide.hip: [Cout_pad/128][Cin/32][9 taps][2 K-steps of 16][4 blocks of
