@@ -495,16 +495,17 @@ extern "C" int m3d_maxpool2x2(const float *in, int in_cs, float *out, int out_cs
 // (model/pose_dla_dcn.py:536-538,550-552).  out[y][x] += in[iy][ix] * w[ky][kx] with
 // y = 2*iy - 1 + ky: each output pixel has exactly 2x2 contributing inputs.
 // wgt layout [4][4][C] (ky, kx, c).
+template <typename IT>
 __global__ void upsample2x_add_kernel(const float *__restrict__ in, int in_cs, const float *__restrict__ wgt,
                                       const float *__restrict__ skip, int skip_cs, float *__restrict__ out, int out_cs,
                                       int N, int H, int W, int C4)
 {
     const int Ho = 2 * H, Wo = 2 * W, C = C4 * 4;
-    const long long total = (long long)N * Ho * Wo * C4;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
+    const IT total = (IT)N * Ho * Wo * C4;
+    for (IT i = (IT)blockIdx.x * (IT)blockDim.x + threadIdx.x; i < total;
+         i += (IT)gridDim.x * (IT)blockDim.x) {
         const int c4 = (int)(i % C4);
-        long long p = i / C4;
+        IT p = i / C4;
         const int x = (int)(p % Wo);
         p /= Wo;
         const int y = (int)(p % Ho), n = (int)(p / Ho);
@@ -536,7 +537,11 @@ extern "C" int m3d_upsample2x_add(const float *in, int in_cs, const float *wgt, 
     M3D_REQUIRE(in && wgt && out && C % 4 == 0 && in_cs % 4 == 0 && out_cs % 4 == 0 && (!skip || skip_cs % 4 == 0),
                 "upsample2x_add: C and strides must be x4");
     const long long total = (long long)N * 4 * H * W * (C / 4);
-    hipLaunchKernelGGL(upsample2x_add_kernel, dim3(imin(cdiv(total, 256), 8192)), dim3(256), 0, (hipStream_t)stream, in,
+    if (total < (1ll << 31))
+        hipLaunchKernelGGL(upsample2x_add_kernel<int>, dim3(imin(cdiv(total, 256), 8192)), dim3(256), 0, (hipStream_t)stream, in,
+                           in_cs, wgt, skip, skip_cs, out, out_cs, N, H, W, C / 4);      // (32-bit index arithmetic: no 64-bit divisions)
+    else
+        hipLaunchKernelGGL(upsample2x_add_kernel<long long>, dim3(imin(cdiv(total, 256), 8192)), dim3(256), 0, (hipStream_t)stream, in,
                        in_cs, wgt, skip, skip_cs, out, out_cs, N, H, W, C / 4);
     M3D_LAUNCH_CHECK();
     return M3D_OK;

@@ -176,15 +176,16 @@ extern "C" int m3d_maxpool2x2_bf16(const void *in, int in_cs, void *out, int out
 }
 
 // out[y][x] = sum over the 2x2 contributing inputs in[iy][ix] * w[ky][kx] (y = 2*iy - 1 + ky) + skip[y][x]; wgt fp32 [4][4][C]
+template <typename IT>
 __global__ void upsample2x_add_bf16_kernel(const __bf16 *__restrict__ in, int in_cs, const float *__restrict__ wgt,
                                            const __bf16 *__restrict__ skip, int skip_cs, __bf16 *__restrict__ out, int out_cs, int N,
                                            int H, int W, int C8)
 {
     const int Ho = 2 * H, Wo = 2 * W, C = C8 * 8;
-    const long long total = (long long)N * Ho * Wo * C8;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const IT total = (IT)N * Ho * Wo * C8;
+    for (IT i = (IT)blockIdx.x * (IT)blockDim.x + threadIdx.x; i < total; i += (IT)gridDim.x * (IT)blockDim.x) {
         const int c8 = (int)(i % C8);
-        long long p = i / C8;
+        IT p = i / C8;
         const int x = (int)(p % Wo);
         p /= Wo;
         const int y = (int)(p % Ho), n = (int)(p / Ho);
@@ -223,7 +224,11 @@ extern "C" int m3d_upsample2x_add_bf16(const void *in, int in_cs, const float *w
     M3D_REQUIRE(in && wgt && out && C % 8 == 0 && in_cs % 8 == 0 && out_cs % 8 == 0 && (!skip || skip_cs % 8 == 0),
                 "upsample2x_add_bf16: C and strides must be x8");
     const long long total = (long long)N * 4 * H * W * (C / 8);
-    hipLaunchKernelGGL(upsample2x_add_bf16_kernel, dim3(imin(cdiv(total, 256), 16384)), dim3(256), 0, (hipStream_t)stream,
+    if (total < (1ll << 31))
+        hipLaunchKernelGGL(upsample2x_add_bf16_kernel<int>, dim3(imin(cdiv(total, 256), 16384)), dim3(256), 0, (hipStream_t)stream,
+                           (const __bf16 *)in, in_cs, wgt, (const __bf16 *)skip, skip_cs, (__bf16 *)out, out_cs, N, H, W, C / 8);
+    else
+        hipLaunchKernelGGL(upsample2x_add_bf16_kernel<long long>, dim3(imin(cdiv(total, 256), 16384)), dim3(256), 0, (hipStream_t)stream,
                        (const __bf16 *)in, in_cs, wgt, (const __bf16 *)skip, skip_cs, (__bf16 *)out, out_cs, N, H, W, C / 8);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
