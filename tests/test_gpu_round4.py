@@ -170,3 +170,32 @@ torch.save(out.cpu(), sys.argv[1])
             assert r.returncode == 0, r.stderr[-2000:]
             outs.append(torch.load(path))
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("nbytes", [16, 4096 + 7, 223200, 1 << 20])
+def test_upload_indirect_copies_what_the_slot_names(nbytes):
+    """m3d_upload_indirect: the kernel reads the source ADDRESS from an 8-byte word in pinned host memory when it runs; sizes
+    that are not multiples of 16 bytes, a NULL slot (no copy) and a device-resident source."""
+    L = _hip.lib()
+    dev = _dev()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.RandomState(nbytes % 97)
+    a = torch.from_numpy(rng.randint(0, 256, size=nbytes).astype(np.uint8)).pin_memory()
+    b = torch.from_numpy(rng.randint(0, 256, size=nbytes).astype(np.uint8)).pin_memory()
+    slot = torch.zeros(1, dtype=torch.int64).pin_memory()
+    dst = torch.zeros(-(-nbytes // 16) * 16 + 16, dtype=torch.uint8, device=dev)
+    for src in (a, b):
+        slot[0] = src.data_ptr()
+        _hip.check(L.m3d_upload_indirect(ctypes.c_void_p(slot.data_ptr()), ctypes.c_void_p(dst.data_ptr()), nbytes, st))
+        torch.cuda.synchronize()
+        assert torch.equal(dst[:nbytes].cpu(), src) and int(dst[nbytes:].sum()) == 0       # nothing past the end is touched
+    slot[0] = 0
+    dst.fill_(7)
+    _hip.check(L.m3d_upload_indirect(ctypes.c_void_p(slot.data_ptr()), ctypes.c_void_p(dst.data_ptr()), nbytes, st))
+    torch.cuda.synchronize()
+    assert int((dst != 7).sum()) == 0                                                      # NULL slot: no copy
+    d_src = a.to(dev)
+    slot[0] = d_src.data_ptr()
+    _hip.check(L.m3d_upload_indirect(ctypes.c_void_p(slot.data_ptr()), ctypes.c_void_p(dst.data_ptr()), nbytes, st))
+    torch.cuda.synchronize()
+    assert torch.equal(dst[:nbytes].cpu(), a)
