@@ -370,7 +370,8 @@ def main():
             c2, _ = run_config(args, "bf16", args.configs2_steps, None, rank, world, dev, mdist)
             out["configs2_bf16"] = {k: c2[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config",
                                                         "launch", "roofline", "step_roofline", "gpu_ms_by_kernel_one_step",
-                                                        "mfma_kernel_families") if k in c2}
+                                                        "mfma_kernel_families", "helper_kernels", "mfma_time_weighted_frac",
+                                                        "sclk_under_step_ghz", "roofline_frac_at_held_clock") if k in c2}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(out))
@@ -546,6 +547,26 @@ def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=N
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
+    # ---- shader clock under the step (outside the timed region): one wave on a side stream samples the cycle counter against the
+    # 100 MHz wall clock over a 30 ms window while the step replays next to it
+    sclk = None
+    try:
+        import ctypes
+        from m3dssd_amd import _hip as _h
+        probe = torch.zeros(4, dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        _h.check(_h.lib().m3d_clock_probe(ctypes.c_void_p(probe.data_ptr()), 0.03, ctypes.c_void_p(side.cuda_stream)))
+        for _ in range(max(3, int(0.05 / max(dt / steps, 1e-4)))):
+            timed_step()
+        if flush is not None:
+            flush()
+        torch.cuda.synchronize()
+        pc = probe.cpu().tolist()
+        if pc[3] > pc[1]:
+            sclk = (pc[2] - pc[0]) / (pc[3] - pc[1]) * 0.1
+    except Exception:
+        sclk = None
     eng.profile = roof_rows
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -650,6 +671,10 @@ def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=N
             "mfma_kernel_families": families,
             "mfma_time_weighted_frac": round(mfma_weighted, 4),
             "helper_kernels": helpers,
+            # the clock the chip held while the step replayed (s_memtime / s_memrealtime of a probe wave): `peak` above is the
+            # 2.4 GHz datasheet figure; peak x sclk / 2.4 is what the matrix pipes offered in this run
+            "sclk_under_step_ghz": round(sclk, 3) if sclk else None,
+            "roofline_frac_at_held_clock": round(achieved / wino_div / (peak_tf * sclk / 2.4), 4) if sclk else None,
         }
         if feed:
             out["feed_u8"] = feed_u8_leg(net, conf, B, dev, steps, 1e3 * dt / steps)

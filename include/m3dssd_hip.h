@@ -514,6 +514,10 @@ int m3d_eval_fused_statistics(const double *overlaps, long long ov_stride, doubl
 /* ------------------------------------------------------------------------------------------
  * Instrumentation: HIP-event timing of a launch sequence on a stream (used by bench.py).
  * ------------------------------------------------------------------------------------------ */
+/* One wave samples the shader-cycle counter and the 100 MHz wall clock at both ends of a `seconds`-long window (<= 1 s):
+ * out4_dev = {cycles0, realtime0, cycles1, realtime1}; (cycles1 - cycles0) / (realtime1 - realtime0) x 100 MHz = the shader clock the
+ * chip held while whatever ran next to it on other streams (bench.py: sclk_under_step_ghz). */
+int m3d_clock_probe(long long *out4_dev, double seconds, m3d_stream_t stream);
 int m3d_event_create(void **ev);
 int m3d_event_record(void *ev, m3d_stream_t stream);
 int m3d_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on stop */

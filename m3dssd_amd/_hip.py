@@ -159,6 +159,7 @@ SIGNATURES = {
     "m3d_eval_statistics": (c_int, [P, c_ll, P, c_int, P, c_int, P, P, P, c_int, c_int, ctypes.c_double, ctypes.c_double,
                                     c_int, c_int, P, P, ctypes.POINTER(c_int)]),
     "m3d_eval_fused_statistics": (c_int, [P, c_ll, P, P, P, P, c_int, P, P, P, P, P, c_int, ctypes.c_double, P, c_int, c_int]),
+    "m3d_clock_probe": (c_int, [P, ctypes.c_double, P]),
     "m3d_event_create": (c_int, [ctypes.POINTER(c_void_p)]),
     "m3d_event_record": (c_int, [P, P]),
     "m3d_event_elapsed_ms": (c_int, [P, P, ctypes.POINTER(c_float)]),

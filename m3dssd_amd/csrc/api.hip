@@ -42,6 +42,32 @@ extern "C" int m3d_event_destroy(void *ev)
 }
 
 // ------------------------------------------------------------------------------------------
+// Shader clock the chip actually holds over a window (bench.py: `sclk_under_step_ghz`): ONE wave samples s_memtime (one tick per
+// shader cycle) and s_memrealtime (constant 100 MHz) when it starts, sleeps until `ticks` of the 100 MHz clock have passed and
+// samples both again; run on a side stream while the step replays on the main one, d(memtime) / d(realtime) x 100 MHz is the
+// clock the MFMA peak of that window has to be priced at (the 157.3 TFLOP/s behind `roofline.frac` assume 2.4 GHz; under the fp32
+// kernels the part holds 2.0-2.1 at ~1.2 kW: DESIGN.md).  out = {memtime0, realtime0, memtime1, realtime1}.
+__global__ void clock_probe_kernel(long long *out, long long ticks)
+{
+    if (threadIdx.x != 0) return;
+    const long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    long long r1 = r0;
+    while (r1 - r0 < ticks) {
+        __builtin_amdgcn_s_sleep(127);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    out[0] = c0; out[1] = r0; out[2] = __builtin_readcyclecounter(); out[3] = r1;
+}
+
+extern "C" int m3d_clock_probe(long long *out4_dev, double seconds, m3d_stream_t stream)
+{
+    M3D_REQUIRE(out4_dev && seconds > 0 && seconds <= 1.0, "clock_probe: bad arguments (window <= 1 s)");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out4_dev, (long long)(seconds * 1e8));
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // Drop-in for dcn_v2_cuda_forward (model/DCNv2/src/dcn_v2_cuda.c:10-102) on NCHW tensors.
 // The reference loops over images on the host and round-trips a `columns` scratch through HBM;
 // here the whole batch is one fused gather+GEMM launch.  NCHW<->NHWC conversion and weight packing
