@@ -367,13 +367,19 @@ def main():
             # BASELINE.json configs[2] (bs = 64, bf16 storage + MFMA) on the same clock as the headline line: same step
             # definition, same timed-region bracket, its own roofline objects.
             torch.cuda.empty_cache()
-            c2, _ = run_config(args, "bf16", args.configs2_steps, None, rank, world, dev, mdist)
+            try:
+                c2, _ = run_config(args, "bf16", args.configs2_steps, None, rank, world, dev, mdist)
+            except Exception as e:                 # noqa: BLE001  (side leg: the headline line survives)
+                c2 = {"error": "%s: %s" % (type(e).__name__, e)}
             out["configs2_bf16"] = {k: c2[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config",
                                                         "launch", "roofline", "step_roofline", "gpu_ms_by_kernel_one_step",
                                                         "mfma_kernel_families", "helper_kernels", "mfma_time_weighted_frac",
-                                                        "sclk_under_step_ghz", "roofline_frac_at_held_clock") if k in c2}
+                                                        "sclk_under_step_ghz", "roofline_frac_at_held_clock", "error") if k in c2}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd)
+            try:                                   # a reported side figure: its failure must not take the headline line with it
+                out["cpu_baseline"] = cpu_baseline(sd)
+            except Exception as e:                 # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "unit": "images/sec", "kind": "port", "error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
@@ -677,7 +683,10 @@ def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=N
             "roofline_frac_at_held_clock": round(achieved / wino_div / (peak_tf * sclk / 2.4), 4) if sclk else None,
         }
         if feed:
-            out["feed_u8"] = feed_u8_leg(net, conf, B, dev, steps, 1e3 * dt / steps)
+            try:                                   # (side leg: never part of `value`)
+                out["feed_u8"] = feed_u8_leg(net, conf, B, dev, steps, 1e3 * dt / steps)
+            except Exception as e:                 # noqa: BLE001
+                out["feed_u8"] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
         if rccl is not None:
             out["rccl"] = rccl
             if not rccl["shards_match"]:
