@@ -191,26 +191,59 @@ def kernel_symbol(label):
         "true" if "planar" in label else "false")
 
 
-def pmc_traffic(kernel_label):
-    """(HBM bytes per launch, source file) of a kernel from the committed PMC passes (profiles/*_hbm_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 wide-read correction applied); (None, None) if the
-    kernel was not profiled.  PMC counters cannot be collected inside the timed run itself: the figure is a constant
-    from the builder's profiling lease, labelled as such (`traffic_source`)."""
+# engine family label prefix -> the kernel sources whose edit invalidates a PMC pass of that family (plus the shared headers)
+FAMILY_SOURCES = (("bf16_anab", ("bf16_anab.hip",)), ("bf16_head_mlp", ("bf16_head_mlp.hip",)), ("bf16_frontend", ("bf16_frontend.hip",)),
+                  ("bf16_dcn_patch", ("bf16_dcn_patch.hip", "bf16_conv.hip")), ("bf16_wide", ("bf16_conv_wide.hip",)),
+                  ("bf16_halo", ("bf16_conv.hip",)), ("bf16_conv", ("bf16_conv.hip",)), ("wino44", ("wino44_conv.hip",)),
+                  ("wino", ("wino_conv.hip",)), ("conv_wave", ("dcn_wave.hip", "igemm_conv.hip")), ("head_mlp", ("head_mlp.hip",)),
+                  ("igemm", ("igemm_conv.hip",)))
+SHARED_SOURCES = ("common.h", "bf16_tile.h", "m3dssd_hip.h")
+PROFILES_DIR = os.path.join(ROOT, "profiles")
+
+
+def family_sources(kernel_label):
+    for prefix, files in FAMILY_SOURCES:
+        if kernel_label.startswith(prefix):
+            return files + SHARED_SOURCES
+    return SHARED_SOURCES
+
+
+def traffic_is_stale(doc, kernel_label, lib_hashes):
+    """A committed PMC pass is stale for a family when the library that is LOADED NOW was built from other sources of that
+    family's kernels than the library the pass ran: `csrc_files` of the pass (name -> sha256[:16], written by
+    tools/pmc_traffic.py from m3d_source_hashes() of the profiled library) against the loaded library's own record.  A pass that
+    carries no record (rounds 1-4) cannot be checked: stale."""
+    rec = doc.get("csrc_files")
+    if not rec or not lib_hashes:
+        return True
+    return any(rec.get(f) != lib_hashes.get(f) for f in family_sources(kernel_label))
+
+
+def pmc_traffic(kernel_label, lib_hashes=None, profiles_dir=None):
+    """(HBM bytes per launch, source file, stale) of a kernel family from the committed PMC passes (profiles/*_hbm_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 wide-read correction applied); (None, None, None) if the
+    kernel was not profiled.  PMC counters cannot be collected inside the timed run itself: the figure is a constant from the
+    builder's profiling lease, labelled as such (`traffic_source`) and checked against the loaded library's source record
+    (`traffic_stale`)."""
     import glob
+    if lib_hashes is None:
+        from m3dssd_amd import _hip
+        lib_hashes = _hip.lib_source_hashes()
     sym = kernel_symbol(kernel_label)
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(profiles_dir or PROFILES_DIR, "*_hbm_traffic.json")), reverse=True):
         try:
             doc = json.load(open(f))
         except Exception:
             continue
         fam = doc.get("families") or {}
+        rel = os.path.relpath(f, ROOT)
         if kernel_label in fam:          # per-FAMILY average (tools/pmc_traffic.py aligned with --dump-launches)
-            return fam[kernel_label]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT) + "#families"
+            return fam[kernel_label]["hbm_bytes_per_launch"], rel + "#families", traffic_is_stale(doc, kernel_label, lib_hashes)
         if fam:
             continue                     # a file with family rows that lacks this label is from another dtype / plan
         if sym in doc.get("kernels", {}):   # older passes: per-SYMBOL average (one symbol can serve several families)
-            return doc["kernels"][sym]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT) + "#symbol-average"
-    return None, None
+            return doc["kernels"][sym]["hbm_bytes_per_launch"], rel + "#symbol-average", traffic_is_stale(doc, kernel_label, lib_hashes)
+    return None, None, None
 
 
 def algorithmic_bytes(op):
@@ -315,6 +348,9 @@ def parse_args():
     ap.add_argument("--no-configs2", action="store_true",
                     help="skip the extra configs[2] (bs=64 bf16) measurement that the default N=1 f32 run appends as 'configs2_bf16'")
     ap.add_argument("--configs2-steps", type=int, default=60)
+    ap.add_argument("--no-configs3", action="store_true",
+                    help="skip the configs[3]-shaped leg (32 images per GPU, f32 and bf16) that the default N=1 f32 run appends as 'configs3_shard32'")
+    ap.add_argument("--configs3-steps", type=int, default=30)
     ap.add_argument("--no-feed", action="store_true",
                     help="skip the fed-input leg (uint8 frames from pinned host memory every step) that the default N=1 f32 run appends as 'feed_u8'")
     ap.add_argument("--dump-layers", default=None, help="write the per-launch table of one instrumented step here")
@@ -375,6 +411,20 @@ def main():
                                                         "launch", "roofline", "step_roofline", "gpu_ms_by_kernel_one_step",
                                                         "mfma_kernel_families", "helper_kernels", "mfma_time_weighted_frac",
                                                         "sclk_under_step_ghz", "roofline_frac_at_held_clock", "error") if k in c2}
+        if world == 1 and args.dtype == "f32" and args.batch is None and not args.no_configs3:
+            # BASELINE.json configs[3]: bs = 256 sharded 32 per GPU over 8 MI355X.  One GPU measures its shard (32 images per
+            # step, both precisions, same bracket) and the one-rank RCCL cost of the [32, 41, 14] block every rank contributes;
+            # `python bench.py --gpus 8 --batch 32` is the full shape when a node is available.
+            c3 = {"workload": "BASELINE.json configs[3] per-GPU shard: 32 images/GPU per step, 1280x384 (bs 256 = 8 x 32)"}
+            for dt_ in ("f32", "bf16"):
+                torch.cuda.empty_cache()
+                try:
+                    c3[dt_] = shard_leg(dt_, 32, args.configs3_steps, dev)
+                except Exception as e:             # noqa: BLE001  (side leg)
+                    c3[dt_] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
+            c3["allgather_us_one_rank_rccl"] = rccl_one_rank_allgather_us(32, 40, dev)
+            c3["allgather_bytes_per_rank"] = 32 * 41 * 14 * 4
+            out["configs3_shard32"] = c3
         if world == 1 and not args.no_cpu_baseline:
             try:                                   # a reported side figure: its failure must not take the headline line with it
                 out["cpu_baseline"] = cpu_baseline(sd)
@@ -430,6 +480,71 @@ def feed_u8_leg(net, conf, B, dev, steps, resident_ms):
             "h2d_alone_ms": round(h2d_alone_ms, 4), "h2d_alone_gbs": round(nbytes / (h2d_alone_ms * 1e-3) / 1e9, 2)}
 
 
+def rccl_one_rank_allgather_us(B, post, dev):
+    """The collective of SURVEY 8e on its real block size ([B, post + 1, 14] fp32) through the nccl (= RCCL) backend with ONE rank --
+    what a single-GPU lease can measure of it: launch + protocol latency without a peer.  None when no process group can be made."""
+    import socket
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return None
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    try:
+        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+        blk = torch.zeros(B, post + 1, 14, device=dev, dtype=torch.float32)
+        out = torch.empty_like(blk)
+        for _ in range(10):
+            dist.all_gather_into_tensor(out, blk)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(100):
+            dist.all_gather_into_tensor(out, blk)
+        e1.record()
+        torch.cuda.synchronize()
+        return round(e0.elapsed_time(e1) * 10.0, 2)
+    except Exception:                  # noqa: BLE001
+        return None
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def shard_leg(dtype, B, steps, dev):
+    """One (dtype, per-GPU batch) point with the step definition and timed bracket of the headline line (pipelined hipGraph replays,
+    `steps` batches forwarded AND detected inside the bracket), without the instrumentation passes: BASELINE.json configs[3] is
+    bs = 256 sharded 32 per GPU -- this is its per-GPU shard on one MI355X."""
+    from m3dssd_amd import synth
+    from m3dssd_amd.pipeline import PipelinedDetector
+    from model.M3d_inference_align import build
+    conf = synth.synth_conf(CROP, 0, batch_size=B, device=str(dev))
+    net = build(conf, "test")
+    net.load_state_dict(synth.synth_state_dict(0), strict=True)
+    net = net.to(dev).set_compute_dtype(dtype)
+    x = synth.synth_frames(B, CROP, 1234).to(dev)
+    pipe = PipelinedDetector(net, conf, B, CROP[0], CROP[1])
+    pipe.input.copy_(x)
+    for _ in range(3):
+        pipe.step(as_block=True)
+    pipe.flush(as_block=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.step(as_block=True)
+    r = pipe.flush(as_block=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    counts = r[1]
+    out = {"value": round(B * steps / dt, 2), "unit": "images/sec", "per_gpu_batch": B, "steps": steps,
+           "ms_per_step": round(1e3 * dt / steps, 3), "dtype": dtype, "detections_last_batch": int(counts.sum().item()),
+           "algorithmic_tflops": round(B * ALG_GFLOP_PER_IMAGE * 1e9 * steps / dt / 1e12, 1)}
+    del pipe, net
+    torch.cuda.empty_cache()
+    return out
+
+
 def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=None, feed=False):
     """Warm up, instrument, time `steps` steps of one (dtype, batch) configuration; returns (JSON dict or None off rank 0, state dict)."""
     from m3dssd_amd import synth
@@ -481,12 +596,20 @@ def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=N
         a[2] += 1
     # MFMA-bound kernel families (everything else is a small HBM/latency-bound helper)
     igemm = {k: v for k, v in per_kind.items() if k.startswith(MFMA_FAMILIES)}
-    dominant = max(igemm, key=lambda k: igemm[k][0])
+    # The dominant KERNEL is chosen by symbol, not by engine family: one symbol serves several families (conv_wave_kernel<true, 4>
+    # = the full-size deformable layers and their three split-K forms), and the headline roofline belongs to the symbol with the
+    # largest share of GPU time (VERDICT r4 #4 / #3a: by family the second-largest kernel won).
+    by_symbol = {}
+    for k, v in igemm.items():
+        by_symbol.setdefault(kernel_symbol(k), []).append(k)
+    dom_symbol = max(by_symbol, key=lambda sy: sum(igemm[k][0] for k in by_symbol[sy]))
+    dom_kinds = sorted(by_symbol[dom_symbol], key=lambda k: -igemm[k][0])
+    dominant = dom_kinds[0]                     # the largest family of the dominant symbol (labels, Winograd divisor)
     gpu_ms_all = sum(v[0] for v in per_kind.values())
     breakdown = {k: round(v[0], 3) for k, v in sorted(per_kind.items(), key=lambda kv: -kv[1][0])}
 
     # ---- roofline pass: a few eager steps with HIP events around the dominant kernel's launches ---------
-    eng.profile, eng.profile_kinds = [], {dominant}
+    eng.profile, eng.profile_kinds = [], set(dom_kinds)
     ROOF_REPS = 5
     for _ in range(ROOF_REPS):
         step()
@@ -597,18 +720,32 @@ def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=N
             a = alg.setdefault(op[1], [0.0, 0])
             a[0] += ab
             a[1] += 1
-    alg_bytes = int(alg[dominant][0] / alg[dominant][1]) if dominant in alg else None
+    dom_alg = [alg[k] for k in dom_kinds if k in alg]
+    alg_bytes = int(sum(a[0] for a in dom_alg) / sum(a[1] for a in dom_alg)) if dom_alg else None
     peak_tf = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+    from m3dssd_amd import _hip as _hl
+    lib_hashes = _hl.lib_source_hashes()
     families = {}
     for k, (ms, fl, cnt) in sorted(igemm.items(), key=lambda kv: -kv[1][0]):
         div = 4.0 if k.startswith("wino44") else (2.25 if k.startswith("wino") else 1.0)
         tf = fl / (ms * 1e-3) / 1e12 / div if ms > 0 else 0.0
-        tr, src = pmc_traffic(k)
+        tr, src, stale = pmc_traffic(k, lib_hashes)
+        abl = int(alg[k][0] / alg[k][1]) if k in alg else None
+        gbs = alg[k][0] / (ms * 1e-3) / 1e9 if (k in alg and ms > 0) else None
         families[k] = {"kernel": kernel_symbol(k), "launches_per_step": cnt, "ms_per_step": round(ms, 3),
                        "executed_tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / peak_tf, 3),
-                       "algorithmic_bytes_per_launch": int(alg[k][0] / alg[k][1]) if k in alg else None,
-                       "algorithmic_gbs": round(alg[k][0] / (ms * 1e-3) / 1e9, 1) if (k in alg and ms > 0) else None,
-                       "traffic": tr, "traffic_source": src}
+                       "algorithmic_bytes_per_launch": abl,
+                       "algorithmic_gbs": round(gbs, 1) if gbs is not None else None,
+                       "hbm_frac": round(gbs / PEAK_HBM_GBS, 3) if gbs is not None else None,
+                       # which roof the family sits closer to (fraction of the MFMA peak vs fraction of the HBM peak of its
+                       # algorithmic bytes): the larger fraction names the binding resource
+                       "nearer_roof": ("hbm" if (gbs is not None and gbs / PEAK_HBM_GBS > tf / peak_tf) else "mfma"),
+                       "traffic": tr, "traffic_ratio": round(tr / abl, 2) if (tr and abl) else None,
+                       "traffic_source": src, "traffic_stale": stale}
+    # the dominant symbol's traffic: launch-weighted mean over its families
+    dom_tr = [(families[k]["traffic"], families[k]["launches_per_step"]) for k in dom_kinds if families[k]["traffic"]]
+    dom_traffic = int(sum(t * n for t, n in dom_tr) / sum(n for _, n in dom_tr)) if dom_tr else None
+    dom_stale = any(families[k]["traffic_stale"] for k in dom_kinds if families[k]["traffic"]) if dom_tr else None
 
     rccl = None
     if world > 1:
@@ -645,7 +782,8 @@ def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=N
             "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]: full M3d_inference_align (DLA-34 + DCNv2 align + ANAB) "
                                    "forward + decode + top-3000 + NMS, bs=%d/GPU, 1280x384, %s, random-init "
-                                   "synthetic weights and frames" % (2 if bf16 else 1, B, "bf16 storage + bf16 MFMA, fp32 "
+                                   "synthetic weights and frames" % (3 if B == 32 else (2 if bf16 else 1), B,
+                                                                     "bf16 storage + bf16 MFMA, fp32 "
                                                                      "accumulation / epilogues" if bf16 else "fp32"),
                        "per_gpu_batch": B, "global_batch": B * world, "resolution": [CROP[1], CROP[0]],
                        "parallelism": "dp%d (batch sharded, 1 all-gather of [B,40,14] detections)" % world},
@@ -665,14 +803,17 @@ def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=N
                                    "the 2.4 GHz boost clock")) if wino_div > 1 else
                                  "achieved = algorithmic FLOPs of the launches / HIP-event time",
                          "direct_conv_equivalent_tflops": round(achieved, 2),
-                         "traffic": pmc_traffic(dominant)[0], "traffic_source": pmc_traffic(dominant)[1],
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes committed under profiles/, not this run)",
+                         "traffic": dom_traffic, "traffic_source": families[dominant]["traffic_source"],
+                         "traffic_stale": dom_stale,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes committed under profiles/, not this run; "
+                                         "traffic_stale = the loaded library was built from other sources of this kernel than the profiled one)",
+                         "families_of_symbol": dom_kinds,
                          "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": dom_n, "timing": "median of %d HIP-event measurements per launch" % ROOF_REPS,
                          "algorithmic_gbs": round(alg_bytes / (dom_ms / max(dom_n, 1) * 1e-3) / 1e9, 1) if alg_bytes and dom_ms > 0 else None,
                          "hbm_frac_of_peak": round(alg_bytes / (dom_ms / max(dom_n, 1) * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if alg_bytes and dom_ms > 0 else None,
                          "avg_launch_ms": round(dom_ms / max(dom_n, 1), 4),
                          "avg_launch_gflop": round(dom_flops / max(dom_n, 1) / 1e9, 3),
-                         "share_of_gpu_time": round(igemm[dominant][0] / gpu_ms_all, 3)},
+                         "share_of_gpu_time": round(sum(igemm[k][0] for k in dom_kinds) / gpu_ms_all, 3)},
             "gpu_ms_by_kernel_one_step": breakdown,
             "mfma_kernel_families": families,
             "mfma_time_weighted_frac": round(mfma_weighted, 4),

@@ -61,6 +61,8 @@ enum {
 const char *m3d_last_error(void);
 /* Library/ABI version (bumped when a signature changes). */
 int m3d_abi_version(void);
+/* "file:sha256[:16];file:sha256[:16];..." of the sources (csrc .hip / .h files and this header) the loaded library was built from. */
+const char *m3d_source_hashes(void);
 
 /* ------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32), NHWC activations.
@@ -147,7 +149,11 @@ int m3d_wino44_kpair(const m3d_conv_desc *d);
 /* Split-K for maps whose 16-tile strips x 64-channel blocks do not fill the chip (512 -> 512 @ 12x40 at bs 8):
  * *splits slices of >= 64 input channels run as gridDim.z, raw partial outputs go to splitk_ws ([splits][N*H*W][Cout_pad]
  * fp32, *ws_bytes), a second launch adds them in slice order and applies the epilogue.  *splits = 1 / *ws_bytes = 0: no split.
- * m3d_wino44_conv3x3_forward[_ex with nb != 1] splits when the descriptor carries a workspace of at least *ws_bytes. */
+ * m3d_wino44_conv3x3_forward and _ex with nb == 0 or nb == the split form (1 = 64-channel workgroups by default) split when the
+ * descriptor carries a workspace of at least *ws_bytes; _ex with the other nb runs unsplit.  The split form and the fill
+ * threshold are process-wide and read ONCE from the environment (M3D_W44_SPLIT_NB = 1 | 2, M3D_W44_SPLIT_FILL = workgroups a
+ * layer must reach to run unsplit): size the workspace with m3d_wino44_splitk_plan in the process that launches, not from a
+ * table computed under another setting. */
 int m3d_wino44_splitk_plan(const m3d_conv_desc *d, int *splits, long long *ws_bytes);
 /* Same as _ex, and every thread of the launch first touches a few 128-byte lines of [touch, touch + touch_bytes): the engine
  * passes the U tensor of the NEXT F(4x4) layer, which is then in the memory-side cache instead of HBM when that layer's B
@@ -419,6 +425,10 @@ int m3d_softmax_rows(float *x, int rows, int valid, int cs, m3d_stream_t stream)
  * key of m3d_topk_decode. */
 int m3d_bundle_outputs(const float *cls_planar, const float *box_planar, float *cls, float *prob, float *bbox_2d,
                        float *bbox_3d, unsigned int *score_bits, int B, int A, int HW, m3d_stream_t stream);
+/* The sort keys alone (score_bits [B][A*HW]) from the planar class logits, with the softmax arithmetic of m3d_bundle_outputs (the
+ * same bits): for callers that only run the detection stage (m3d_topk_decode_planar) and never read cls / prob / bbox_2d /
+ * bbox_3d in full -- 5.5 MB per image instead of the 38 MB the bundling moves.  HW % 4 == 0, 16-byte aligned buffers. */
+int m3d_score_keys_planar(const float *cls_planar, unsigned int *score_bits, int B, int A, int HW, m3d_stream_t stream);
 /* The reference's `argsort()[::-1][:nms_topN_pre]` + decode (lib/rpn_util.py:1442-1544) in one launch, one workgroup
  * per image: radix select of the k rows with the largest (score, -row) -- descending score, ascending row among equal
  * scores: a total order, unlike the reference's unstable argsort -- bitonic sort of those k, decode of exactly those rows
@@ -435,6 +445,14 @@ int m3d_topk_decode(const unsigned int *score_bits, const float *prob, const flo
 int m3d_topk_decode_scaled(const unsigned int *score_bits, const float *prob, const float *bbox_2d, const float *bbox_3d,
                            const float *rois, const float *anchors, const float *means, const float *stds, const float *scale,
                            float *aboxes, int *rows_out, void *workspace, long long workspace_bytes, int B, int R, int k,
+                           m3d_stream_t stream);
+/* m3d_topk_decode_scaled reading the planar staging of the heads instead of the bundled tensors (cls_planar [B][4A][HW],
+ * box_planar [B][11][A*HW]; score_bits from m3d_score_keys_planar or m3d_bundle_outputs): row = a*HW + p like
+ * lib/rpn_util.py:892-901 flattens it; class probabilities of the k decoded rows are recomputed from their logits.  Output
+ * identical (bit for bit) to m3d_bundle_outputs + m3d_topk_decode_scaled. */
+int m3d_topk_decode_planar(const unsigned int *score_bits, const float *cls_planar, const float *box_planar, const float *rois,
+                           const float *anchors, const float *means, const float *stds, const float *scale, float *aboxes,
+                           int *rows_out, void *workspace, long long workspace_bytes, int B, int A, int HW, int k,
                            m3d_stream_t stream);
 /* Decode `n_rows` selected rows per image -> aboxes [B][n_rows][14]
  * (x1,y1,x2,y2,score,cls,x3d,y3d,z3d,w3d,h3d,l3d,ry3d,anchor). */

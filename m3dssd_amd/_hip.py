@@ -86,6 +86,7 @@ P = c_void_p
 SIGNATURES = {
     "m3d_last_error": (ctypes.c_char_p, []),
     "m3d_abi_version": (c_int, []),
+    "m3d_source_hashes": (ctypes.c_char_p, []),
     "m3d_conv2d_forward": (c_int, [ctypes.POINTER(ConvDesc), P]),
     "m3d_conv_bf16_forward": (c_int, [ctypes.POINTER(ConvBf16Desc), P]),
     "m3d_conv_bf16_variant": (c_int, [ctypes.POINTER(ConvBf16Desc)]),
@@ -149,6 +150,8 @@ SIGNATURES = {
     "m3d_topk_decode_workspace_bytes": (c_ll, [c_int, c_int]),
     "m3d_topk_decode": (c_int, [P] * 11 + [c_ll] + [c_int] * 3 + [P]),
     "m3d_topk_decode_scaled": (c_int, [P] * 12 + [c_ll] + [c_int] * 3 + [P]),
+    "m3d_score_keys_planar": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "m3d_topk_decode_planar": (c_int, [P] * 11 + [c_ll] + [c_int] * 4 + [P]),
     "m3d_select_post": (c_int, [P] * 3 + [c_int] * 3 + [P, P, P]),
     "m3d_nms_workspace_bytes": (c_ll, [c_int, c_int]),
     "m3d_nms_sorted_dev": (c_int, [P, c_int, c_int, c_int, c_float, P, P, P, P]),
@@ -193,6 +196,19 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = L
     return _lib
+
+
+def lib_source_hashes():
+    """{file name: sha256[:16]} of the sources the LOADED library was built from (m3d_source_hashes)."""
+    txt = lib().m3d_source_hashes().decode()
+    return dict(item.split(":", 1) for item in txt.split(";") if item)
+
+
+def tree_source_hashes():
+    """The same record computed from the sources in the tree (what the library would carry if it were rebuilt now)."""
+    import hashlib
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip") or f.endswith(".h")] + [HEADER]
+    return {os.path.basename(f): hashlib.sha256(open(f, "rb").read()).hexdigest()[:16] for f in files}
 
 
 def check(status):

@@ -537,7 +537,8 @@ extern "C" int m3d_upsample2x_add(const float *in, int in_cs, const float *wgt, 
     M3D_REQUIRE(in && wgt && out && C % 4 == 0 && in_cs % 4 == 0 && out_cs % 4 == 0 && (!skip || skip_cs % 4 == 0),
                 "upsample2x_add: C and strides must be x4");
     const long long total = (long long)N * 4 * H * W * (C / 4);
-    if (total < (1ll << 31))
+    // the int form's grid-stride increment (at most 8192 x 256) must not carry the index past 2^31 on its last step
+    if (total < (1ll << 31) - 8192ll * 256)
         hipLaunchKernelGGL(upsample2x_add_kernel<int>, dim3(imin(cdiv(total, 256), 8192)), dim3(256), 0, (hipStream_t)stream, in,
                            in_cs, wgt, skip, skip_cs, out, out_cs, N, H, W, C / 4);      // (32-bit index arithmetic: no 64-bit divisions)
     else

@@ -224,7 +224,8 @@ extern "C" int m3d_upsample2x_add_bf16(const void *in, int in_cs, const float *w
     M3D_REQUIRE(in && wgt && out && C % 8 == 0 && in_cs % 8 == 0 && out_cs % 8 == 0 && (!skip || skip_cs % 8 == 0),
                 "upsample2x_add_bf16: C and strides must be x8");
     const long long total = (long long)N * 4 * H * W * (C / 8);
-    if (total < (1ll << 31))
+    // the int form's grid-stride increment (at most 16384 x 256) must not carry the index past 2^31 on its last step
+    if (total < (1ll << 31) - 16384ll * 256)
         hipLaunchKernelGGL(upsample2x_add_bf16_kernel<int>, dim3(imin(cdiv(total, 256), 16384)), dim3(256), 0, (hipStream_t)stream,
                            (const __bf16 *)in, in_cs, wgt, (const __bf16 *)skip, skip_cs, (__bf16 *)out, out_cs, N, H, W, C / 8);
     else

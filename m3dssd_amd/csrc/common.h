@@ -168,6 +168,29 @@ static inline int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ float leaky(float v) { return fmaxf(v, v * M3D_LEAKY_SLOPE); }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
+// ---- class softmax + row score shared by bundle_outputs / score_keys_planar (rpn_kernels.hip) and the planar decode
+// (detect_kernels.hip): one definition, so the probabilities a row is SORTED by and the ones it is DECODED with are the same bits
+// whichever kernel computes them (M3d_inference_align.py:229-232: softmax over the 4 class logits of an anchor row).
+__device__ __forceinline__ f32x4 class_softmax4(f32x4 l)
+{
+    const float mx = fmaxf(fmaxf(l[0], l[1]), fmaxf(l[2], l[3]));
+    f32x4 e;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { e[c] = expf(l[c] - mx); s += e[c]; }
+    f32x4 pr;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pr[c] = e[c] / s;
+    return pr;
+}
+__device__ __forceinline__ float fg_score(f32x4 pr) { return fmaxf(fmaxf(pr[1], pr[2]), pr[3]); }
+// monotone unsigned image of a float: a > b as floats <=> f32_sortable(a) > f32_sortable(b)
+__device__ __forceinline__ unsigned int f32_sortable(float f)
+{
+    unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
 // ---- deterministic split-K reduction shared by the LDS-tiled and the wave-granular implicit GEMMs (igemm_conv.hip) -----------
 // ws holds `splits` raw partial sums [split][M][Cout_pad]; they are added in split order and the conv epilogue is applied.
 struct SplitkReduceArgs {

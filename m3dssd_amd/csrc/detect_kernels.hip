@@ -18,10 +18,10 @@
 
 // Decode (lib/rpn_util.py:1442-1521 + bbox_transform_inv :1137-1186), scale_factor = 1.
 // Row layout out: x1,y1,x2,y2,score,cls,x3d,y3d,z3d,w3d,h3d,l3d,ry3d,anchor  (rpn_util.py:1550)
-__device__ __forceinline__ void decode_row(int row, size_t o, const float *__restrict__ prob, const float *__restrict__ b2,
-                                           const float *__restrict__ b3, const float *__restrict__ rois,
-                                           const float *__restrict__ anchors, const float *__restrict__ means,
-                                           const float *__restrict__ stds, float *__restrict__ q)
+__device__ __forceinline__ void decode_values(int row, const float *__restrict__ v2 /*[4]*/, const float *__restrict__ v3 /*[7]*/,
+                                              float p1, float p2, float p3, const float *__restrict__ rois,
+                                              const float *__restrict__ anchors, const float *__restrict__ means,
+                                              const float *__restrict__ stds, float *__restrict__ q)
 {
     const float *ro = rois + (size_t)row * 5;
     const float x1 = ro[0], y1 = ro[1], x2 = ro[2], y2 = ro[3];
@@ -31,18 +31,17 @@ __device__ __forceinline__ void decode_row(int row, size_t o, const float *__res
     const float ctr_x = x1 + 0.5f * widths, ctr_y = y1 + 0.5f * heights;
     float d3[7];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) d3[k] = b3[o * 7 + k] * stds[4 + k] + means[4 + k];
-    const float dx = b2[o * 4 + 0] * stds[0] + means[0];
-    const float dy = b2[o * 4 + 1] * stds[1] + means[1];
-    const float dw = b2[o * 4 + 2] * stds[2] + means[2];
-    const float dh = b2[o * 4 + 3] * stds[3] + means[3];
+    for (int k = 0; k < 7; ++k) d3[k] = v3[k] * stds[4 + k] + means[4 + k];
+    const float dx = v2[0] * stds[0] + means[0];
+    const float dy = v2[1] * stds[1] + means[1];
+    const float dw = v2[2] * stds[2] + means[2];
+    const float dh = v2[3] * stds[3] + means[3];
     const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
     const float pw = expf(dw) * widths, ph = expf(dh) * heights;
     q[0] = pcx - 0.5f * pw;
     q[1] = pcy - 0.5f * ph;
     q[2] = pcx + 0.5f * pw;
     q[3] = pcy + 0.5f * ph;
-    const float p1 = prob[o * 4 + 1], p2 = prob[o * 4 + 2], p3 = prob[o * 4 + 3];
     float sc = p1;
     int cl = 1;
     if (p2 > sc) { sc = p2; cl = 2; }
@@ -57,6 +56,43 @@ __device__ __forceinline__ void decode_row(int row, size_t o, const float *__res
     q[11] = expf(d3[5]) * an[7];
     q[12] = an[8] + d3[6];
     q[13] = (float)tr;
+}
+
+// rows of the bundled tensors prob [B][R][4], bbox_2d [B][R][4], bbox_3d [B][R][7]; o = img * R + row
+__device__ __forceinline__ void decode_row(int row, size_t o, const float *__restrict__ prob, const float *__restrict__ b2,
+                                           const float *__restrict__ b3, const float *__restrict__ rois,
+                                           const float *__restrict__ anchors, const float *__restrict__ means,
+                                           const float *__restrict__ stds, float *__restrict__ q)
+{
+    float v2[4], v3[7];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v2[k] = b2[o * 4 + k];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v3[k] = b3[o * 7 + k];
+    decode_values(row, v2, v3, prob[o * 4 + 1], prob[o * 4 + 2], prob[o * 4 + 3], rois, anchors, means, stds, q);
+}
+
+// the same row read from the planar staging the heads write (cls [B][4A][HW], box [B][11][A*HW]): the class probabilities are
+// recomputed from the four logits with the arithmetic of bundle_outputs (class_softmax4, common.h) -- the same bits
+__device__ __forceinline__ void decode_row_planar(int row, int img, int A, int HW, const float *__restrict__ cls_pl,
+                                                  const float *__restrict__ box_pl, const float *__restrict__ rois,
+                                                  const float *__restrict__ anchors, const float *__restrict__ means,
+                                                  const float *__restrict__ stds, float *__restrict__ q)
+{
+    const int R = A * HW;
+    const int an = row / HW, p = row - an * HW;
+    const float *cb = cls_pl + (size_t)img * 4 * R;
+    f32x4 l;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) l[c] = cb[(size_t)(c * A + an) * HW + p];
+    const f32x4 pr = class_softmax4(l);
+    const float *bb = box_pl + (size_t)img * 11 * R + row;
+    float v2[4], v3[7];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v2[k] = bb[(size_t)k * R];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v3[k] = bb[(size_t)(4 + k) * R];
+    decode_values(row, v2, v3, pr[1], pr[2], pr[3], rois, anchors, means, stds, q);
 }
 
 __global__ void decode_rows_kernel(const long long *__restrict__ rows, const float *__restrict__ prob,
@@ -93,6 +129,7 @@ struct TopkArgs {
     unsigned long long *cand;         // workspace [B][2][R]
     const float *scale;               // [B] or null: test-time scale factor of each image (lib/rpn_util.py:1504-1506)
     int R, k;
+    int A, HW;                        // planar form (A > 0): prob = cls planar [B][4A][HW], b2 = box planar [B][11][A*HW], b3 unused
 };
 
 // Exclusive prefix sum of one value per thread over the 1024-thread workgroup (16 waves): wave shuffles + one LDS hop.
@@ -233,7 +270,8 @@ __global__ __launch_bounds__(TOPK_NT) void topk_decode_kernel(TopkArgs a)
         const int row = (int)(0xFFFFFFFFu - (unsigned)sel[i]);
         if (a.rows_out) a.rows_out[(size_t)img * k + i] = row;
         float *q = a.aboxes + ((size_t)img * k + i) * 14;
-        decode_row(row, (size_t)img * R + row, a.prob, a.b2, a.b3, a.rois, a.anchors, a.means, a.stds, q);
+        if (a.A > 0) decode_row_planar(row, img, a.A, a.HW, a.prob, a.b2, a.rois, a.anchors, a.means, a.stds, q);
+        else decode_row(row, (size_t)img * R + row, a.prob, a.b2, a.b3, a.rois, a.anchors, a.means, a.stds, q);
         if (a.scale) {
             // `coords_2d[:, 0:4] /= scale_factor; coords_3d[:, 0:2] /= scale_factor` BEFORE the sort and the NMS, as the reference
             // does it (lib/rpn_util.py:1504-1506): the +1 convention of the NMS areas is not scale invariant, so an IoU next to
@@ -277,7 +315,30 @@ extern "C" int m3d_topk_decode_scaled(const unsigned int *score_bits, const floa
     TopkArgs a;
     a.score_bits = score_bits; a.prob = prob; a.b2 = bbox_2d; a.b3 = bbox_3d; a.rois = rois; a.anchors = anchors;
     a.means = means; a.stds = stds; a.aboxes = aboxes; a.rows_out = rows_out; a.cand = (unsigned long long *)workspace;
-    a.R = R; a.k = k; a.scale = scale;
+    a.R = R; a.k = k; a.scale = scale; a.A = 0; a.HW = 0;
+    hipLaunchKernelGGL(topk_decode_kernel, dim3(B), dim3(TOPK_NT), 0, (hipStream_t)stream, a);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+extern "C" int m3d_topk_decode_planar(const unsigned int *score_bits, const float *cls_planar, const float *box_planar,
+                                      const float *rois, const float *anchors, const float *means, const float *stds,
+                                      const float *scale, float *aboxes, int *rows_out, void *workspace, long long workspace_bytes,
+                                      int B, int A, int HW, int k, m3d_stream_t stream)
+{
+    M3D_REQUIRE(score_bits && cls_planar && box_planar && rois && anchors && means && stds && aboxes && workspace,
+                "topk_decode_planar: null pointer");
+    M3D_REQUIRE(B >= 1 && A >= 1 && HW >= 1 && (long long)A * HW < (1 << 22), "topk_decode_planar: A * HW must be in [1, 2^22)");
+    const int R = A * HW;
+    M3D_REQUIRE(k >= 1 && k <= R && k <= TOPK_MAXK, "topk_decode_planar: k (%d) must be in [1, min(R, %d)]", k, TOPK_MAXK);
+    if (workspace_bytes < m3d_topk_decode_workspace_bytes(B, R)) {
+        m3d_set_error("topk_decode_planar: workspace of %lld bytes, %lld needed", workspace_bytes, m3d_topk_decode_workspace_bytes(B, R));
+        return M3D_E_WORKSPACE;
+    }
+    TopkArgs a;
+    a.score_bits = score_bits; a.prob = cls_planar; a.b2 = box_planar; a.b3 = nullptr; a.rois = rois; a.anchors = anchors;
+    a.means = means; a.stds = stds; a.aboxes = aboxes; a.rows_out = rows_out; a.cand = (unsigned long long *)workspace;
+    a.R = R; a.k = k; a.scale = scale; a.A = A; a.HW = HW;
     hipLaunchKernelGGL(topk_decode_kernel, dim3(B), dim3(TOPK_NT), 0, (hipStream_t)stream, a);
     M3D_LAUNCH_CHECK();
     return M3D_OK;

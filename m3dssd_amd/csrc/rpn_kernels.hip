@@ -477,12 +477,6 @@ extern "C" int m3d_softmax_rows(float *x, int rows, int valid, int cs, m3d_strea
 // ---------------------------------------------------------------------------------------
 // Output bundling: flatten_tensor x13 + cat + class softmax (M3d_inference_align.py:229-232,280-301).
 // One thread per anchor row = (a*HW + p); planar reads are coalesced along p, row writes are 16 B.
-__device__ __forceinline__ unsigned int f32_sortable(float f)
-{
-    unsigned int u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-
 __global__ void bundle_outputs_kernel(const float *__restrict__ cls_pl, const float *__restrict__ box_pl,
                                       float *__restrict__ cls, float *__restrict__ prob, float *__restrict__ b2,
                                       float *__restrict__ b3, unsigned int *__restrict__ key, int A, int HW)
@@ -496,14 +490,7 @@ __global__ void bundle_outputs_kernel(const float *__restrict__ cls_pl, const fl
     f32x4 l;
 #pragma unroll
     for (int c = 0; c < 4; ++c) l[c] = cb[(size_t)(c * A + a) * HW + p];
-    const float mx = fmaxf(fmaxf(l[0], l[1]), fmaxf(l[2], l[3]));
-    f32x4 e;
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { e[c] = expf(l[c] - mx); s += e[c]; }
-    f32x4 pr;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) pr[c] = e[c] / s;
+    const f32x4 pr = class_softmax4(l);
     const size_t o = (size_t)b * R + row;
     *reinterpret_cast<f32x4 *>(cls + o * 4) = l;
     *reinterpret_cast<f32x4 *>(prob + o * 4) = pr;
@@ -515,8 +502,7 @@ __global__ void bundle_outputs_kernel(const float *__restrict__ cls_pl, const fl
 #pragma unroll
     for (int k = 0; k < 7; ++k) b3[o * 7 + k] = bb[(size_t)(4 + k) * R];
     if (key) {
-        const float sc = fmaxf(fmaxf(pr[1], pr[2]), pr[3]);
-        key[o] = f32_sortable(sc);
+        key[o] = f32_sortable(fg_score(pr));
     }
 }
 
@@ -531,3 +517,39 @@ extern "C" int m3d_bundle_outputs(const float *cls_planar, const float *box_plan
     return M3D_OK;
 }
 
+// The sort keys alone, straight from the planar class logits: what the detection stage needs of the 38 MB per image that
+// bundle_outputs moves when nobody reads cls / prob / bbox_2d / bbox_3d in full (m3dssd_amd.pipeline.PipelinedDetector:
+// m3d_topk_decode_planar decodes its 3000 rows from the planar staging).  Same softmax arithmetic as bundle_outputs_kernel
+// (class_softmax4, common.h), so the keys are the same bits.  4 consecutive rows per thread: 16-byte loads / stores.
+__global__ void score_keys_planar_kernel(const float *__restrict__ cls_pl, unsigned int *__restrict__ key, int A, int HW)
+{
+    const int b = blockIdx.y;
+    const int R = A * HW;
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (row >= R) return;
+    const int a = row / HW, p = row - a * HW;                  // HW % 4 == 0: the four rows share the anchor
+    const float *cb = cls_pl + (size_t)b * 4 * R;
+    f32x4 lc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lc[c] = *reinterpret_cast<const f32x4 *>(cb + (size_t)(c * A + a) * HW + p);
+    u32x4 k;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f32x4 l;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) l[c] = lc[c][e];
+        k[e] = f32_sortable(fg_score(class_softmax4(l)));
+    }
+    *reinterpret_cast<u32x4 *>(key + (size_t)b * R + row) = k;
+}
+
+extern "C" int m3d_score_keys_planar(const float *cls_planar, unsigned int *score_bits, int B, int A, int HW, m3d_stream_t stream)
+{
+    M3D_REQUIRE(cls_planar && score_bits && B >= 1 && A >= 1 && HW >= 4, "score_keys_planar: bad arguments");
+    M3D_REQUIRE(HW % 4 == 0 && ((uintptr_t)cls_planar & 15) == 0 && ((uintptr_t)score_bits & 15) == 0,
+                "score_keys_planar: HW (%d) must be a multiple of 4 and the buffers 16-byte aligned", HW);
+    hipLaunchKernelGGL(score_keys_planar_kernel, dim3(cdiv((long long)A * HW / 4, 256), B), dim3(256), 0, (hipStream_t)stream,
+                       cls_planar, score_bits, A, HW);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}

@@ -425,6 +425,9 @@ class EngineBF16(Engine):
         box_pl = torch.empty(B * 11 * A * HW, device=self.device, dtype=torch.float32)
         plan.keep += [cls_pl, box_pl]
         plan.named["cls_planar"], plan.named["box_planar"] = cls_pl, box_pl
+        # every op from here on may write the planar staging: a detection stage that reads it for the PREVIOUS batch
+        # (m3dssd_amd.pipeline.PipelinedDetector, planar form) has to be done before op `planar_first_op` of this one starts
+        plan.named["planar_first_op"] = len(plan.ops)
 
         def stacked(names, li):
             key = "stack:" + "+".join(names) + li

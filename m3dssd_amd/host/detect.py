@@ -72,6 +72,44 @@ def detect_from_outputs(eng, plan, prob, bbox_2d, bbox_3d, rois, conf, scale=Non
     return aboxes, keep, num
 
 
+def detect_from_planar(eng, plan, rois, conf, scale=None):
+    """detect_from_outputs without the bundled tensors: the sort keys come from ``m3d_score_keys_planar`` (run behind the forward
+    in place of ``m3d_bundle_outputs``) and the top-N-pre rows are decoded straight from the planar staging the heads write
+    (``m3d_topk_decode_planar``).  Same rows, same bits (tests/test_gpu_detect.py); 5.5 MB per image instead of 38."""
+    L = _hip.lib()
+    cls_pl, box_pl, bits = plan.named["cls_planar"], plan.named["box_planar"], plan.named["score_bits"]
+    dev = bits.device
+    B, R = bits.shape[0], bits.shape[1]
+    A = eng.A
+    HW = R // A
+    n_pre = min(int(conf.nms_topN_pre), R)
+    P = eng.P
+    with torch.cuda.device(dev):
+        st = _stream(dev)
+        aboxes = torch.empty(B, n_pre, 14, device=dev, dtype=torch.float32)
+        keep = torch.empty(B, n_pre, device=dev, dtype=torch.int32)
+        num = torch.empty(B, device=dev, dtype=torch.int32)
+        tk_bytes = L.m3d_topk_decode_workspace_bytes(B, R)
+        ws = torch.empty(max(tk_bytes, L.m3d_nms_workspace_bytes(B, n_pre)), device=dev, dtype=torch.uint8)
+        _hip.check(L.m3d_topk_decode_planar(bits.data_ptr(), cls_pl.data_ptr(), box_pl.data_ptr(), rois.data_ptr(),
+                                            P["anchors"].data_ptr(), P["means"].data_ptr(), P["stds"].data_ptr(),
+                                            None if scale is None else scale.data_ptr(), aboxes.data_ptr(), None, ws.data_ptr(),
+                                            tk_bytes, B, A, HW, n_pre, st))
+        _hip.check(L.m3d_nms_sorted_dev(aboxes.data_ptr(), B, n_pre, 14, float(conf.nms_thres), ws.data_ptr(),
+                                        keep.data_ptr(), num.data_ptr(), st))
+    return aboxes, keep, num
+
+
+def score_keys_planar(eng, plan):
+    """The launch that replaces bundle_outputs when only the detection stage follows: sort keys from the planar class logits."""
+    bits = plan.named["score_bits"]
+    B, R = bits.shape[0], bits.shape[1]
+    dev = bits.device
+    with torch.cuda.device(dev):
+        _hip.check(_hip.lib().m3d_score_keys_planar(plan.named["cls_planar"].data_ptr(), bits.data_ptr(), B, eng.A, R // eng.A,
+                                                    _stream(dev)))
+
+
 def detect_device(net, im, conf, top_post=None, scale=None):
     """-> (aboxes [B, n_pre, 14] score-sorted, keep [B, n_pre] int32 positions, num_keep [B] int32), device tensors.
     scale: test-time scale factor(s) of the frames (float, [B] floats or tensor): applied before the NMS."""

@@ -82,7 +82,8 @@ class RPN(nn.Module):
     #     through child._load_from_state_dict and never calls the child's load_state_dict, so the invalidation hangs on
     #     _load_from_state_dict of every sub-module via a load_state_dict post-hook registered in __init__;
     #   * .to / .cuda / .float (through _apply).
-    # Code that writes parameter storage IN PLACE (p.data.copy_, optimiser steps) calls refresh_engine() itself -- hashing
+    # Code that writes parameter storage IN PLACE (p.data.copy_, optimiser steps) calls refresh_engine() itself (on the SOURCE
+    # module: it also drops the per-device engines that DataParallel replicas use) -- hashing
     # ~540 (data_ptr, _version) pairs on every forward cost 0.3 ms of host time per call; M3D_CHECK_PARAMS=1 turns that full
     # check on for debugging (forward then raises on a stale packing instead of using it).
     def refresh_engine(self):
@@ -132,16 +133,23 @@ class RPN(nn.Module):
             return self.engine()
         cache = self.__dict__.setdefault("_device_engines", {})
         key = (str(dev), self.compute_dtype)
+        check = os.environ.get("M3D_CHECK_PARAMS", "0") == "1"
+        if key in cache and check and cache[key][1] != self._signature():
+            # the reference's DataParallel re-broadcasts the parameters on every forward; a replica engine packed from an older
+            # state of the source's parameters would silently keep using it
+            raise RuntimeError("RPN: parameters changed in place since the replica engine on %s packed them; call "
+                               "net.refresh_engine() on the source module" % (dev,))
         if key not in cache:
             if dev.type != "cuda":
                 raise NotImplementedError("RPN.forward runs on a ROCm device only (replica on %s)" % (dev,))
             sd = {k: v.to(dev) for k, v in self.state_dict().items()}
             if self.compute_dtype == "bf16":
                 from ..engine_bf16 import EngineBF16
-                cache[key] = EngineBF16(sd, self._conf, device=dev)
+                eng = EngineBF16(sd, self._conf, device=dev)
             else:
-                cache[key] = Engine(sd, self._conf, device=dev)
-        return cache[key]
+                eng = Engine(sd, self._conf, device=dev)
+            cache[key] = (eng, self._signature() if check else None)
+        return cache[key][0]
 
     def _signature(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters()) + \

@@ -4,12 +4,18 @@ The post-forward stage (64-bit-key top-k, decode, NMS, row selection -- lib/rpn_
 is latency-bound and leaves the chip mostly idle for ~0.35 ms per batch.  ``PipelinedDetector`` overlaps it with
 the forward of the NEXT batch: one captured hipGraph per input shape whose two branches are
 
-    branch A (main stream):  forward(batch k)  [all launches except the final output bundling]
-    branch B (side stream):  detect(batch k-1) on the output buffers written by the previous replay
-    join, then bundle_outputs(batch k)  -> the output buffers branch B of the next replay will read
+    branch A (main stream):  forward(batch k)  [the launches in front of the first head that writes the planar staging]
+    branch B (side stream):  detect(batch k-1) on the planar head outputs + sort keys the previous replay left
+    join, then the heads of batch k and ``m3d_score_keys_planar`` -> what branch B of the next replay will read
 
 so each ``step(x)`` returns the detections of the PREVIOUS batch (one batch of pipeline latency) and ``flush()``
-drains the last one.  Results are identical to ``lib.rpn_util.detect_batch`` (tests/test_gpu_parity.py).
+drains the last one.  Results are identical to ``lib.rpn_util.detect_batch`` (tests/test_gpu_detect.py).
+
+The detection stage needs 3000 decoded rows per image, not the bundled ``cls / prob / bbox_2d / bbox_3d`` tensors
+(M3d_inference_align.py:280-301: 38 MB per image written and read back, 2.5 GB per step at bs = 64): ``planar=True`` (default)
+replaces ``m3d_bundle_outputs`` by the key-only pass and decodes from the planar staging (``m3d_topk_decode_planar``, same
+bits); ``planar=False`` (or M3D_PIPE_PLANAR=0) is the bundled form: detect(k-1) beside forward(k), join, bundle(k).  In the
+planar form ``plan.named["prob" / "bbox_2d" / "bbox_3d" / "cls"]`` are NOT written by a replay.
 
 ``u8_frame=(h, w)`` is the fed-input form (the reference pays ``im.cuda()`` per frame, lib/rpn_util.py:1427-1429,
 and preprocesses on the host, lib/dataloader.py:934-950, lib/augmentations.py:472-501): raw uint8 BGR frames [B, h, w, 3] sit in
@@ -26,19 +32,21 @@ scale, clipping, alpha -> ry, hill climbing, back-projection; ``m3d_refine_3d_ex
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
 
 from . import _hip
-from .host.detect import detect_from_outputs, select_block
+from .host.detect import detect_from_outputs, detect_from_planar, score_keys_planar, select_block
 from .host.refine import p2_arrays
 
 
 class PipelinedDetector:
     def __init__(self, net, conf, batch, height, width, refine=False, score_thresh=0.75, step_r_init=0.3 * math.pi, r_lim=0.01,
-                 u8_frame=None):
+                 u8_frame=None, planar=None):
         self.net, self.conf = net, conf
+        self.planar = (os.environ.get("M3D_PIPE_PLANAR", "1") != "0") if planar is None else bool(planar)
         self.u8_frame = None if u8_frame is None else (int(u8_frame[0]), int(u8_frame[1]))
         self.refine = bool(refine)
         self._rargs = (float(score_thresh), 1 if bool(getattr(conf, "hill_climbing", True)) else 0, float(step_r_init), float(r_lim))
@@ -67,9 +75,12 @@ class PipelinedDetector:
             self._cur = 0                                              # buffer the next submitted batch is read from
             self._primed = False                                       # buffer _cur holds the head of the queue
             self._inflight = [None, None]                              # frames a replay of graph i is uploading (kept alive)
+            self._prime_ev = None                                      # behind feed()'s own copy of a batch nothing in flight uploads
         self.n_fwd = len(self.plan.ops) - 1
         assert self.plan.ops[-1][0] == "bundle_outputs"
         n = self.plan.named
+        # planar form: the side branch must be done before the first launch that overwrites the planar staging
+        self.n_join = int(n["planar_first_op"]) if self.planar else self.n_fwd
         self._outs = (n["prob"], n["bbox_2d"], n["bbox_3d"])
         self._rois = net.rois.to(dev)
         self._pending = False
@@ -89,8 +100,12 @@ class PipelinedDetector:
         prob, b2, b3 = self._outs
         # refine mode carries the frames' test-time scale factors: the boxes are divided by them inside the decode, before the NMS
         # (lib/rpn_util.py:1504-1506), not in the refinement behind it
-        block, counts = select_block(*detect_from_outputs(self.eng, self.plan, prob, b2, b3, self._rois, self.conf,
-                                                          self._scale if self.refine else None), self.conf)
+        scale = self._scale if self.refine else None
+        if self.planar:
+            rows = detect_from_planar(self.eng, self.plan, self._rois, self.conf, scale)
+        else:
+            rows = detect_from_outputs(self.eng, self.plan, prob, b2, b3, self._rois, self.conf, scale)
+        block, counts = select_block(*rows, self.conf)
         if not self.refine:
             return block, counts, None
         B, K1, _ = block.shape                          # K1 = kept rows + the count row (past counts[b]: refined to zeros)
@@ -113,6 +128,15 @@ class PipelinedDetector:
         finally:
             self.plan.named["input_u8"][0] = 0
 
+    def _finish(self, buf=0):
+        """The launches behind the join: the rest of the forward, then the key-only pass (planar) or the output bundling."""
+        if self.planar:
+            if self.n_join < self.n_fwd:
+                self._forward(self.n_join, self.n_fwd, buf)
+            score_keys_planar(self.eng, self.plan)
+        else:
+            self._forward(self.n_join, None, buf)
+
     def _capture_step(self, cap, side, buf):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=cap):
@@ -123,17 +147,18 @@ class PipelinedDetector:
                     _hip.check(_hip.lib().m3d_upload_indirect(
                         ctypes.c_void_p(self._slots.data_ptr() + 8 * buf), ctypes.c_void_p(self._u8_flat[buf ^ 1].data_ptr()),
                         self._u8_bytes, ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
-            self._forward(0, self.n_fwd, buf)        # batch k, everything but the bundling
+            self._forward(0, self.n_join, buf)       # batch k, everything in front of the first write of what the side branch reads
             cap.wait_stream(side)                    # join: outputs may now be overwritten
-            self._forward(self.n_fwd, None, buf)
+            self._finish(buf)
         return g, outs
 
     def _build(self):
         cap, side = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
         cap.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(cap), torch.no_grad():
-            self._forward(0, None)                       # warm-up outside capture: plan buffers, allocator pools,
-            self._detect()                               # kernel attributes, zero page
+            self._forward(0, self.n_join)                # warm-up outside capture: plan buffers, allocator pools,
+            self._finish()                               # kernel attributes, zero page
+            self._detect()
             torch.cuda.synchronize(self.dev)
             self.graph, (self._block, self._counts, self._refined) = self._capture_step(cap, side, 0)
             if self.u8_frame is not None:                # second input buffer: its own graph, its own result tensors
@@ -164,8 +189,11 @@ class PipelinedDetector:
     # ---- fed-input form ---------------------------------------------------------------------------------------------------------
     def feed(self, frames):
         """Queue one batch of uint8 BGR frames [B, h, w, 3] in PINNED host memory (a device tensor works too).  Nothing is copied
-        here: the graph of the batch submitted BEFORE this one uploads it (the first batch is uploaded right away).  The tensor
-        must stay unchanged until the step_fed() that submits it has been called.  At most two batches can be queued."""
+        here: the graph of the batch submitted BEFORE this one uploads it (the first batch is uploaded right away) -- an
+        asynchronous read of this tensor.  The tensor must stay unchanged until the step_fed() that SUBMITS it has returned:
+        that call waits (on the host, behind its own replay launch, so the device never idles) for the replay / copy that
+        uploaded the batch.  A ring of two pinned buffers written in the order feed, step_fed, feed, step_fed, ... is therefore
+        safe.  At most two batches can be queued."""
         if self.u8_frame is None:
             raise RuntimeError("feed() needs PipelinedDetector(..., u8_frame=(h, w))")
         if len(self._queue) >= 2:
@@ -178,6 +206,8 @@ class PipelinedDetector:
         self._queue.append(frames)
         if not self._primed:                                     # nothing in flight names this batch: upload it now
             self.inputs_u8[self._cur].copy_(frames, non_blocking=True)
+            self._prime_ev = torch.cuda.Event()                  # the copy reads the pinned tensor asynchronously
+            self._prime_ev.record(torch.cuda.current_stream(self.dev))
             self._primed = True
 
     def step_fed(self, as_block=False):
@@ -197,6 +227,15 @@ class PipelinedDetector:
         had = self._pending
         self._graphs[i].replay()
         self._done[i].record(main)
+        # The batch submitted here was uploaded by the PREVIOUS replay (graph i ^ 1, side branch) or by feed()'s own copy: wait
+        # for that read of the caller's pinned tensor -- behind this replay's launch, so one replay is always queued on the
+        # device -- and the documented lifetime ("unchanged until the step_fed() that submits it has returned") holds for a
+        # two-deep ring as well (_done[i] above is two replays back and did not cover it).
+        if self._used[i ^ 1]:
+            self._done[i ^ 1].synchronize()
+        if self._prime_ev is not None:
+            self._prime_ev.synchronize()
+            self._prime_ev = None
         self._used[i] = True
         self._pending = True
         self._cur ^= 1

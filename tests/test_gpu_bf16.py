@@ -20,13 +20,27 @@ from m3dssd_amd import synth
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BF16 = torch.bfloat16
-# What the bf16 path meets against the fp32 oracle (normalised regression outputs, all rows, all 7 / 4 box parameters), see
-# typical error = bf16 rounding accumulated through ~50 layers (rms ~1e-2); the L-inf sits at isolated pixels where the
-# noisy centre predictions move an alignment sampling position (center_align resamples the map at predicted offsets).
+# What the bf16 path meets against the fp32 oracle (normalised regression outputs = what the heads write, before exp() / anchor
+# scaling), per output COLUMN, with the engine's discrete decisions injected into the oracle.  The typical error is bf16 rounding
+# accumulated through ~50 layers; the L-inf sits at isolated pixels where the noisy centre predictions move a center_align
+# sampling position (feturealign_mgpu.py:58-89) -- which is why the columns behind center_align2d (w, h) carry the largest maxima.
+# Every bound = 1.3 x the value MEASURED at 1280x384 (gpurun_out/parity_r05.jsonl, tests "bf16_network" / "bf16_configs2_slice"; the
+# measured values are in BF16_MEASURED for the record), so a 1.3x regression of any column fails (round 4 had one
+# max bound of 2.0 for all columns against 0.77 / 0.21 measured).
+BF16_COLS = {"bbox_2d": ("x", "y", "w", "h"), "bbox_3d": ("x3d", "y3d", "z3d", "w3d", "h3d", "l3d", "rY3d")}
+BF16_MEASURED = {      # (max, p99.9, rms) per column at 1280x384, 2 frames (seed 1234, right third zero-padded)
+    "bbox_2d": {"x": (0.0349, 0.0138, 0.0030), "y": (0.0281, 0.0124, 0.0027), "w": (0.547, 0.106, 0.0128), "h": (0.770, 0.118, 0.0140)},
+    "bbox_3d": {"x3d": (0.0256, 0.0123, 0.0027), "y3d": (0.0310, 0.0133, 0.0029), "z3d": (0.169, 0.0215, 0.0124),
+                "w3d": (0.136, 0.0178, 0.0079), "h3d": (0.146, 0.0170, 0.0068), "l3d": (0.206, 0.0210, 0.0100), "rY3d": (0.166, 0.0202, 0.0091)},
+}
+BF16_GUARD = 1.3
+BF16_PROB_TOL = 0.05
+BF16_PROB_MEASURED = 0.0203           # max |prob - oracle| at 1280x384
+BF16_FLIP_RATE_MEASURED = 193 / 15360  # top-1 anchor decisions that differ from the free-running fp32 oracle's (1.26 %)
+# aggregate bounds kept for the A/B-plan comparison test (two bf16 plans against each other: both sides carry the error)
 BF16_BBOX_RMS_TOL = 0.03
 BF16_BBOX_P999_TOL = 0.2
 BF16_BBOX_MAX_TOL = 2.0
-BF16_PROB_TOL = 0.05
 
 
 def _dev():
@@ -37,7 +51,7 @@ def _dev():
 def _log(name, payload):
     d = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(d):
-        with open(os.path.join(d, "parity_r04.jsonl"), "a") as f:
+        with open(os.path.join(d, "parity_r05.jsonl"), "a") as f:
             f.write(json.dumps({"test": name, **payload}) + "\n")
 
 
@@ -737,53 +751,115 @@ def _net(crop, B, dtype):
     return net.to(_dev()).set_compute_dtype(dtype), conf
 
 
-@pytest.mark.parametrize("crop,B,pad", [((128, 320), 2, False), ((384, 1280), 2, True)])
-def test_bf16_network_matches_fp32_oracle_within_stated_tolerance(crop, B, pad):
-    """bf16 engine vs the fp32 CPU oracle, the engine's discrete decisions (top-1 anchor, hard mask) injected into the
-    oracle.  Reports the L-inf of every output and of the stage taps; asserts the stated bf16 tolerance."""
+def _bf16_vs_oracle(net, plan, x, outs, rows, crop):
+    """Engine outputs `outs` = (cls, prob, bbox_2d, bbox_3d) of the frames `rows` of the plan's batch (CPU tensors) against the fp32
+    CPU oracle on those frames `x`, the engine's top-1 anchor / hard-mask decisions injected -> report dict."""
     from oracle import model_cpu
-    net, conf = _net(crop, B, "bf16")
     sd = synth.synth_state_dict(0)
-    x = synth.synth_frames(B, crop, 1234, pad_right_third=pad)
-    with torch.no_grad():
-        cls, prob, b2, b3 = (t.cpu() for t in net(x.to(_dev()))[:4])
-    eng = net.engine()
-    assert type(eng).__name__ == "EngineBF16"
-    plan = eng.plan_for(B, *crop)
-    assert all(not k[1].startswith(("igemm", "wino", "conv_wave", "head_mlp")) for k in plan.ops), "fp32 MFMA kernel in the bf16 plan"
+    n = len(rows)
     fh, fw = crop[0] // 8, crop[1] // 8
-    ind = plan.named["sel_idx"].view(B, 1, fh, fw).long().cpu()
-    prob_sel = plan.named["sel_prob"].view(B, 1, fh, fw).cpu()
-    cconf = synth.synth_conf(crop, 0, batch_size=B, device="cpu")
+    ind = plan.named["sel_idx"].view(-1, 1, fh, fw)[rows].long().cpu()
+    prob_sel = plan.named["sel_prob"].view(-1, 1, fh, fw)[rows].cpu()
+    cconf = synth.synth_conf(crop, 0, batch_size=n, device="cpu")
     taps, taps_free = {}, {}
     with torch.no_grad():
         free = model_cpu.rpn_forward(sd, cconf, x, taps_free)
         inj = model_cpu.rpn_forward(sd, cconf, x, taps, inject={"sel": {"ind": ind, "hard": (prob_sel > 0.5).float()}})
+    cls, prob, b2, b3 = outs
     fg = taps_free["fg_prob"]
     o_mask, o_ind = fg.max(dim=1, keepdim=True)
-    n_idx, n_flip = int((o_ind != ind).sum()), int(((o_mask > 0.5) != (prob_sel > 0.5)).sum())
-    rep = {"crop": list(crop), "B": B, "n_idx": n_idx, "n_flip": n_flip, "pixels": int(ind.numel())}
+    diff = o_ind != ind
+    rep = {"crop": list(crop), "frames": n, "n_idx": int(diff.sum()), "n_flip": int(((o_mask > 0.5) != (prob_sel > 0.5)).sum()),
+           "pixels": int(ind.numel())}
+    rep["flip_rate"] = rep["n_idx"] / rep["pixels"]
+    # the oracle's own margin at the pixels where the engine chose another anchor (all inside the probability tolerance)
+    rep["flip_margin_max"] = (o_mask - torch.gather(fg, 1, ind))[diff].abs().max().item() if diff.any() else 0.0
     for name in ("level2", "level5", "feats0", "feats", "feats_align2d", "feats_align3d", "feats_gl"):
-        got = plan.named[name].torch_nchw().cpu()
+        got = plan.named[name].torch_nchw()[rows].cpu()
         ref = (taps_free if name in ("level2", "level5", "feats0") else taps)[name]
         rep["rel_" + name] = ((got - ref).abs().max() / ref.abs().max()).item()
     rep["cls"] = (cls - free[0]).abs().max().item()
     rep["prob"] = (prob - inj[1]).abs().max().item()
     for nm, got, ref in (("bbox_2d", b2, inj[2]), ("bbox_3d", b3, inj[3])):
-        e = (got - ref).abs()
+        e = (got - ref).abs().view(-1, got.shape[-1])
         rep[nm] = e.max().item()
-        rep[nm + "_rms"] = e.pow(2).mean().sqrt().item()
-        rep[nm + "_p999"] = torch.quantile(e.flatten()[::7].float(), 0.999).item()
-        rep[nm + "_cols"] = [v.item() for v in e.view(-1, e.shape[-1]).max(0)[0]]
-    _log("bf16_network", rep)
+        rep[nm + "_cols"] = {c: [e[:, j].max().item(), torch.quantile(e[:, j][::3].float(), 0.999).item(),
+                                 e[:, j].pow(2).mean().sqrt().item()] for j, c in enumerate(BF16_COLS[nm])}
     assert torch.isfinite(b3).all() and torch.isfinite(cls).all()
-    assert rep["prob"] < BF16_PROB_TOL, rep
-    for nm in ("bbox_2d", "bbox_3d"):
-        assert rep[nm + "_rms"] < BF16_BBOX_RMS_TOL and rep[nm + "_p999"] < BF16_BBOX_P999_TOL and rep[nm] < BF16_BBOX_MAX_TOL, rep
-    # the decisions differ from the fp32 oracle's only where its margins are within bf16 noise
-    diff = o_ind != ind
-    if diff.any():
-        assert ((o_mask - torch.gather(fg, 1, ind))[diff].abs() < BF16_PROB_TOL).all()
+    return rep
+
+
+def _assert_bf16_report(rep, full_size):
+    """The per-column bounds (1.3 x measured) hold at the size they were measured at; smaller maps are looser by construction (fewer
+    rows for the maxima) and are held to the same table."""
+    assert rep["prob"] < BF16_PROB_TOL and rep["prob"] <= BF16_GUARD * BF16_PROB_MEASURED + (0.0 if full_size else 0.01), rep
+    for nm, cols in BF16_COLS.items():
+        for c in cols:
+            mx, p999, rms = rep[nm + "_cols"][c]
+            tmx, tp, tr = (BF16_GUARD * v for v in BF16_MEASURED[nm][c])
+            assert mx <= tmx and p999 <= tp and rms <= tr, (nm, c, (mx, p999, rms), (tmx, tp, tr))
+    # decisions differ from the free-running fp32 oracle's only where its own margin is within bf16 noise, and not more often
+    # than measured (x 1.3; the small map has 1280 pixels: its rate is noisier and gets the absolute slack of 10 pixels)
+    assert rep["flip_margin_max"] < BF16_PROB_TOL, rep
+    assert rep["n_idx"] <= BF16_GUARD * BF16_FLIP_RATE_MEASURED * rep["pixels"] + (0 if full_size else 10), rep
+
+
+@pytest.mark.parametrize("crop,B,pad", [((128, 320), 2, False), ((384, 1280), 2, True)])
+def test_bf16_network_matches_fp32_oracle_within_stated_tolerance(crop, B, pad):
+    """bf16 engine vs the fp32 CPU oracle, the engine's discrete decisions (top-1 anchor, hard mask) injected into the
+    oracle.  Logs max / p99.9 / rms of every output column, the stage taps and the top-1-anchor flip rate; asserts the per-column
+    bounds (1.3 x measured)."""
+    net, conf = _net(crop, B, "bf16")
+    x = synth.synth_frames(B, crop, 1234, pad_right_third=pad)
+    with torch.no_grad():
+        outs = [t.cpu() for t in net(x.to(_dev()))[:4]]
+    eng = net.engine()
+    assert type(eng).__name__ == "EngineBF16"
+    plan = eng.plan_for(B, *crop)
+    assert all(not k[1].startswith(("igemm", "wino", "conv_wave", "head_mlp")) for k in plan.ops), "fp32 MFMA kernel in the bf16 plan"
+    rep = _bf16_vs_oracle(net, plan, x, outs, list(range(B)), crop)
+    # What an fp32 last class layer would buy (VERDICT r4 #2 "consider keeping the cls head's last 1x1 and the softmax in fp32"):
+    # recompute cls.6 in fp32 (torch, fp32 weights) from the engine's bf16 hidden map and count the top-1 decisions that still differ
+    # from the free-running oracle's.  The softmax / fg_prob / top-1 already run in fp32 on fp32 logits (m3d_anchor_select).
+    sd = synth.synth_state_dict(0)
+    c2 = [op for op in plan.ops if op[0] == "cls.6"][0][4]
+    fh, fw = crop[0] // 8, crop[1] // 8
+    hidden = None                        # the plan-owned bf16 buffer cls.6 reads (256 channels per pixel)
+    for t in plan.keep:
+        if torch.is_tensor(t) and t.data_ptr() == c2.inp:
+            hidden = t
+    if hidden is not None:
+        h = hidden.view(B, fh, fw, 256).float().permute(0, 3, 1, 2)
+        logits = F.conv2d(h, sd["cls.6.weight"].to(_dev()).float(), sd["cls.6.bias"].to(_dev()).float())
+        A = eng.A
+        pr = torch.softmax(logits.view(B, 4, A * fh, fw), dim=1)
+        fg32 = (1 - pr[:, 0]).view(B, A, fh, fw)
+        ind32 = fg32.max(dim=1, keepdim=True)[1].cpu()
+        from oracle import model_cpu
+        cconf = synth.synth_conf(crop, 0, batch_size=B, device="cpu")
+        tf = {}
+        with torch.no_grad():
+            model_cpu.rpn_forward(sd, cconf, x, tf)
+        o_ind = tf["fg_prob"].max(dim=1, keepdim=True)[1]
+        rep["n_idx_with_fp32_cls6"] = int((o_ind != ind32).sum())
+    _log("bf16_network", rep)
+    _assert_bf16_report(rep, full_size=(crop == (384, 1280)))
+
+
+def test_bf16_configs2_batch64_matches_fp32_oracle_on_a_slice():
+    """BASELINE.json configs[2] AT ITS OWN SIZE (bs = 64, 1280x384, the plan the bench times): frames 0, 21, 42, 63 of the batch
+    against the fp32 CPU oracle run on those four frames (engine decisions injected), same per-column bounds as the 2-frame test."""
+    crop, B = (384, 1280), 64
+    net, conf = _net(crop, B, "bf16")
+    x = synth.synth_frames(B, crop, 1234)
+    rows = [0, 21, 42, 63]
+    with torch.no_grad():
+        outs = [t[rows].cpu() for t in net(x.to(_dev()))[:4]]
+    plan = net.engine().plan_for(B, *crop)
+    rep = _bf16_vs_oracle(net, plan, x[rows], outs, rows, crop)
+    rep["batch"] = B
+    _log("bf16_configs2_slice", rep)
+    _assert_bf16_report(rep, full_size=True)
 
 
 # What the bf16 path means for the DECODED boxes (pixels / metres / radians), measured on the rows the fp32 oracle keeps: the

@@ -59,3 +59,19 @@ amdhsa.kernels:
     _, spills = chk.scan(meta)
     assert spills == [("_Z13wino44_kernelILi1ELi2ELi1EEv10Wino44Args", 20), ("_Z15refine3d_kernel10RefineArgs", 496)]
     assert any(h in spills[0][0] for h in chk.HAND_COUNTED) and not any(h in spills[1][0] for h in chk.HAND_COUNTED)
+
+
+def test_back_edge_and_swap_destinations_are_followed():
+    """a 16-byte global store at the end of a loop body whose back edge leads to a write of its data registers (one wait
+    state: the branch) must be flagged; so must a v_swap that writes a data register as its SECOND operand."""
+    loop = ("k:\n.LBB0_1:\n\tv_mov_b32_e32 v2, 0\n\tv_add_u32_e32 v9, 1, v9\n\tglobal_store_dwordx4 v[16:17], v[0:3], off\n"
+            "\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n")
+    f, _ = chk.scan(loop)
+    assert len(f) == 1 and f[0][4] == 1 and f[0][5] == 2 and "v_mov_b32_e32 v2" in f[0][3]
+    padded = loop.replace("\ts_cbranch_scc1", "\ts_nop 1\n\ts_cbranch_scc1")
+    assert chk.scan(padded)[0] == []
+    uncond = ("k:\n\tglobal_store_dwordx4 v[16:17], v[0:3], off\n\ts_branch .LBB0_2\n\tv_mov_b32_e32 v1, 0\n.LBB0_2:\n"
+              "\tv_mov_b32_e32 v9, 0\n\ts_endpgm\n")
+    assert chk.scan(uncond)[0] == []                    # the write behind an unconditional branch is not on the path
+    swap = "k:\n\tglobal_store_dwordx4 v[16:17], v[0:3], off\n\tv_swap_b32 v20, v3\n\ts_endpgm\n"
+    assert len(chk.scan(swap)[0]) == 1

@@ -58,20 +58,68 @@ def store_info(line):
     return data, need
 
 
+DUAL_DST = ("v_swap_b32", "v_swap_b16", "v_permlane16_swap", "v_permlane32_swap")     # write BOTH of their first two operands
+
+
 def valu_dst(line):
-    """registers written by a VALU instruction (first operand), else empty."""
+    """registers written by a VALU instruction (first operand; both operands of the swap forms), else empty."""
     s = line.strip()
     if not s.startswith("v_") or s.startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
         return set()
     ops = s.split(None, 1)
     if len(ops) < 2:
         return set()
-    return regs_of(ops[1].split(",")[0])
+    parts = ops[1].split(",")
+    out = regs_of(parts[0])
+    if ops[0].startswith(DUAL_DST) and len(parts) > 1:
+        out |= regs_of(parts[1])
+    return out
+
+
+BRANCH = re.compile(r"^(s_branch|s_cbranch_\w+)\s+(\S+)")
 
 
 def scan(asm_text):
     findings, kernel = [], None
     lines = asm_text.splitlines()
+    labels = {}
+    for i, raw in enumerate(lines):
+        m = re.match(r"^([A-Za-z_.$][\w$.]*):", raw.split(";")[0].rstrip())
+        if m:
+            labels[m.group(1)] = i
+
+    def walk(start, waited, need, data, seen):
+        """First VALU write of `data` reachable from line `start` within the hazard window, following BOTH arms of a branch (a
+        16-byte store at the end of a loop body followed by the back edge to a write of its data registers is the case the
+        fall-through-only scan of round 4 missed) -> (instruction text, wait states seen) or None."""
+        j = start
+        while waited < need and j < len(lines):
+            if (j, waited) in seen:
+                return None
+            seen.add((j, waited))
+            nxt = lines[j].split(";")[0].strip()
+            j += 1
+            if not nxt or nxt.startswith((".", ";")) or nxt.endswith(":"):
+                continue
+            if valu_dst(nxt) & data:
+                return nxt, waited
+            if nxt.startswith("s_endpgm"):
+                return None
+            b = BRANCH.match(nxt)
+            if b:
+                waited += 1                                   # the branch itself is one wait state
+                tgt = labels.get(b.group(2))
+                if tgt is not None and waited < need:
+                    hit = walk(tgt, waited, need, data, seen)
+                    if hit:
+                        return hit
+                if b.group(1) == "s_branch":
+                    return None                               # unconditional: no fall-through
+                continue
+            m = re.match(r"^s_nop\s+(\d+)", nxt)
+            waited += int(m.group(1)) + 1 if m else 1
+        return None
+
     for i, raw in enumerate(lines):
         line = raw.split(";")[0].rstrip()
         m = re.match(r"^([A-Za-z_][\w$.]*):", line)
@@ -81,18 +129,9 @@ def scan(asm_text):
         if not si:
             continue
         data, need = si
-        waited, j = 0, i + 1
-        while waited < need and j < len(lines):
-            nxt = lines[j].split(";")[0].strip()
-            j += 1
-            if not nxt or nxt.startswith((".", ";")) or nxt.endswith(":"):
-                continue
-            hit = valu_dst(nxt) & data
-            if hit:
-                findings.append((kernel, i + 1, line.strip(), nxt, waited, need))
-                break
-            m = re.match(r"^s_nop\s+(\d+)", nxt)
-            waited += int(m.group(1)) + 1 if m else 1
+        hit = walk(i + 1, 0, need, data, set())
+        if hit:
+            findings.append((kernel, i + 1, line.strip(), hit[0], hit[1], need))
     # scratch per kernel from the metadata block (keys of an entry come in alphabetical order: .name ... .symbol)
     spills = []
     cur = {}
@@ -110,8 +149,11 @@ def scan(asm_text):
 def device_asm(src):
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "dev.s")
-        subprocess.run([HIPCC] + FLAGS + ["--cuda-device-only", "-S", src, "-o", out], check=True, stdout=subprocess.DEVNULL,
-                       stderr=subprocess.DEVNULL)
+        res = subprocess.run([HIPCC] + FLAGS + ["--cuda-device-only", "-S", src, "-o", out], stdout=subprocess.DEVNULL,
+                             stderr=subprocess.PIPE, text=True)
+        if res.returncode != 0:
+            sys.stderr.write(res.stderr)
+            raise RuntimeError("check_isa_hazards: hipcc failed on %s (exit code %d)" % (src, res.returncode))
         return open(out).read()
 
 

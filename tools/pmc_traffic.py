@@ -72,7 +72,15 @@ def main(d, out, launches=None):
         if k in w:
             res[k] = {"launches": nf[k], "fetch_kib_raw": round(f[k], 1), "write_kib": round(w[k], 1),
                       "hbm_bytes_per_launch": int((2.0 * f[k] + w[k]) * 1024)}
-    json.dump({"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs of "
+    csrc_files = None
+    try:                               # the library that just ran under rocprofv3 (this script runs on the GPU box right behind the passes)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from m3dssd_amd import _hip
+        csrc_files = _hip.lib_source_hashes()
+    except Exception as e:             # noqa: BLE001
+        print("pmc_traffic: no source record of the library (%s): bench.py will report this pass as stale" % (e,))
+    json.dump({"csrc_files": csrc_files,
+               "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs of "
                          "`bench.py --steps 3 --warmup 2 --no-graph`; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB "
                          "(factors calibrated per access width in profiles/r04_pmc_calibration.txt: 2.000 / 1.000 for every width); `families` = the same rows averaged per "
                          "engine family label (aligned with bench.py --dump-launches by dispatch order)",
