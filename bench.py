@@ -366,6 +366,21 @@ def main():
     if len(sys.argv) == 3 and sys.argv[1] == "--cpu-worker":
         return _cpu_worker(sys.argv[2])
     args = parse_args()
+    # ONE JSON line on stdout, whatever the libraries print: RCCL writes its version banner to the C stdout when a communicator is
+    # created (seen behind the JSON line of a run with the one-rank collective leg).  File descriptor 1 points at stderr for the
+    # whole run; the line goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        return _main(args, real_stdout)
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+
+
+def _main(args, real_stdout):
     from m3dssd_amd import dist as mdist
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -380,6 +395,7 @@ def main():
         os.environ.setdefault("OMP_NUM_THREADS", "8")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.dup2(real_stdout, 1)                    # the launcher and its ranks inherit the real stdout (rank 0 prints the line)
         os.execv(sys.executable, cmd)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
@@ -430,7 +446,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(sd)
             except Exception as e:                 # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "images/sec", "kind": "port", "error": "%s: %s" % (type(e).__name__, e)}
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -267,6 +267,19 @@ int m3d_frontend_bf16_forward(const void *img, int is_u8, int img_h, int img_w, 
                               const void *w_stem, const float *s_stem, const float *t_stem, const void *w_l0, const float *s_l0,
                               const float *t_l0, const void *w_l1, const float *s_l1, const float *t_l1, void *out, int out_cs,
                               int N, int H, int W, m3d_stream_t stream);
+/* Round-5 form of the fused front end (csrc/bf16_frontend2.hip): fp16 inside the kernel (the tiles never leave LDS), the
+ * BatchNorm scales folded into fp16 weights by the caller, the shifts added as the C operand of the MFMA chains; stem on
+ * v_mfma_f32_32x32x16_f16 with two adjacent output pixels per column.  Operands (m3dssd_amd/engine_bf16.py: pack_frontend_f16):
+ *   w_stem_frag fp16 [7 tap rows][2 K-steps][64 lanes][8]: lane l, element e = weight * scale of channel 4 * ((l % 32) / 8) +
+ *               (l % 4) [(l % 32) % 8 < 4: pixel shift 0, else 1], colour e % 4 (3 = zero), tap column 4 * kstep + 2 * (l / 32)
+ *               + e / 4 - shift (outside [0, 7): zero); colour slot 3 of tap (0, 0) = the channel's BatchNorm shift (the kernel
+ *               writes 1.0 into that slot of every image pixel; t_stem itself is not read);
+ *   w_l0 / w_l1 fp16 [16 | 32][160], k = tap * 16 + c (k >= 144 zero), scale folded; t_* fp32 shifts [16], [16], [32].
+ * Same image arguments and output as m3d_frontend_bf16_forward. */
+int m3d_frontend2_bf16_forward(const void *img, int is_u8, int img_h, int img_w, const float *mean3, const float *stds3,
+                               const void *w_stem_frag, const float *t_stem, const void *w_l0, const float *t_l0,
+                               const void *w_l1, const float *t_l1, void *out, int out_cs, int N, int H, int W,
+                               m3d_stream_t stream);
 /* ANAB attention of the bf16 path in one launch (model/module/attention.py:207-211 + the BatchNorm / LeakyReLU after the block):
  * out[p] = act((softmax_k(q[p] . khat[k]) @ vhat + res[p]) * scale + shift) per image, replacing the logits GEMM / row softmax /
  * P.V GEMM sequence (m3d_conv_bf16_forward with per-image weights, m3d_softmax_rows_bf16).  q bf16 [B*HW][q_cs] (channels

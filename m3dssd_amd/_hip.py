@@ -95,6 +95,8 @@ SIGNATURES = {
                                       P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "m3d_frontend_bf16_forward": (c_int, [P, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
                                   + [P] * 10 + [c_int] * 4 + [P]),
+    "m3d_frontend2_bf16_forward": (c_int, [P, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+                                   + [P] * 7 + [c_int] * 4 + [P]),
     "m3d_anab_attend_bf16": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, c_int, P, c_int, P]),
     "m3d_maxpool2x2_bf16": (c_int, [P, c_int, P, c_int] + [c_int] * 4 + [P]),
     "m3d_upsample2x_add_bf16": (c_int, [P, c_int, P, P, c_int, P, c_int] + [c_int] * 4 + [P]),

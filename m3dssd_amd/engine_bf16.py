@@ -30,6 +30,7 @@ KV_BF16 = os.environ.get("M3D_BF16_KV_BF16", "1") != "0"
 FUSED_HEADS = os.environ.get("M3D_BF16_FUSED_HEADS", "1") != "0"
 USE_WIDE = os.environ.get("M3D_BF16_WIDE", "1") != "0"       # 3x3 layers on the 128 x 128 wave-tile kernel where it applies
 FUSED_FRONT = os.environ.get("M3D_BF16_FUSED_FRONT", "1") != "0"
+FRONT2 = os.environ.get("M3D_BF16_FRONT2", "1") != "0"         # round-5 form of the fused front end (csrc/bf16_frontend2.hip)
 
 
 def pack_frontend_bf16(w_stem, w_l0, w_l1, device):
@@ -44,6 +45,38 @@ def pack_frontend_bf16(w_stem, w_l0, w_l1, device):
         t[:, :144] = w.detach().float().cpu().permute(0, 2, 3, 1).reshape(co, 144)
         out.append(t)
     return [t.to(device, BF16).contiguous() for t in out]
+
+
+def pack_frontend_f16(w_stem, bn_stem, w_l0, bn_l0, w_l1, bn_l1, device):
+    """Operands of m3d_frontend2_bf16_forward (csrc/bf16_frontend2.hip): fp16 weights with the folded BatchNorm scale multiplied
+    in, fp32 shifts.  bn_* = (scale [C], shift [C]).
+    stem: A fragments of v_mfma_f32_32x32x16_f16 [7 tap rows][2 K-steps][64 lanes][8]: MFMA row r = lane % 32 is channel
+    4 * (r / 8) + r % 4 of output pixel `shift` = (r % 8 >= 4) of a pixel pair, k = 8 * (lane / 32) + e is window column
+    4 * kstep + 2 * (lane / 32) + e / 4, colour e % 4; the weight is w[ch, colour, i, column - shift]; colour slot 3 (the kernel
+    writes 1.0 there) carries the folded BatchNorm SHIFT at tap (0, 0) of the pixel.
+    level0 / level1: [Co][160], k = (i * 3 + j) * 16 + c, zero past 144."""
+    ws = (w_stem.detach().float().cpu() * bn_stem[0].detach().float().cpu()[:, None, None, None])    # [16, 3, 7, 7]
+    frag = torch.zeros(7, 2, 64, 8)
+    for lane in range(64):
+        r, kh = lane % 32, lane // 32
+        shift = 1 if (r % 8) >= 4 else 0
+        ch = 4 * (r // 8) + r % 4
+        for s in range(2):
+            for e in range(8):
+                col, rgb = 4 * s + 2 * kh + e // 4, e % 4
+                j = col - shift
+                if rgb < 3 and 0 <= j < 7:
+                    frag[:, s, lane, e] = ws[ch, rgb, :, j]
+                elif rgb == 3 and j == 0:
+                    frag[0, s, lane, e] = bn_stem[1][ch]       # the shift: slot 3 of every image-tile pixel holds 1.0
+    out = [frag.to(device, torch.float16).contiguous(), bn_stem[1].detach().float().to(device).contiguous()]
+    for w, bn in ((w_l0, bn_l0), (w_l1, bn_l1)):
+        co = w.shape[0]
+        wf = w.detach().float().cpu() * bn[0].detach().float().cpu()[:, None, None, None]
+        t = torch.zeros(co, 160)
+        t[:, :144] = wf.permute(0, 2, 3, 1).reshape(co, 144)
+        out += [t.to(device, torch.float16).contiguous(), bn[1].detach().float().to(device).contiguous()]
+    return out
 
 
 class View16:
@@ -141,6 +174,9 @@ class EngineBF16(Engine):
         P["level0"] = self._pc(b + ".level0.0", b + ".level0.1")
         P["level1"] = self._pc(b + ".level1.0", b + ".level1.1")
         P["front.w"] = pack_frontend_bf16(sd[b + ".base_layer.0.weight"], sd[b + ".level0.0.weight"], sd[b + ".level1.0.weight"], dev)
+        P["front2"] = pack_frontend_f16(sd[b + ".base_layer.0.weight"], (P["stem.scale"], P["stem.shift"]),
+                                        sd[b + ".level0.0.weight"], (P["level0"].scale, P["level0"].shift),
+                                        sd[b + ".level1.0.weight"], (P["level1"].scale, P["level1"].shift), dev)
 
         def block(p):
             P[p + ".conv1"] = self._pc(p + ".conv1", p + ".bn1")
@@ -312,6 +348,14 @@ class EngineBF16(Engine):
                     in_u8[0] if u8 else in_ptr[0], u8, in_u8[1], in_u8[2], mean3, stds3, fwts[0].data_ptr(),
                     P["stem.scale"].data_ptr(), P["stem.shift"].data_ptr(), fwts[1].data_ptr(), p0.scale.data_ptr(),
                     p0.shift.data_ptr(), fwts[2].data_ptr(), p1.scale.data_ptr(), p1.shift.data_ptr(), l1.ptr, l1.cs, B, H, W, st))
+            if FRONT2:
+                f2 = P["front2"]
+
+                def front(st):         # noqa: F811
+                    u8 = 1 if in_u8[0] else 0
+                    _hip.check(L.m3d_frontend2_bf16_forward(
+                        in_u8[0] if u8 else in_ptr[0], u8, in_u8[1], in_u8[2], mean3, stds3, f2[0].data_ptr(), f2[1].data_ptr(),
+                        f2[2].data_ptr(), f2[3].data_ptr(), f2[4].data_ptr(), f2[5].data_ptr(), l1.ptr, l1.cs, B, H, W, st))
             flops = 2.0 * B * H * W * (147 * 16 + 144 * 16) + 2.0 * B * (H // 2) * (W // 2) * 144 * 32
             # (bytes: the fp32 NCHW image in, the 32-channel half-resolution bf16 map out)
             plan.ops.append(("stem+level0+level1", "bf16_frontend", flops, front,

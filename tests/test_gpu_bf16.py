@@ -28,15 +28,22 @@ BF16 = torch.bfloat16
 # measured values are in BF16_MEASURED for the record), so a 1.3x regression of any column fails (round 4 had one
 # max bound of 2.0 for all columns against 0.77 / 0.21 measured).
 BF16_COLS = {"bbox_2d": ("x", "y", "w", "h"), "bbox_3d": ("x3d", "y3d", "z3d", "w3d", "h3d", "l3d", "rY3d")}
-BF16_MEASURED = {      # (max, p99.9, rms) per column at 1280x384, 2 frames (seed 1234, right third zero-padded)
-    "bbox_2d": {"x": (0.0349, 0.0138, 0.0030), "y": (0.0281, 0.0124, 0.0027), "w": (0.547, 0.106, 0.0128), "h": (0.770, 0.118, 0.0140)},
-    "bbox_3d": {"x3d": (0.0256, 0.0123, 0.0027), "y3d": (0.0310, 0.0133, 0.0029), "z3d": (0.169, 0.0215, 0.0124),
-                "w3d": (0.136, 0.0178, 0.0079), "h3d": (0.146, 0.0170, 0.0068), "l3d": (0.206, 0.0210, 0.0100), "rY3d": (0.166, 0.0202, 0.0091)},
+BF16_MEASURED = {      # (max, p99.9, rms) per column at 1280x384: the LARGEST over the measurement sets of round 5 -- 2 frames
+    # (seed 1234, right third zero-padded) and frames 0 / 21 / 42 / 63 of the bs-64 batch, with the round-4 and the round-5 front
+    # end.  rms / p99.9 are stable to ~5 % between builds; the maxima sit at single pixels and move by +-25 % with any change of
+    # the rounding points (h: 0.73 .. 0.94 over the four sets), hence "largest seen" and not one run's value.
+    "bbox_2d": {"x": (0.0349, 0.0205, 0.0050), "y": (0.0299, 0.0173, 0.0046), "w": (0.620, 0.179, 0.0173), "h": (0.943, 0.197, 0.0187)},
+    "bbox_3d": {"x3d": (0.0293, 0.0176, 0.0047), "y3d": (0.0324, 0.0202, 0.0051), "z3d": (0.2154, 0.0591, 0.0133),
+                "w3d": (0.206, 0.0574, 0.0116), "h3d": (0.2473, 0.0570, 0.0116), "l3d": (0.2496, 0.0588, 0.0123),
+                "rY3d": (0.2363, 0.0629, 0.0125)},
 }
 BF16_GUARD = 1.3
 BF16_PROB_TOL = 0.05
-BF16_PROB_MEASURED = 0.0203           # max |prob - oracle| at 1280x384
-BF16_FLIP_RATE_MEASURED = 193 / 15360  # top-1 anchor decisions that differ from the free-running fp32 oracle's (1.26 %)
+BF16_PROB_MEASURED = 0.0217           # max |prob - oracle| at 1280x384
+BF16_FLIP_RATE_MEASURED = 589 / 30720  # top-1 anchor decisions that differ from the free-running fp32 oracle's: 1.3 % (2 frames) .. 1.9 % (bs-64 slice)
+# (an fp32 last class layer would not help: recomputing cls.6 in fp32 from the engine's bf16 hidden map leaves 182 of the 199
+# flips of the 2-frame set -- they come from the ~1 % feature noise upstream, not from the last layer's rounding; logged as
+# n_idx_with_fp32_cls6.  Softmax / fg_prob / top-1 already run in fp32 on fp32 logits.)
 # aggregate bounds kept for the A/B-plan comparison test (two bf16 plans against each other: both sides carry the error)
 BF16_BBOX_RMS_TOL = 0.03
 BF16_BBOX_P999_TOL = 0.2
@@ -697,13 +704,17 @@ def test_bf16_helpers_match_torch():
     assert ((got - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-4).all()
 
 
-@pytest.mark.parametrize("n,H,W,u8", [(2, 32, 128, False), (1, 48, 96, False), (2, 32, 128, True)])
-def test_fused_frontend_bf16_matches_torch_chain(n, H, W, u8):
-    """m3d_frontend_bf16_forward (stem -> level0 -> level1 in one launch, intermediates in LDS) against the torch chain with
-    bf16-rounded weights and the two intermediates rounded to bf16 where the kernel rounds them; image borders, several tiles
-    per image, a width that is not a multiple of the tile, and the uint8 input path."""
+@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("n,H,W,u8", [(2, 32, 128, False), (1, 48, 96, False), (2, 32, 128, True), (2, 96, 192, False),
+                                      (1, 64, 80, False), (3, 96, 256, True)])
+def test_fused_frontend_bf16_matches_torch_chain(n, H, W, u8, form):
+    """m3d_frontend_bf16_forward / m3d_frontend2_bf16_forward (stem -> level0 -> level1 in one launch, intermediates in LDS)
+    against the torch chain with bf16-rounded weights and the two intermediates rounded to bf16 where the first form rounds them
+    (the second keeps them in fp16 and folds the BatchNorm scales into fp16 weights: inside the same bound); image borders,
+    several tiles per image incl. interior ones (96 x 192 / 96 x 256: the mask-free code path of form 2), a width that is not a
+    multiple of the tile, and the uint8 input path."""
     from m3dssd_amd import _hip
-    from m3dssd_amd.engine_bf16 import pack_frontend_bf16
+    from m3dssd_amd.engine_bf16 import pack_frontend_bf16, pack_frontend_f16
     L = _hip.lib()
     dev = _dev()
     g = torch.Generator().manual_seed(H + W)
@@ -730,10 +741,16 @@ def test_fused_frontend_bf16_matches_torch_chain(n, H, W, u8):
     out = torch.full((n, H // 2, W // 2, 40), 512.0, device=dev, dtype=BF16)
     mean3 = (ctypes.c_float * 3)(*[float(v) for v in conf.image_means])
     stds3 = (ctypes.c_float * 3)(*[float(v) for v in conf.image_stds])
-    _hip.check(L.m3d_frontend_bf16_forward(src.data_ptr(), 1 if u8 else 0, H - 5 if u8 else 0, W - 9 if u8 else 0, mean3, stds3,
-                                           packs[0].data_ptr(), dv[0].data_ptr(), dv[1].data_ptr(), packs[1].data_ptr(),
-                                           dv[2].data_ptr(), dv[3].data_ptr(), packs[2].data_ptr(), dv[4].data_ptr(), dv[5].data_ptr(),
-                                           out.data_ptr(), 40, n, H, W, _st()))
+    if form == 1:
+        _hip.check(L.m3d_frontend_bf16_forward(src.data_ptr(), 1 if u8 else 0, H - 5 if u8 else 0, W - 9 if u8 else 0, mean3, stds3,
+                                               packs[0].data_ptr(), dv[0].data_ptr(), dv[1].data_ptr(), packs[1].data_ptr(),
+                                               dv[2].data_ptr(), dv[3].data_ptr(), packs[2].data_ptr(), dv[4].data_ptr(),
+                                               dv[5].data_ptr(), out.data_ptr(), 40, n, H, W, _st()))
+    else:
+        f2 = pack_frontend_f16(ws, aff[0], w0, aff[1], w1, aff[2], dev)
+        _hip.check(L.m3d_frontend2_bf16_forward(src.data_ptr(), 1 if u8 else 0, H - 5 if u8 else 0, W - 9 if u8 else 0, mean3,
+                                                stds3, f2[0].data_ptr(), f2[1].data_ptr(), f2[2].data_ptr(), f2[3].data_ptr(),
+                                                f2[4].data_ptr(), f2[5].data_ptr(), out.data_ptr(), 40, n, H, W, _st()))
     torch.cuda.synchronize()
     assert (out[..., 32:].float() == 512.0).all()
     got = out[..., :32].float().permute(0, 3, 1, 2).cpu()
@@ -832,7 +849,7 @@ def test_bf16_network_matches_fp32_oracle_within_stated_tolerance(crop, B, pad):
         h = hidden.view(B, fh, fw, 256).float().permute(0, 3, 1, 2)
         logits = F.conv2d(h, sd["cls.6.weight"].to(_dev()).float(), sd["cls.6.bias"].to(_dev()).float())
         A = eng.A
-        pr = torch.softmax(logits.view(B, 4, A * fh, fw), dim=1)
+        pr = torch.softmax(logits.reshape(B, 4, A * fh, fw), dim=1)
         fg32 = (1 - pr[:, 0]).view(B, A, fh, fw)
         ind32 = fg32.max(dim=1, keepdim=True)[1].cpu()
         from oracle import model_cpu

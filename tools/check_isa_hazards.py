@@ -25,7 +25,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 # kernels whose main loops carry hand-counted `s_waitcnt vmcnt(N)` (asm loads): a spill inside them corrupts results
-HAND_COUNTED = ("wino44_kernel", "bf16_conv3x3_wide_kernel", "head_mlp_kernel", "wino_wave_kernelILb0E")
+HAND_COUNTED = ("wino44_kernel", "bf16_conv3x3_wide_kernel", "head_mlp_kernel", "wino_wave_kernelILb0E", "bf16_frontend2_kernel")
 
 STORE = re.compile(r"^\s*(buffer|global|flat|scratch)_store_(dwordx3|dwordx4|b96|b128)\s+(.*)$")
 REG = re.compile(r"\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]")
