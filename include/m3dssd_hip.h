@@ -250,6 +250,26 @@ typedef struct m3d_head_bf16_desc {
     int groups;
 } m3d_head_bf16_desc;
 int m3d_head_mlp_bf16_forward(const m3d_head_bf16_desc *d, m3d_stream_t stream);
+/* Round-5 form of the fused head (csrc/bf16_head_mlp2.hip): the weights of layers 1 / 2 live in registers for the whole launch (wave w
+ * of the 8-wave workgroup owns output channels [32w, 32w + 32)), hidden activations fp16 in LDS, layers 2 / 3 on fp16 MFMA.  The
+ * caller folds the BatchNorm scales into the weights and packs them (m3dssd_amd/engine_bf16.py: pack_head2):
+ *   w1f bf16 [groups][8 waves][8 K-steps][64 lanes][8], w2f fp16 [groups][8][16][64][8]: lane l of wave w, K-step s, element e =
+ *       scale[ch] * W[ch][16 s + 8 (l / 32) + e] with ch = 32 w + 16 ((r % 8) / 4) + 4 (r / 8) + r % 4, r = l % 32;
+ *   w3 fp16 [groups][64][256] row-major, scale folded, rows >= Cout zero; t1 / t2 [groups][256], t3 [groups][64] fp32 shifts.
+ * Same input / output conventions as m3d_head_mlp_bf16_forward (128 input channels, Cout <= 64, planar fp32 output). */
+typedef struct m3d_head2_bf16_desc {
+    const void *in;           /* bf16 [M][in_cs], first 128 channels used */
+    int in_cs;
+    long long M;
+    const void *w1f, *w2f, *w3;
+    const float *t1, *t2, *t3;
+    int Cout;
+    float *out;
+    long long out_group_off, out_img_stride;
+    int HW;
+    int groups;
+} m3d_head2_bf16_desc;
+int m3d_head_mlp2_bf16_forward(const m3d_head2_bf16_desc *d, m3d_stream_t stream);
 
 /* HBM-bound helpers of the bf16 path: NHWC bf16 views (pixel strides in bf16 elements, multiples of 8), fp32 arithmetic.
  * m3d_stem_conv7x7_bf16: DLA.base_layer from the fp32 [N][3][H][W] image (is_u8 = 0; img_h/img_w/mean3/stds3 ignored) or

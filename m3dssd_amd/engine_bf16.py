@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _hip
-from ._hip import ConvBf16Desc, HeadBf16Desc
+from ._hip import ConvBf16Desc, Head2Bf16Desc, HeadBf16Desc
 from .engine import BN_EPS, PSP_SIZES, Engine, OpCost, _Plan, _rup
 
 BF16 = torch.bfloat16
@@ -30,6 +30,7 @@ KV_BF16 = os.environ.get("M3D_BF16_KV_BF16", "1") != "0"
 FUSED_HEADS = os.environ.get("M3D_BF16_FUSED_HEADS", "1") != "0"
 USE_WIDE = os.environ.get("M3D_BF16_WIDE", "1") != "0"       # 3x3 layers on the 128 x 128 wave-tile kernel where it applies
 FUSED_FRONT = os.environ.get("M3D_BF16_FUSED_FRONT", "1") != "0"
+HEADS2 = os.environ.get("M3D_BF16_HEADS2", "1") != "0"         # round-5 form of the fused heads (csrc/bf16_head_mlp2.hip)
 FRONT2 = os.environ.get("M3D_BF16_FRONT2", "1") != "0"         # round-5 form of the fused front end (csrc/bf16_frontend2.hip)
 
 
@@ -77,6 +78,39 @@ def pack_frontend_f16(w_stem, bn_stem, w_l0, bn_l0, w_l1, bn_l1, device):
         t[:, :144] = wf.permute(0, 2, 3, 1).reshape(co, 144)
         out += [t.to(device, torch.float16).contiguous(), bn[1].detach().float().to(device).contiguous()]
     return out
+
+
+def _head2_frag(w, dtype):
+    """[256, K] fp32 (scale folded) -> A-operand fragments of the 8 waves of csrc/bf16_head_mlp2.hip: [8][K/16][64][8]; MFMA row
+    r = lane % 32 of wave w is channel 32 w + 16 ((r % 8) / 4) + 4 (r / 8) + r % 4, element e is k = 16 s + 8 (lane / 32) + e."""
+    K = w.shape[1]
+    r = torch.arange(32)
+    ch_of_row = 16 * ((r % 8) // 4) + 4 * (r // 8) + r % 4                  # [32]
+    lane = torch.arange(64)
+    ch = (32 * torch.arange(8)[:, None] + ch_of_row[lane % 32][None, :])     # [8, 64]
+    k = (16 * torch.arange(K // 16)[:, None, None] + 8 * (lane // 32)[None, :, None] + torch.arange(8)[None, None, :])   # [K/16, 64, 8]
+    out = w[ch[:, None, :, None], k[None, :, :, :]]                          # [8, K/16, 64, 8]
+    return out.to(dtype).contiguous()
+
+
+def pack_head2(heads, device):
+    """Operands of m3d_head_mlp2_bf16_forward for the heads of one launch: heads = [(w1 [256,128], s1, t1, w2 [256,256], s2, t2,
+    w3 [Cout,256], s3, t3)] fp32 (s / t = folded BatchNorm / bias scale and shift) -> (w1f bf16, w2f fp16, w3 fp16 [G,64,256],
+    t1 [G,256], t2 [G,256], t3 [G,64]) with the scales multiplied into the weights."""
+    w1f, w2f, w3p, t1, t2, t3 = [], [], [], [], [], []
+    for (w1, s1, b1, w2, s2, b2, w3, s3, b3) in heads:
+        f = lambda t: t.detach().float().cpu()                # noqa: E731
+        w1f.append(_head2_frag(f(w1).reshape(256, 128) * f(s1)[:, None], BF16))
+        w2f.append(_head2_frag(f(w2).reshape(256, 256) * f(s2)[:, None], torch.float16))
+        co = w3.shape[0]
+        w3s = torch.zeros(64, 256)
+        w3s[:co] = f(w3).reshape(co, 256) * f(s3)[:, None]
+        w3p.append(w3s.to(torch.float16))
+        t1.append(f(b1)); t2.append(f(b2))
+        tt = torch.zeros(64)
+        tt[:co] = f(b3)
+        t3.append(tt)
+    return tuple(torch.stack(x).to(device).contiguous() for x in (w1f, w2f, w3p, t1, t2, t3))
 
 
 class View16:
@@ -358,7 +392,7 @@ class EngineBF16(Engine):
                         f2[2].data_ptr(), f2[3].data_ptr(), f2[4].data_ptr(), f2[5].data_ptr(), l1.ptr, l1.cs, B, H, W, st))
             flops = 2.0 * B * H * W * (147 * 16 + 144 * 16) + 2.0 * B * (H // 2) * (W // 2) * 144 * 32
             # (bytes: the fp32 NCHW image in, the 32-channel half-resolution bf16 map out)
-            plan.ops.append(("stem+level0+level1", "bf16_frontend", flops, front,
+            plan.ops.append(("stem+level0+level1", "bf16_frontend2" if FRONT2 else "bf16_frontend", flops, front,
                              OpCost(B * H * W * 3 * 4 + B * (H // 2) * (W // 2) * 32 * 2)))
         else:
             s0 = self._buf16(plan, B, H, W, 16)
@@ -490,6 +524,26 @@ class EngineBF16(Engine):
             w2, s2, t2 = stacked(names, ".3")
             w3, s3, t3 = stacked(names, ".6")
             cp = P[names[0] + ".6"].cout_pad
+            if FUSED_HEADS and HEADS2 and x.c == 128 and A <= 64:
+                key2 = "head2:" + "+".join(names)
+                if key2 not in P:
+                    sd = self.sd
+                    P[key2] = pack_head2([(sd[n + ".0.weight"], P[n + ".0"].scale, P[n + ".0"].shift,
+                                           sd[n + ".3.weight"], P[n + ".3"].scale, P[n + ".3"].shift,
+                                           sd[n + ".6.weight"], P[n + ".6"].scale, P[n + ".6"].shift) for n in names], self.device)
+                pk = P[key2]
+                d = Head2Bf16Desc()
+                d.inp, d.in_cs, d.M = x.ptr, x.cs, B * HW
+                d.w1f, d.w2f, d.w3, d.t1, d.t2, d.t3 = (t.data_ptr() for t in pk)
+                d.Cout = A
+                d.out = box_pl.data_ptr() + 4 * first_box_index * A * HW
+                d.out_group_off, d.out_img_stride, d.HW, d.groups = A * HW, 11 * A * HW, HW, G
+                ref = ctypes.byref(d)
+                plan.keep += list(pk)
+                flops = 2.0 * B * HW * G * (128 * 256 + 256 * 256 + 256 * A)
+                plan.ops.append(("+".join(names) + ".mlp", "bf16_head2", flops,
+                                 lambda st: _hip.check(L.m3d_head_mlp2_bf16_forward(ref, st)), d))
+                return
             if FUSED_HEADS and x.c == 128 and cp == 64:
                 d = HeadBf16Desc()
                 d.inp, d.in_cs, d.M, d.Cin = x.ptr, x.cs, B * HW, 128

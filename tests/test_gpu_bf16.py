@@ -392,11 +392,15 @@ def test_conv_bf16_grouped_and_per_image_weights():
     _check(got, ref, 1)
 
 
-@pytest.mark.parametrize("G,n,h,w,cout", [(1, 2, 8, 16, 36), (4, 1, 13, 21, 36), (2, 2, 16, 40, 5)])
-def test_fused_head_mlp_bf16_matches_torch_chain(G, n, h, w, cout):
-    """m3d_head_mlp_bf16_forward (3 layers, hidden activations in LDS, heads of one map in one launch) against the torch
-    chain on the same bf16-rounded input / weights with the hidden activations rounded to bf16 where the kernel rounds them."""
+@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("G,n,h,w,cout", [(1, 2, 8, 16, 36), (4, 1, 13, 21, 36), (2, 2, 16, 40, 5), (6, 3, 48, 160, 36), (1, 1, 4, 8, 64)])
+def test_fused_head_mlp_bf16_matches_torch_chain(G, n, h, w, cout, form):
+    """m3d_head_mlp_bf16_forward / m3d_head_mlp2_bf16_forward (3 layers, hidden activations in LDS, heads of one map in one
+    launch) against the torch chain on the same bf16-rounded input / weights with the hidden activations rounded to bf16 where the
+    first form rounds them (the second keeps them in fp16 and folds the scales into the weights: inside the same bound).  Ragged
+    tiles (13 x 21), several tiles per workgroup and persistent workgroups per head (6 heads x 3 x 48 x 160), Cout = 64."""
     from m3dssd_amd import _hip
+    from m3dssd_amd.engine_bf16 import pack_head2
     L = _hip.lib()
     dev = _dev()
     g = torch.Generator().manual_seed(G * 100 + h)
@@ -411,12 +415,22 @@ def test_fused_head_mlp_bf16_matches_torch_chain(G, n, h, w, cout):
     sh = [torch.randn(G, c, generator=g) * 0.1 for c in (256, 256, cout)]
     out = torch.full((n, G * cout + 1, HW), 512.0, device=dev)
     dv = [t.to(dev).contiguous() for t in (w1.to(BF16), w2.to(BF16), w3.to(BF16), aff[0], sh[0], aff[1], sh[1], aff[2], sh[2])]
-    d = _hip.HeadBf16Desc()
-    d.inp, d.in_cs, d.M, d.Cin = xin.data_ptr(), 136, M, 128
-    d.w1, d.w2, d.w3, d.s1, d.t1, d.s2, d.t2, d.s3, d.t3 = (t.data_ptr() for t in dv)
-    d.Cout, d.Cout_pad, d.out = cout, 64, out.data_ptr()
-    d.out_group_off, d.out_img_stride, d.HW, d.groups = cout * HW, (G * cout + 1) * HW, HW, G
-    _hip.check(L.m3d_head_mlp_bf16_forward(ctypes.byref(d), _st()))
+    if form == 1:
+        d = _hip.HeadBf16Desc()
+        d.inp, d.in_cs, d.M, d.Cin = xin.data_ptr(), 136, M, 128
+        d.w1, d.w2, d.w3, d.s1, d.t1, d.s2, d.t2, d.s3, d.t3 = (t.data_ptr() for t in dv)
+        d.Cout, d.Cout_pad, d.out = cout, 64, out.data_ptr()
+        d.out_group_off, d.out_img_stride, d.HW, d.groups = cout * HW, (G * cout + 1) * HW, HW, G
+        _hip.check(L.m3d_head_mlp_bf16_forward(ctypes.byref(d), _st()))
+    else:
+        pk = pack_head2([(w1[gi], aff[0][gi], sh[0][gi], w2[gi], aff[1][gi], sh[1][gi], w3[gi, :cout], aff[2][gi], sh[2][gi])
+                         for gi in range(G)], dev)
+        d = _hip.Head2Bf16Desc()
+        d.inp, d.in_cs, d.M = xin.data_ptr(), 136, M
+        d.w1f, d.w2f, d.w3, d.t1, d.t2, d.t3 = (t.data_ptr() for t in pk)
+        d.Cout, d.out = cout, out.data_ptr()
+        d.out_group_off, d.out_img_stride, d.HW, d.groups = cout * HW, (G * cout + 1) * HW, HW, G
+        _hip.check(L.m3d_head_mlp2_bf16_forward(ctypes.byref(d), _st()))
     torch.cuda.synchronize()
     got = out.cpu()
     assert (got[:, G * cout] == 512.0).all()
@@ -973,17 +987,24 @@ def test_bf16_engine_alternative_paths_agree(monkeypatch):
     crop, B = (128, 320), 2
     x = synth.synth_frames(B, crop, 99).to(_dev())
     ref = None
-    for fused, kv16, heads, front in [(True, True, True, True), (False, True, True, True), (True, False, True, True),
-                                      (False, False, True, True), (True, True, False, True), (True, True, True, False)]:
+    # (fused ANAB, bf16 K|V, fused heads, fused front end, round-5 heads, round-5 front end)
+    for fused, kv16, heads, front, heads2, front2 in [(True, True, True, True, True, True), (False, True, True, True, True, True),
+                                                      (True, False, True, True, True, True), (False, False, True, True, True, True),
+                                                      (True, True, False, True, True, True), (True, True, True, False, True, True),
+                                                      (True, True, True, True, False, True), (True, True, True, True, True, False)]:
         monkeypatch.setattr(engine_bf16, "FUSED_ANAB", fused)
         monkeypatch.setattr(engine_bf16, "KV_BF16", kv16)
         monkeypatch.setattr(engine_bf16, "FUSED_HEADS", heads)
         monkeypatch.setattr(engine_bf16, "FUSED_FRONT", front)
+        monkeypatch.setattr(engine_bf16, "HEADS2", heads2)
+        monkeypatch.setattr(engine_bf16, "FRONT2", front2)
         net, _ = _net(crop, B, "bf16")
         with torch.no_grad():
             out = [t.float().cpu() for t in net(x)[:4]]
         kinds = {op[1] for op in net.engine().plan_for(B, *crop).ops}
-        assert ("bf16_anab" in kinds) == fused and ("bf16_head_mlp" in kinds) == heads and ("bf16_frontend" in kinds) == front
+        assert ("bf16_anab" in kinds) == fused
+        assert ("bf16_head2" in kinds) == (heads and heads2) and ("bf16_head_mlp" in kinds) == (heads and not heads2)
+        assert ("bf16_frontend2" in kinds) == (front and front2) and ("bf16_frontend" in kinds) == (front and not front2)
         if ref is None:
             ref = out
             continue
@@ -993,7 +1014,7 @@ def test_bf16_engine_alternative_paths_agree(monkeypatch):
             # error -- / max; a flipped discrete
             # decision -- top-1 anchor, hard mask -- moves a few entries by more than the rounding noise)
             assert float((d ** 2).mean().sqrt()) <= BF16_BBOX_RMS_TOL and float(torch.quantile(d.flatten()[:2000000], 0.999)) <= 2 * BF16_BBOX_P999_TOL \
-                and float(d.max()) <= BF16_BBOX_MAX_TOL, (fused, kv16, heads, front, name, float(d.max()))
+                and float(d.max()) <= BF16_BBOX_MAX_TOL, (fused, kv16, heads, front, heads2, front2, name, float(d.max()))
 
 
 def test_bf16_batch64_full_size_properties():
