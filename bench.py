@@ -35,7 +35,7 @@ PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29
 CROP = (384, 1280)
 PER_GPU_BATCH = 8
 MFMA_FAMILIES = ("igemm", "wino", "head_mlp", "conv_wave", "bf16_conv", "bf16_halo", "bf16_wide", "bf16_anab", "bf16_dcn_patch",
-                 "bf16_head_mlp", "bf16_head2", "bf16_frontend")
+                 "bf16_head_mlp", "bf16_head2", "bf16_tail2", "bf16_frontend")
 # SURVEY 8d, per image: 105.8 GFLOP; activations 1003.6 MB (fp32) + outputs 21 MB + input 5.9 MB; weights 82.6 MB (fp32) per batch
 ALG_GFLOP_PER_IMAGE = 105.8
 ALG_MB_PER_IMAGE_F32 = 1003.6 + 21.0 + 5.9
@@ -155,6 +155,8 @@ def kernel_symbol(label):
         return "bf16_anab_attend_kernel(AnabArgs)"
     if label.startswith("bf16_head2"):
         return "bf16_head2_kernel(Head2Args)"
+    if label.startswith("bf16_tail2"):
+        return "bf16_tail2_kernel(Tail2Args)"
     if label.startswith("bf16_head_mlp"):
         return "bf16_head_mlp_kernel(HeadArgs)"
     if label.startswith("bf16_frontend2"):
@@ -196,7 +198,7 @@ def kernel_symbol(label):
 
 
 # engine family label prefix -> the kernel sources whose edit invalidates a PMC pass of that family (plus the shared headers)
-FAMILY_SOURCES = (("bf16_anab", ("bf16_anab.hip",)), ("bf16_head2", ("bf16_head_mlp2.hip",)), ("bf16_head_mlp", ("bf16_head_mlp.hip",)),
+FAMILY_SOURCES = (("bf16_anab", ("bf16_anab.hip",)), ("bf16_head2", ("bf16_head_mlp2.hip",)), ("bf16_tail2", ("bf16_head_mlp2.hip",)), ("bf16_head_mlp", ("bf16_head_mlp.hip",)),
                   ("bf16_frontend2", ("bf16_frontend2.hip",)), ("bf16_frontend", ("bf16_frontend.hip",)),
                   ("bf16_dcn_patch", ("bf16_dcn_patch.hip", "bf16_conv.hip")), ("bf16_wide", ("bf16_conv_wide.hip",)),
                   ("bf16_halo", ("bf16_conv.hip",)), ("bf16_conv", ("bf16_conv.hip",)), ("wino44", ("wino44_conv.hip",)),
@@ -258,6 +260,8 @@ def algorithmic_bytes(op):
         return None
     if hasattr(d, "hbm_bytes"):                           # engine.OpCost: a helper launch that states its own byte count
         return d.hbm_bytes
+    if hasattr(d, "waf"):                                 # m3d_tail2_bf16_desc: 256-channel input, two weight sets once, planar fp32 output
+        return d.M * 256 * 2 + d.M * d.Cout * 4 + (256 * 256 + 256 * d.Cout) * 2
     if hasattr(d, "w1f"):                                 # m3d_head2_bf16_desc: G heads, one 128-channel input, weights once
         return (d.M * 128 * 2 + d.groups * (d.M * d.Cout * 4 + (128 * 256 + 256 * 256 + 256 * 64) * 2))
     if hasattr(d, "out_group_off") and hasattr(d, "groups") and not hasattr(d, "Kpad"):   # m3d_head_bf16_desc: G heads, one input

@@ -270,6 +270,22 @@ typedef struct m3d_head2_bf16_desc {
     int groups;
 } m3d_head2_bf16_desc;
 int m3d_head_mlp2_bf16_forward(const m3d_head2_bf16_desc *d, m3d_stream_t stream);
+/* The two 1x1 layers behind the 3x3 convolution of the class head (M3d_inference_align.py:66-76: 256 -> 256 + affine + LeakyReLU,
+ * 256 -> Cout <= 256 + affine) in one launch, same scheme: waf bf16 / wbf fp16 fragments [8 waves][16 K-steps][64 lanes][8] in the
+ * layout of w2f above (scales folded, rows >= Cout of wbf zero), t1 / t2 fp32 [256] shifts (t2 past Cout ignored); input bf16
+ * [M][in_cs >= 256]; output planar fp32 out[img * out_img_stride + c * HW + p]. */
+typedef struct m3d_tail2_bf16_desc {
+    const void *in;
+    int in_cs;
+    long long M;
+    const void *waf, *wbf;
+    const float *t1, *t2;
+    int Cout;
+    float *out;
+    long long out_img_stride;
+    int HW;
+} m3d_tail2_bf16_desc;
+int m3d_head_tail2_bf16_forward(const m3d_tail2_bf16_desc *d, m3d_stream_t stream);
 
 /* HBM-bound helpers of the bf16 path: NHWC bf16 views (pixel strides in bf16 elements, multiples of 8), fp32 arithmetic.
  * m3d_stem_conv7x7_bf16: DLA.base_layer from the fp32 [N][3][H][W] image (is_u8 = 0; img_h/img_w/mean3/stds3 ignored) or

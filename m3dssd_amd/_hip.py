@@ -93,6 +93,17 @@ class Head2Bf16Desc(ctypes.Structure):
     ]
 
 
+class Tail2Bf16Desc(ctypes.Structure):
+    """Mirror of ``m3d_tail2_bf16_desc``."""
+    _fields_ = [
+        ("inp", c_void_p), ("in_cs", c_int), ("M", c_ll),
+        ("waf", c_void_p), ("wbf", c_void_p), ("t1", c_void_p), ("t2", c_void_p),
+        ("Cout", c_int),
+        ("out", c_void_p), ("out_img_stride", c_ll),
+        ("HW", c_int),
+    ]
+
+
 P = c_void_p
 # name -> (restype, argtypes); every name here must be declared in include/m3dssd_hip.h
 SIGNATURES = {
@@ -104,6 +115,7 @@ SIGNATURES = {
     "m3d_conv_bf16_variant": (c_int, [ctypes.POINTER(ConvBf16Desc)]),
     "m3d_head_mlp_bf16_forward": (c_int, [ctypes.POINTER(HeadBf16Desc), P]),
     "m3d_head_mlp2_bf16_forward": (c_int, [ctypes.POINTER(Head2Bf16Desc), P]),
+    "m3d_head_tail2_bf16_forward": (c_int, [ctypes.POINTER(Tail2Bf16Desc), P]),
     "m3d_stem_conv7x7_bf16": (c_int, [P, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                       P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "m3d_frontend_bf16_forward": (c_int, [P, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]

@@ -282,6 +282,205 @@ __global__ __launch_bounds__(512) void bf16_head2_kernel(const Head2Args a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Two-layer tail of the class head (M3d_inference_align.py:66-76: cls.3 = 1x1 256 -> 256 + BatchNorm + LeakyReLU, cls.6 = 1x1 256 ->
+// 4 * A + bias; the 3x3 cls.0 in front of them is a convolution launch): the same scheme -- wave w owns rows [32w, 32w + 32) of BOTH
+// layers with their 2 x 16 fragments resident in registers (waves whose rows lie past Cout sit layer 2 out), hidden tile fp16 in
+// LDS, three barriers per tile, planar fp32 output through a per-wave transposition in the (dead) input region.  Two generic
+// implicit-GEMM launches (0.16 ms each at bs 64, 400 / 220 TFLOP/s) become one.
+#define T2_IN 0                     // [128 px][256 ch] bf16, 512-byte rows; later 8 x 8 KB output transposition [32 ch][64 px] fp32
+#define T2_H 65536                  // [128 px][256 ch] fp16
+#define T2_SH (65536 + 65536)       // t1 [256] fp16 (512 bytes), then t2 [256] fp32
+#define T2_LDS (T2_SH + 512 + 1024)
+
+struct Tail2Args {
+    const void *in;                 // bf16 [M][in_cs], first 256 channels
+    const void *waf;                // bf16 fragments [8 waves][16 K-steps][64 lanes][8]   (layer 1, scale folded)
+    const void *wbf;                // fp16 fragments [8 waves][16 K-steps][64 lanes][8]   (layer 2, scale folded, rows >= Cout zero)
+    const float *t1, *t2;           // shifts [256], [256]
+    float *out;                     // planar: out + img*out_img_stride + c*HW + p
+    long long out_img_stride;
+    int in_cs, M, HW, Cout, tiles_m;
+};
+
+// packed fp16 pair: convert, add the shift pair, LeakyReLU
+__device__ __forceinline__ unsigned t2_shift_leaky_pack(float lo, float hi, unsigned shift_pair)
+{
+    const f32x2 v = {lo, hi};
+    const f16x2 y = __builtin_convertvector(v, f16x2) + __builtin_bit_cast(f16x2, shift_pair);
+    const f16x2 sl = {(_Float16)M3D_LEAKY_SLOPE, (_Float16)M3D_LEAKY_SLOPE};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(y, y * sl));
+}
+
+__global__ __launch_bounds__(512) void bf16_tail2_kernel(const Tail2Args a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[T2_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    bf16x8 wa[16];
+    f16x8 wb[16];
+    {
+        const bf16x8 *pa = reinterpret_cast<const bf16x8 *>(a.waf) + ((size_t)wave * 16) * 64 + lane;
+        const f16x8 *pb = reinterpret_cast<const f16x8 *>(a.wbf) + ((size_t)wave * 16) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) wa[s] = pa[s * 64];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) wb[s] = pb[s * 64];
+    }
+    // shifts: layer 1's as fp16 (added to the converted pairs in the epilogue), layer 2's as fp32 (added when the transposed rows
+    // are stored) -- as C operands of the chains they would cost 16 registers this kernel does not have (2 x 64 of resident weights)
+    {
+        _Float16 *sh1 = reinterpret_cast<_Float16 *>(lds + T2_SH);
+        float *sh2w = reinterpret_cast<float *>(lds + T2_SH + 512);
+        if (tid < 256) { sh1[tid] = (_Float16)a.t1[tid]; sh2w[tid] = a.t2[tid]; }
+    }
+    const float *sh2 = reinterpret_cast<const float *>(lds + T2_SH + 512);
+    // input staging: 32 pieces of 16 bytes per row, 16 rows per pass, 8 passes
+    const int c32 = tid & 31, r0 = tid >> 5;
+    u32x4 vin[8];
+    auto load_input = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int m = tile * 128 + p * 16 + r0;
+            vin[p] = u32x4{0u, 0u, 0u, 0u};
+            if (tile < a.tiles_m && m < a.M) vin[p] = *reinterpret_cast<const u32x4 *>((const __bf16 *)a.in + (size_t)m * a.in_cs + c32 * 8);
+        }
+    };
+    load_input(blockIdx.x);
+    const int lanepart = (lh ^ (l31 & 15)) << 4;
+    const unsigned char *inrow = lds + T2_IN + l31 * 512;
+    const unsigned char *hrow = lds + T2_H + l31 * 512;
+    // byte offset of this lane's chunk of K-step s inside its row, computed AT the read (one v_xor next to a 32-cycle MFMA): hoisted
+    // out of the loops the 2 x 16 offsets of the two tiles would occupy 32 of the registers the resident weights need
+    auto piece = [&](int s) {
+        int r;
+        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(r) : "v"(lanepart), "s"((((2 * s) & 15) << 4) | (((2 * s) & 16) << 4)));
+        return r;
+    };
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool active2 = 32 * wave < a.Cout;                   // (wave-uniform) this wave has output rows in layer 2
+
+    for (int tile = blockIdx.x; tile < a.tiles_m; tile += gridDim.x) {
+        const int m0 = tile * 128;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) *reinterpret_cast<u32x4 *>(lds + T2_IN + h2_off(p * 16 + r0, c32, 512)) = vin[p];
+        __syncthreads();                                        // A: input tile complete
+        f32x16 acc[2];
+        // ---- layer 1 (bf16, K = 256): two half tiles of two pixel blocks ---------------------------------------------------------
+        {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                bf16x8 q[3];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) q[i] = *reinterpret_cast<const bf16x8 *>(inrow + (2 * half + (i & 1)) * (32 * 512) + piece(i >> 1));
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const int cb = i & 1, s = i >> 1;
+                    if (i + 2 < 32)
+                        q[(i + 2) % 3] = *reinterpret_cast<const bf16x8 *>(inrow + (2 * half + ((i + 2) & 1)) * (32 * 512) + piece((i + 2) >> 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[s], q[i % 3], s == 0 ? zero16 : acc[cb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const u32x4 *shp = reinterpret_cast<const u32x4 *>(lds + T2_SH + (32 * wave + 16 * lh) * 2);
+                const u32x4 s0 = shp[0], s1 = shp[1];             // the lane's 16 shifts as 8 fp16 pairs
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    u32x4 o0, o1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o0[e] = t2_shift_leaky_pack(acc[cb][2 * e], acc[cb][2 * e + 1], s0[e]);
+                        o1[e] = t2_shift_leaky_pack(acc[cb][8 + 2 * e], acc[cb][8 + 2 * e + 1], s1[e]);
+                    }
+                    const int px = half * 64 + cb * 32 + l31, c0 = 4 * wave + 2 * lh;
+                    *reinterpret_cast<u32x4 *>(lds + T2_H + h2_off(px, c0, 512)) = o0;
+                    *reinterpret_cast<u32x4 *>(lds + T2_H + h2_off(px, c0 + 1, 512)) = o1;
+                }
+            }
+        }
+        __syncthreads();                                        // B: hidden tile complete, input tile dead
+        load_input(tile + gridDim.x);                           // (the next tile's input: in flight under layer 2 -- its 32 registers are free now)
+        // ---- layer 2 (fp16, K = 256, no activation) + output -----------------------------------------------------------------------
+        if (active2) {
+            float *ot = reinterpret_cast<float *>(lds + T2_IN + wave * 8192);      // [32 ch][64 px] fp32, wave-private
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                f16x8 q[3];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) q[i] = *reinterpret_cast<const f16x8 *>(hrow + (2 * half + (i & 1)) * (32 * 512) + piece(i >> 1));
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const int cb = i & 1, s = i >> 1;
+                    if (i + 2 < 32)
+                        q[(i + 2) % 3] = *reinterpret_cast<const f16x8 *>(hrow + (2 * half + ((i + 2) & 1)) * (32 * 512) + piece((i + 2) >> 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[s], q[i % 3], s == 0 ? zero16 : acc[cb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (half) __builtin_amdgcn_wave_barrier();          // (the wave's reads of the previous half's transposition are done: LDS is in order per wave)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) ot[(16 * lh + j) * 64 + cb * 32 + l31] = acc[cb][j];
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                const int mq = m0 + 64 * half;
+                if (a.HW % 64 == 0 && mq + 64 <= a.M) {
+                    // buffer stores: base = the image's planes, voffset = the lane's (channel row, 4-pixel piece) -- the same for every
+                    // tile -- soffset = the half tile's first pixel + 4 channel rows per step; rows past Cout fall outside the
+                    // resource's range and are dropped by the hardware
+                    const int img = mq / a.HW, p0 = mq - img * a.HW;
+                    const __amdgpu_buffer_rsrc_t ro = make_rsrc(a.out + (size_t)img * a.out_img_stride, (unsigned)a.Cout * a.HW * 4);
+                    const unsigned vo = (unsigned)(((32 * wave + (lane >> 4)) * a.HW + (lane & 15) * 4) * 4);
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {                 // 32 channels x 16 pieces of 4 pixels = 8 x 64 lanes
+                        const int c = (lane >> 4) + 4 * kk;
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(ot + c * 64 + (lane & 15) * 4) + sh2[32 * wave + c];
+                        buf_store_f32x4_nop(v, ro, vo, (unsigned)((p0 + kk * 4 * a.HW) * 4));
+                    }
+                } else {
+                    for (int i = lane; i < 32 * 64; i += 64) {
+                        const int c = i >> 6, m = mq + (i & 63), ch = 32 * wave + c;
+                        if (m < a.M && ch < a.Cout) {
+                            const int img = m / a.HW, pp = m - img * a.HW;
+                            a.out[(size_t)img * a.out_img_stride + (size_t)ch * a.HW + pp] = ot[i] + sh2[ch];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();                                        // E: input region (transposition) and hidden tile are free
+    }
+}
+
+extern "C" int m3d_head_tail2_bf16_forward(const m3d_tail2_bf16_desc *d, m3d_stream_t stream)
+{
+    M3D_REQUIRE(d && d->in && d->waf && d->wbf && d->out && d->t1 && d->t2, "head_tail2_bf16: null pointer");
+    M3D_REQUIRE(d->in_cs % 8 == 0 && d->in_cs >= 256 && ((uintptr_t)d->in & 15) == 0, "head_tail2_bf16: 256 input channels, 16-byte aligned rows");
+    M3D_REQUIRE(d->Cout >= 1 && d->Cout <= 256 && d->M >= 1 && d->HW >= 1, "head_tail2_bf16: bad sizes (Cout <= 256)");
+    M3D_REQUIRE((((uintptr_t)d->waf | (uintptr_t)d->wbf) & 15) == 0, "head_tail2_bf16: 16-byte aligned weights");
+    Tail2Args a;
+    a.in = d->in; a.waf = d->waf; a.wbf = d->wbf; a.t1 = d->t1; a.t2 = d->t2; a.out = d->out; a.out_img_stride = d->out_img_stride;
+    a.in_cs = d->in_cs; a.M = (int)d->M; a.HW = d->HW; a.Cout = d->Cout; a.tiles_m = cdiv(d->M, 128);
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    }
+    static int scratch = -1;
+    if (scratch < 0) {
+        hipFuncAttributes fa;
+        M3D_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&bf16_tail2_kernel)));
+        scratch = (int)fa.localSizeBytes;
+    }
+    M3D_REQUIRE(scratch == 0, "head_tail2_bf16: the kernel was built with register spills (%d bytes of scratch)", scratch);
+    hipLaunchKernelGGL(bf16_tail2_kernel, dim3(std::max(1, std::min(a.tiles_m, ncu))), dim3(512), 0, (hipStream_t)stream, a);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
 extern "C" int m3d_head_mlp2_bf16_forward(const m3d_head2_bf16_desc *d, m3d_stream_t stream)
 {
     M3D_REQUIRE(d && d->in && d->w1f && d->w2f && d->w3 && d->out && d->t1 && d->t2 && d->t3, "head_mlp2_bf16: null pointer");

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _hip
-from ._hip import ConvBf16Desc, Head2Bf16Desc, HeadBf16Desc
+from ._hip import ConvBf16Desc, Head2Bf16Desc, HeadBf16Desc, Tail2Bf16Desc
 from .engine import BN_EPS, PSP_SIZES, Engine, OpCost, _Plan, _rup
 
 BF16 = torch.bfloat16
@@ -111,6 +111,18 @@ def pack_head2(heads, device):
         tt[:co] = f(b3)
         t3.append(tt)
     return tuple(torch.stack(x).to(device).contiguous() for x in (w1f, w2f, w3p, t1, t2, t3))
+
+
+def pack_tail2(wa, sa, ta, wb, sb, tb, device):
+    """Operands of m3d_head_tail2_bf16_forward: wa [256,256] (+ scale sa, shift ta: 1x1 256 -> 256, LeakyReLU behind it), wb [Cout,256]
+    (+ sb, tb: 1x1 256 -> Cout) fp32 -> (waf bf16, wbf fp16 fragments [8][16][64][8], t1 [256], t2 [256]) with the scales folded."""
+    f = lambda t: t.detach().float().cpu()                    # noqa: E731
+    co = wb.shape[0]
+    wbp, t2 = torch.zeros(256, 256), torch.zeros(256)
+    wbp[:co] = f(wb).reshape(co, 256) * f(sb)[:, None]
+    t2[:co] = f(tb)
+    return (_head2_frag(f(wa).reshape(256, 256) * f(sa)[:, None], BF16).to(device), _head2_frag(wbp, torch.float16).to(device),
+            f(ta).to(device).contiguous(), t2.to(device).contiguous())
 
 
 class View16:
@@ -570,11 +582,27 @@ class EngineBF16(Engine):
         # cls head: 3x3 128 -> 256, 1x1 256 -> 256, 1x1 256 -> NC*A (planar fp32)
         c1 = self._buf16(plan, B, fh, fw, 256)
         self._pconv(plan, "cls.0", P["cls.0"], feats0, c1, 1, 1, act=1)
-        c2 = self._buf16(plan, B, fh, fw, 256)
-        self._pconv(plan, "cls.3", P["cls.3"], c1, c2, 1, 0, act=1)
         pc = P["cls.6"]
-        self._conv16(plan, "cls.6", c2, None, wgt=pc.wp, kpad=pc.kpad, cout=pc.cout, cout_pad=pc.cout_pad, scale=pc.scale,
-                     shift=pc.shift, planar=(cls_pl, NC * A * HW, 0), cin=256)
+        if FUSED_HEADS and HEADS2 and P["cls.3"].cout == 256 and P["cls.3"].cin == 256 and P["cls.3"].kh == 1 and pc.cout <= 256:
+            # cls.3 + cls.6 in one launch (csrc/bf16_head_mlp2.hip: bf16_tail2_kernel), weights resident in registers
+            if "cls.tail2" not in P:
+                sd = self.sd
+                P["cls.tail2"] = pack_tail2(sd["cls.3.weight"], P["cls.3"].scale, P["cls.3"].shift,
+                                            sd["cls.6.weight"], pc.scale, pc.shift, self.device)
+            pk = P["cls.tail2"]
+            d = Tail2Bf16Desc()
+            d.inp, d.in_cs, d.M = c1.ptr, c1.cs, B * HW
+            d.waf, d.wbf, d.t1, d.t2 = (t.data_ptr() for t in pk)
+            d.Cout, d.out, d.out_img_stride, d.HW = pc.cout, cls_pl.data_ptr(), NC * A * HW, HW
+            ref = ctypes.byref(d)
+            plan.keep += list(pk)
+            plan.ops.append(("cls.3+cls.6", "bf16_tail2", 2.0 * B * HW * (256 * 256 + 256 * pc.cout),
+                             lambda st: _hip.check(L.m3d_head_tail2_bf16_forward(ref, st)), d))
+        else:
+            c2 = self._buf16(plan, B, fh, fw, 256)
+            self._pconv(plan, "cls.3", P["cls.3"], c1, c2, 1, 0, act=1)
+            self._conv16(plan, "cls.6", c2, None, wgt=pc.wp, kpad=pc.kpad, cout=pc.cout, cout_pad=pc.cout_pad, scale=pc.scale,
+                         shift=pc.shift, planar=(cls_pl, NC * A * HW, 0), cin=256)
         sel_idx = torch.empty(B * HW, device=self.device, dtype=torch.int32)
         sel_prob = torch.empty(B * HW, device=self.device, dtype=torch.float32)
         plan.keep += [sel_idx, sel_prob]

@@ -443,6 +443,39 @@ def test_fused_head_mlp_bf16_matches_torch_chain(G, n, h, w, cout, form):
         assert e < 4e-3 * (1.0 + ref.abs().max().item()), (gi, e)      # a hidden value may round to the neighbouring bf16
 
 
+@pytest.mark.parametrize("n,h,w,cout", [(2, 8, 16, 144), (1, 13, 21, 144), (3, 48, 160, 144), (1, 8, 8, 256), (2, 4, 16, 20)])
+def test_head_tail2_bf16_matches_torch_chain(n, h, w, cout):
+    """m3d_head_tail2_bf16_forward (cls.3 + cls.6: 256 -> 256 + affine + LeakyReLU -> 256 -> Cout + affine in one launch) against the
+    torch chain on the bf16-rounded input / weights (hidden map rounded to bf16 in the reference; the kernel keeps it in fp16 and folds
+    the scales into the weights: inside the bound of the 3-layer heads).  Ragged tiles, several tiles per workgroup, Cout = 256 / 20."""
+    from m3dssd_amd import _hip
+    from m3dssd_amd.engine_bf16 import pack_tail2
+    L, dev = _hip.lib(), _dev()
+    g = torch.Generator().manual_seed(n * 100 + h + cout)
+    x = _r(torch.randn(n, 256, h, w, generator=g))
+    M, HW = n * h * w, h * w
+    xin = _nhwc16(x, 264)
+    wa = _r(torch.randn(256, 256, generator=g) / 16)
+    wb = _r(torch.randn(cout, 256, generator=g) / 16)
+    sa, ta = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.1
+    sb, tb = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    out = torch.full((n, cout + 1, HW), 512.0, device=dev)
+    pk = pack_tail2(wa, sa, ta, wb, sb, tb, dev)
+    d = _hip.Tail2Bf16Desc()
+    d.inp, d.in_cs, d.M = xin.data_ptr(), 264, M
+    d.waf, d.wbf, d.t1, d.t2 = (t.data_ptr() for t in pk)
+    d.Cout, d.out, d.out_img_stride, d.HW = cout, out.data_ptr(), (cout + 1) * HW, HW
+    _hip.check(L.m3d_head_tail2_bf16_forward(ctypes.byref(d), _st()))
+    torch.cuda.synchronize()
+    got = out.cpu()
+    assert (got[:, cout] == 512.0).all()
+    xf = x.permute(0, 2, 3, 1).reshape(M, 256)
+    h1 = _r(F.leaky_relu(xf @ wa.T * sa + ta, 0.01))
+    ref = (h1 @ wb.T * sb + tb).view(n, HW, cout).permute(0, 2, 1)
+    e = (got[:, :cout] - ref).abs().max().item()
+    assert e < 4e-3 * (1.0 + ref.abs().max().item()), e
+
+
 @pytest.mark.parametrize("B,h,w,keys", [(2, 8, 16, 337), (1, 16, 40, 337), (3, 8, 32, 85)])
 def test_anab_attend_bf16_matches_torch(B, h, w, keys):
     """m3d_anab_attend_bf16 (logits + softmax + P.V + residual + affine + LeakyReLU in one launch, attention.py:207-211) against
@@ -853,11 +886,11 @@ def test_bf16_network_matches_fp32_oracle_within_stated_tolerance(crop, B, pad):
     # recompute cls.6 in fp32 (torch, fp32 weights) from the engine's bf16 hidden map and count the top-1 decisions that still differ
     # from the free-running oracle's.  The softmax / fg_prob / top-1 already run in fp32 on fp32 logits (m3d_anchor_select).
     sd = synth.synth_state_dict(0)
-    c2 = [op for op in plan.ops if op[0] == "cls.6"][0][4]
-    fh, fw = crop[0] // 8, crop[1] // 8
+    c2 = [op for op in plan.ops if op[0] == "cls.6"]           # (the fused cls.3 + cls.6 launch of round 5 keeps the hidden map in LDS: the
+    fh, fw = crop[0] // 8, crop[1] // 8                         # experiment runs on the unfused plan, M3D_BF16_HEADS2=0; measured: 182 of 199)
     hidden = None                        # the plan-owned bf16 buffer cls.6 reads (256 channels per pixel)
     for t in plan.keep:
-        if torch.is_tensor(t) and t.data_ptr() == c2.inp:
+        if c2 and torch.is_tensor(t) and t.data_ptr() == c2[0][4].inp:
             hidden = t
     if hidden is not None:
         h = hidden.view(B, fh, fw, 256).float().permute(0, 3, 1, 2)
