@@ -379,16 +379,12 @@ def main():
     args = parse_args()
     # ONE JSON line on stdout, whatever the libraries print: RCCL writes its version banner to the C stdout when a communicator is
     # created (seen behind the JSON line of a run with the one-rank collective leg).  File descriptor 1 points at stderr for the
-    # whole run; the line goes to the saved descriptor at the end.
+    # whole run (and is NOT restored: RCCL's banner sits in the C library's stdout buffer until the process exits); the line goes
+    # to the saved descriptor.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    try:
-        return _main(args, real_stdout)
-    finally:
-        sys.stdout.flush()
-        os.dup2(real_stdout, 1)
-        os.close(real_stdout)
+    return _main(args, real_stdout)
 
 
 def _main(args, real_stdout):
@@ -815,7 +811,8 @@ def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=N
                                                                      "accumulation / epilogues" if bf16 else "fp32"),
                        "per_gpu_batch": B, "global_batch": B * world, "resolution": [CROP[1], CROP[0]],
                        "parallelism": "dp%d (batch sharded, 1 all-gather of [B,40,14] detections)" % world},
-            "launch": ("hipGraph replay, detect(k-1) overlapped with forward(k)" if use_pipe else
+            "launch": ("hipGraph replay, detect(k-1) overlapped with forward(k); the timed graph runs m3d_score_keys_planar + planar decode "
+                       "where the eager per-kernel breakdown below shows `bundle`" if use_pipe else
                        "hipGraph replay" if use_graph else "eager"),
             # Winograd F(2x2,3x3) launches: `achieved` counts the MFMA FLOPs the kernel EXECUTES (16 multiplies per 2x2 output
             # tile and channel pair = the direct-convolution count / 2.25), so frac is the MFMA-pipe utilisation and cannot

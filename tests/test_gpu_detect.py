@@ -1,30 +1,427 @@
-"""GPU tests of the detection stage behind the forward (-m gpu): the planar form that the pipelined
-detector runs (sort keys from the planar class logits, top-N-pre rows decoded from the planar staging the heads write) against the
-bundled form (m3d_bundle_outputs + m3d_topk_decode_scaled) that is itself pinned to the reference's im_detect_3d golden rows in
-tests/test_gpu_parity.py.  Integer / row identity: bit for bit."""
+"""GPU tests (-m gpu; every check goes through the C ABI of libm3dssd_hip.so) of the detection stage behind the forward: score keys and top-k / decode (planar and
+bundled forms), NMS (bit-exact against the reference's py_cpu_nms goldens), row selection, the pipelined detector incl. the fed uint8 form
+and the 3-D refinement.
+Re-filed by component in round 5 (before: per-round files); tolerances are stated at the checks."""
+import collections
 import ctypes
+import json
+import os
+import socket
+import subprocess
+import sys
+import time
 
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
+from torch import nn
 
-from m3dssd_amd import synth
+from m3dssd_amd import _hip, synth
+from gpu_common import *  # noqa: F401,F403
 
 pytestmark = pytest.mark.gpu
 
 
-def _dev():
-    if not torch.cuda.is_available():
-        pytest.fail("no ROCm device visible: the gpu-marked tests must run on the MI355X box")
-    return torch.device("cuda:0")
+def test_nms_collisions_and_disjoint_sets():
+    """Domain edge cases of lib/nms (nms_kernel.cu:24-144): identical boxes -> only the first in score order survives;
+    pairwise disjoint boxes -> all survive; IoU exactly at the threshold is kept (suppression is strict '>')."""
+    from m3dssd_amd.host import ops
+    dev = _dev()
+    same = np.tile(np.array([[10.0, 20.0, 60.0, 90.0, 0.0]], dtype=np.float32), (130, 1))
+    same[:, 4] = np.linspace(0.9, 0.1, 130, dtype=np.float32)
+    keep, num = ops.nms_sorted(torch.from_numpy(same).to(dev), 0.4)
+    assert int(num[0]) == 1 and int(keep[0, 0]) == 0
+    grid = np.array([[100.0 * i, 50.0 * j, 100.0 * i + 40, 50.0 * j + 30, 1.0 - 0.001 * (i * 20 + j)]
+                     for i in range(12) for j in range(20)], dtype=np.float32)
+    keep, num = ops.nms_sorted(torch.from_numpy(grid).to(dev), 0.4)
+    assert int(num[0]) == len(grid) and np.array_equal(keep[0, :len(grid)].cpu().numpy(), np.arange(len(grid)))
+    # two boxes with IoU exactly 1/3 (areas 100 px each incl. the +1 convention, overlap 50): kept at thresh 1/3
+    pair = np.array([[0, 0, 9, 9, 0.9], [5, 0, 14, 9, 0.8]], dtype=np.float32)
+    assert int(ops.nms_sorted(torch.from_numpy(pair).to(dev), 50.0 / 150.0)[1][0]) == 2
+    assert int(ops.nms_sorted(torch.from_numpy(pair).to(dev), 0.33)[1][0]) == 1
 
 
-def _net(crop, B, dtype="f32"):
+# ------------------------------------------------------------------------------------ NMS
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 300, 3000])
+def test_nms_bit_exact_vs_reference_golden(n):
+    from lib.nms.gpu_nms import gpu_nms
+    _dev()
+    g = np.load(os.path.join(GOLDEN, "nms.npz"))
+    keep = gpu_nms(g["dets_%d" % n], 0.4, 0)
+    assert np.array_equal(np.asarray(keep, dtype=np.int64), g["keep_%d" % n])
+
+
+@pytest.mark.parametrize("thr", [0.0, 0.25, 0.4, 0.5, 1.0])
+def test_nms_threshold_ties_bit_exact(thr):
+    from lib.nms.gpu_nms import gpu_nms
+    _dev()
+    g = np.load(os.path.join(GOLDEN, "nms.npz"))
+    assert np.array_equal(np.asarray(gpu_nms(g["dets_grid"], thr), dtype=np.int64), g["keep_grid_%g" % thr])
+
+
+def test_nms_batched_device_api_and_properties():
+    """Batched device entry == oracle per image; idempotence: NMS of the kept set keeps everything."""
+    from m3dssd_amd.host import ops
+    from oracle import nms as onms
+    dev = _dev()
+    B, n = 5, 3000
+    dets = np.stack([synth.synth_boxes(n, seed=100 + i) for i in range(B)])
+    order = np.stack([onms.order_desc_stable(d[:, 4]) for d in dets])
+    srt = np.stack([d[o] for d, o in zip(dets, order)])
+    keep, num = ops.nms_sorted(torch.from_numpy(srt).to(dev), 0.4)
+    keep, num = keep.cpu().numpy(), num.cpu().numpy()
+    for i in range(B):
+        ref = onms.nms_sorted(srt[i], 0.4)
+        assert num[i] == len(ref) and np.array_equal(keep[i, :num[i]], ref)
+        kept = srt[i][ref]
+        k2, n2 = ops.nms_sorted(torch.from_numpy(kept).to(dev), 0.4)
+        assert int(n2[0]) == len(ref) and np.array_equal(k2[0, :len(ref)].cpu().numpy(), np.arange(len(ref)))
+    assert ops.nms_sorted(torch.zeros(0, 5, device=dev), 0.4)[1].item() == 0
+    assert gpu_nms_empty() == []
+
+
+# ------------------------------------------------------------------------------------ detection
+def test_detect_matches_oracle_given_same_network_outputs():
+    """decode + top-k + NMS on the device vs oracle/detect.py fed with the ENGINE's network outputs:
+    kept anchors/classes identical, coordinates to fp32 roundoff."""
+    from lib.rpn_util import im_detect_3d, detect_batch
     from model.M3d_inference_align import build
+    from oracle import detect as odet
+    dev = _dev()
+    crop, B = (128, 320), 2
     conf = synth.synth_conf(crop, 0, batch_size=B, device="cuda:0")
     net = build(conf, "test")
     net.load_state_dict(synth.synth_state_dict(0))
-    return net.to(_dev()).set_compute_dtype(dtype), conf
+    net = net.to(dev)
+    x = synth.synth_frames(B, crop, 1234)
+    ab = im_detect_3d(x[0], net, conf)
+    with torch.no_grad():
+        cls, prob, b2, b3, fs, rois = (t.cpu() for t in net(x[:1].to(dev)))
+    ref, keep, top = odet.detect_image(prob[0], b2[0], b3[0], rois, conf)
+    assert ab.shape == ref.shape
+    assert np.array_equal(ab[:, 13], ref[:, 13]) and np.array_equal(ab[:, 5], ref[:, 5])
+    # pure fp32 decode arithmetic on IDENTICAL network outputs: per column, to fp32 roundoff (expf differs by an ulp or two)
+    assert (np.abs(ab - ref) <= 1e-4 * (1.0 + np.abs(ref))).all(), np.abs((ab - ref) / (1.0 + np.abs(ref))).max(0)
+    dets, counts = detect_batch(net, x.to(dev), conf)
+    assert dets.shape == (B, conf.nms_topN_post, 14) and counts.shape == (B,)
+    k = int(counts[0])
+    assert k == min(len(ref), conf.nms_topN_post)
+    assert (np.abs(dets[0, :k].cpu().numpy() - ref[:k]) <= 1e-4 * (1.0 + np.abs(ref[:k]))).all()
+    assert dets[0, k:].abs().max().item() == 0 if k < conf.nms_topN_post else True
+
+
+def test_pipelined_detector_matches_detect_batch():
+    """forward(k) overlapped with detect(k-1) in one hipGraph: same detections as the sequential path."""
+    from lib.rpn_util import detect_batch
+    from m3dssd_amd.pipeline import PipelinedDetector
+    from model.M3d_inference_align import build
+    dev = _dev()
+    conf = synth.synth_conf((128, 320), 0, batch_size=2, device="cuda:0")
+    net = build(conf, "test")
+    net.load_state_dict(synth.synth_state_dict(0))
+    net = net.to(dev)
+    xs = [synth.synth_frames(2, (128, 320), 20 + i).to(dev) for i in range(3)]
+    ref = []
+    for x in xs:
+        d, c = detect_batch(net, x, conf)
+        ref.append((d.clone(), c.clone()))
+    pipe = PipelinedDetector(net, conf, 2, 128, 320)
+    got = []
+    for x in xs:
+        r = pipe.step(x)
+        if r is not None:
+            got.append((r[0].clone(), r[1].clone()))
+    r = pipe.flush()
+    got.append((r[0].clone(), r[1].clone()))
+    assert pipe.flush() is None
+    assert len(got) == 3
+    for (gd, gc), (rd, rc) in zip(got, ref):
+        assert torch.equal(gc, rc) and torch.equal(gd, rd)
+    # refine mode: the post-NMS refinement of test_kitti_3d inside the same captured graph, with the calibration / scale / clip
+    # size of batch k-1 while batch k is in flight == the eager call on detect_batch's rows, bit for bit
+    from m3dssd_amd.host import refine as HR
+    p2 = np.array([[721.5377, 0.0, 609.5593, 44.85728], [0.0, 721.5377, 172.854, 0.2163791], [0.0, 0.0, 1.0, 0.002745884],
+                   [0.0, 0.0, 0.0, 1.0]])
+    metas = [{"p2": np.stack([p2, p2 * np.array([[1.0 + 0.01 * i], [1.0], [1.0], [1.0]])]),
+              "scale": np.array([1.0, 0.9 - 0.1 * i], np.float32), "clip_wh": np.array([[0, 0], [300, 100 + i]], np.float32)}
+             for i in range(3)]
+    pipe = PipelinedDetector(net, conf, 2, 128, 320, refine=True)
+    with pytest.raises(RuntimeError):
+        pipe.step(xs[0])                                   # refine mode needs the batch's meta
+    outs = []
+    for x, m in zip(xs, metas):
+        r = pipe.step(x, meta=m)
+        if r is not None:
+            outs.append(tuple(t.clone() for t in r))
+    outs.append(tuple(t.clone() for t in pipe.flush()))
+    assert len(outs) == 3
+    from m3dssd_amd.host.detect import detect_batch as _db
+    n_changed = 0
+    for (gd, gc, gr), (rd, rc), m, x in zip(outs, ref, metas, xs):
+        # the frames' scale factors divide the boxes inside the decode, BEFORE the NMS (lib/rpn_util.py:1506-1507): the pipelined
+        # rows equal the eager detection with the same factors; image 0 (factor 1) equals the unscaled reference bit for bit
+        sd, sc = (t.clone() for t in _db(net, x, conf, scale=m["scale"]))
+        assert torch.equal(gc, sc) and torch.equal(gd, sd)
+        assert torch.equal(gd[0], rd[0]) and int(gc[0]) == int(rc[0])
+        n_changed += int(not torch.equal(gc, rc))
+        want = HR.refine_detections(sd, sc, m["p2"], hill_climbing=bool(getattr(conf, "hill_climbing", True)), scale=None,
+                                    clip_wh=m["clip_wh"])
+        assert gr.shape == want.shape and torch.equal(gr, want)
+        assert float(gr[:, :, 0].sum()) > 0                # some rows were refined
+
+
+# ------------------------------------------------------------------------------------ post-NMS 3-D refinement (8f row 2)
+def test_refine_3d_matches_oracle_and_reference_text():
+    """m3d_refine_3d (one thread per detection, float64) vs oracle.refine and the reference golden: refined values to 1e-9,
+    identical hill-climb outcomes, and the KITTI text (6 decimals) identical to what the reference's functions produce."""
+    from m3dssd_amd.host import refine as HR
+    from oracle import refine as R
+    dev = _dev()
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "refine.npz"))
+    p2, rows = g["p2"], g["rows"]
+    lbls = ["Car", "Pedestrian", "Cyclist"]
+    # batch of 2 images: 40 + 8 rows (second image padded with garbage past its count)
+    dets = np.zeros((2, 40, 14), dtype=np.float32)
+    dets[0] = rows[:40]
+    dets[1, :8] = rows[40:]
+    dets[1, 8:] = 123.0
+    counts = torch.tensor([40, 8], dtype=torch.int32, device=dev)
+    out = HR.refine_detections(torch.from_numpy(dets).to(dev), counts, p2).cpu().numpy()
+    p2_inv = np.linalg.inv(p2)
+    for b, sl in ((0, range(0, 40)), (1, range(40, 48))):
+        for k, i in enumerate(sl):
+            o = out[b, k]
+            if rows[i][4] >= 0.75:
+                want = np.array(R.refine_row(rows[i], p2, p2_inv))
+                assert o[0] == 1.0 and o[1] == rows[i][5]
+                assert np.abs(o[2:15] - want).max() < 1e-9, (i, o[2:15], want)
+                assert np.abs(o[2:15] - g["refined"][i]).max() < 1e-9
+            else:
+                assert not o.any()
+    assert not out[1, 8:].any()
+    text = HR.kitti_text(out[0], lbls) + HR.kitti_text(out[1], lbls)
+    assert text == str(g["text"])
+    assert text == R.kitti_text(rows, p2, lbls, nms_topn_post=48)
+    # no hill climbing: only the two angle conversions and the back-projection
+    out0 = HR.refine_detections(torch.from_numpy(dets).to(dev), counts, p2, hill_climbing=False).cpu().numpy()
+    want0 = np.array(R.refine_row(rows[0], p2, p2_inv, hill_climbing=False))
+    assert (rows[0][4] < 0.75 and not out0[0, 0].any()) or np.abs(out0[0, 0, 2:15] - want0).max() < 1e-9
+    with pytest.raises(NotImplementedError):
+        HR.refine_detections(torch.from_numpy(dets), counts.cpu(), p2)
+
+
+@pytest.mark.parametrize("name,R,k", TOPK_CASES)
+def test_topk_decode_matches_stable_sort(name, R, k):
+    """rows = the first k of `descending score, ascending row among equals` (oracle/nms.py:order_desc_stable, the total order
+    the reference's unstable argsort()[::-1] is one instance of); aboxes = m3d_decode_rows of those rows, bit for bit."""
+    from m3dssd_amd import _hip
+    from oracle import nms as onms
+    L = _hip.lib()
+    dev = _dev()
+    g = torch.Generator().manual_seed(len(name) * 1000 + R)
+    if name == "all_equal":
+        scores = torch.full((R,), 0.731)
+    elif name == "16_levels":
+        scores = torch.randint(0, 16, (R,), generator=g).float() / 16.0
+    elif name == "ties_at_cut":
+        scores = torch.rand(R, generator=g)
+        scores[torch.randperm(R, generator=g)[:8000]] = 0.95       # the cut at k = 3000 falls inside a block of equal scores
+    elif name == "negative_and_zero":
+        scores = torch.randn(R, generator=g)
+        scores[::7] = 0.0
+        scores[3::11] = -0.0
+    else:
+        scores = torch.rand(R, generator=g) ** 6                   # most rows near 0 like real fg probabilities
+    A = 36
+    prob, b2, b3, rois, anchors, means, stds = _topk_inputs(R, A, R + k, scores)
+    bits32 = _sortable_bits(scores)
+    bits_dev = torch.from_numpy(bits32.numpy().astype(np.uint32).view(np.int32)).to(dev)
+    d = [t.to(dev).contiguous() for t in (prob, b2, b3, rois, anchors, means, stds)]
+    ab = torch.empty(1, k, 14, device=dev)
+    rows = torch.empty(1, k, device=dev, dtype=torch.int32)
+    nb = L.m3d_topk_decode_workspace_bytes(1, R)
+    ws = torch.empty(nb, device=dev, dtype=torch.uint8)
+    _hip.check(L.m3d_topk_decode(bits_dev.data_ptr(), *[t.data_ptr() for t in d], ab.data_ptr(), rows.data_ptr(),
+                                 ws.data_ptr(), nb, 1, R, k, _stream()))
+    torch.cuda.synchronize()
+    # -0.0 sorts below +0.0 in the bit order; the stable-sort reference uses the same monotone key
+    key = bits32.numpy().astype(np.int64)
+    order = np.lexsort((np.arange(R), -key))[:k]
+    assert np.array_equal(rows[0].cpu().numpy().astype(np.int64), order), name
+    if name not in ("negative_and_zero",):
+        assert np.array_equal(order, onms.order_desc_stable(scores.numpy())[:k])
+    ref = torch.empty(1, k, 14, device=dev)
+    rows64 = torch.from_numpy(order[None].astype(np.int64)).to(dev)
+    _hip.check(L.m3d_decode_rows(rows64.data_ptr(), *[t.data_ptr() for t in d], ref.data_ptr(), 1, R, k, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(ab, ref)
+    # second run: bit-identical (integer atomics only)
+    ab2 = torch.empty_like(ab)
+    _hip.check(L.m3d_topk_decode(bits_dev.data_ptr(), *[t.data_ptr() for t in d], ab2.data_ptr(), None,
+                                 ws.data_ptr(), nb, 1, R, k, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(ab, ab2)
+
+
+def test_topk_decode_batched_and_argument_checks():
+    from m3dssd_amd import _hip
+    L = _hip.lib()
+    dev = _dev()
+    R, k, B = 5000, 700, 3
+    g = torch.Generator().manual_seed(5)
+    scores = torch.rand(B, R, generator=g)
+    bits = torch.from_numpy(_sortable_bits(scores).numpy().astype(np.uint32).view(np.int32)).to(dev)
+    prob = torch.zeros(B, R, 4)
+    prob[:, :, 1] = scores
+    b2, b3 = torch.randn(B, R, 4, generator=g), torch.randn(B, R, 7, generator=g)
+    _, _, _, rois, anchors, means, stds = _topk_inputs(R, 36, 1, scores[0])
+    d = [t.to(dev).contiguous() for t in (prob, b2, b3, rois, anchors, means, stds)]
+    ab = torch.empty(B, k, 14, device=dev)
+    rows = torch.empty(B, k, device=dev, dtype=torch.int32)
+    nb = L.m3d_topk_decode_workspace_bytes(B, R)
+    ws = torch.empty(nb, device=dev, dtype=torch.uint8)
+    _hip.check(L.m3d_topk_decode(bits.data_ptr(), *[t.data_ptr() for t in d], ab.data_ptr(), rows.data_ptr(), ws.data_ptr(),
+                                 nb, B, R, k, _stream()))
+    torch.cuda.synchronize()
+    for b in range(B):
+        order = np.lexsort((np.arange(R), -scores[b].numpy().astype(np.float64)))[:k]
+        assert np.array_equal(rows[b].cpu().numpy(), order)
+        assert torch.equal(ab[b, :, 4].cpu(), scores[b][order])
+    args = [bits.data_ptr(), *[t.data_ptr() for t in d], ab.data_ptr(), None, ws.data_ptr()]
+    assert L.m3d_topk_decode(*args, nb, B, R, 4097, _stream()) == -1          # k > 4096
+    assert L.m3d_topk_decode(*args, nb, B, R, R + 1, _stream()) == -1         # k > R  (R = 5000 > 4096 anyway)
+    assert L.m3d_topk_decode(*args, nb - 8, B, R, k, _stream()) == -3         # workspace too small
+    assert b"workspace" in L.m3d_last_error()
+
+
+def test_select_post_blocks():
+    from m3dssd_amd import _hip
+    L = _hip.lib()
+    dev = _dev()
+    B, n, post = 4, 300, 40
+    g = torch.Generator().manual_seed(9)
+    ab = torch.randn(B, n, 14, generator=g)
+    num = torch.tensor([0, 7, 40, 123], dtype=torch.int32)
+    keep = torch.stack([torch.randperm(n, generator=g).sort()[0] for _ in range(B)]).to(torch.int32)
+    block = torch.full((B, post + 1, 14), float("nan"), device=dev)
+    counts = torch.empty(B, dtype=torch.int32, device=dev)
+    _hip.check(L.m3d_select_post(ab.to(dev).data_ptr(), keep.to(dev).data_ptr(), num.to(dev).data_ptr(), B, n, post,
+                                 block.data_ptr(), counts.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    block = block.cpu()
+    assert counts.cpu().tolist() == [0, 7, 40, 40]
+    for b in range(B):
+        c = min(int(num[b]), post)
+        assert torch.equal(block[b, :c], ab[b][keep[b, :c].long()])
+        assert block[b, c:post].abs().max().item() == 0 if c < post else True
+        assert block[b, post, 0].item() == c and block[b, post, 1:].abs().max().item() == 0
+
+
+def test_conf_limits_are_checked_at_build_time():
+    from model.M3d_inference_align import build
+    conf = synth.synth_conf((128, 320), 0, batch_size=1, device="cuda:0")
+    conf.nms_topN_pre = 5000
+    with pytest.raises(ValueError, match="nms_topN_pre"):
+        build(conf, "test")
+
+
+def test_detect_full_size_matches_reference_golden():
+    """decode -> top-3000 -> NMS on the HIP path at 1280x384 against the rows the REFERENCE's im_detect_3d produced
+    (tests/golden/detect_384x1280.npz, tools/gen_golden.py): kept anchors / classes identical, every column within
+    2e-3 * (1 + |ref|) (the network outputs feeding the decode carry the forward's own fp32 roundoff)."""
+    from lib.rpn_util import im_detect_3d
+    from model.M3d_inference_align import build
+    dev = _dev()
+    crop = (384, 1280)
+    conf = synth.synth_conf(crop, 0, batch_size=1, device="cuda:0")
+    net = build(conf, "test")
+    net.load_state_dict(synth.synth_state_dict(0))
+    net = net.to(dev)
+    x = synth.synth_frames(1, crop, 1234, pad_right_third=True)
+    ab = im_detect_3d(x[0], net, conf)
+    ref = np.load(os.path.join(GOLDEN, "detect_384x1280.npz"))["aboxes"]
+    assert ab.shape == ref.shape
+    assert np.array_equal(ab[:, 13], ref[:, 13]) and np.array_equal(ab[:, 5], ref[:, 5])
+    err = np.abs(ab - ref) / (1.0 + np.abs(ref))
+    _log("detect_full_size_golden", dict(max_rel=float(err.max()), per_col=[float(v) for v in err.max(0)]))
+    assert err.max() < 2e-3
+
+
+@pytest.mark.parametrize("backend", ["nccl", "gloo"])
+def test_two_ranks_detect_and_gather_equal_single_process(tmp_path, backend):
+    """The N > 1 path end to end with 2 processes: shard the batch, forward + decode + top-k + NMS per rank on the HIP path,
+    ONE all-gather of the [b, 41, 14] blocks, every rank ends with the detections of the whole batch -- identical to the
+    single-process result.  backend nccl = RCCL (the production backend; both ranks share the one leased GPU, which RCCL
+    may refuse as a duplicate device -- then the RCCL leg is reported as skipped and the gloo leg still covers the path)."""
+    res = _run_ranks(tmp_path, backend)
+    if res.returncode != 0 and backend == "nccl" and (res.timed_out or "uplicate GPU" in res.stdout
+                                                      or "invalid usage" in res.stdout or "ncclInvalidUsage" in res.stdout
+                                                      or "needs one device per" in res.stdout):   # m3dssd_amd.dist's own check
+        _log("two_ranks_nccl", dict(status="refused by RCCL: two ranks on one device", tail=res.stdout[-600:]))
+        pytest.skip("RCCL refuses two ranks on the same device (single leased GPU)")
+    assert res.returncode == 0, res.stdout[-3000:]
+    rd, rc = _single_process_reference()
+    for r in range(2):
+        g = np.load(str(tmp_path / ("rank%d.npz" % r)))
+        assert np.array_equal(g["counts"], rc), (r, g["counts"], rc)
+        assert np.array_equal(g["dets"], rd)
+    _log("two_ranks_" + backend, dict(status="ok"))
+
+
+# ------------------------------------------------------------------------------------ NMS beyond the device reduce's 4096 rows
+@pytest.mark.parametrize("n", [4097, 6000, 12000])
+def test_nms_twin_has_no_row_limit(n):
+    """`_nms` (lib/nms/gpu_nms.hpp:1-2) has no row limit in the reference (nms_kernel.cu:91-144).  The on-device greedy reduce holds
+    4096 rows; larger inputs go through device masks + the reference's host pass and must give the oracle's keep list bit for bit."""
+    import numpy as np
+    from lib.nms.gpu_nms import gpu_nms
+    from oracle import nms as onms
+    rng = np.random.default_rng(n)
+    ctr = rng.uniform([0, 0], [1280, 384], (n, 2))
+    wh = rng.uniform([5, 5], [200, 150], (n, 2))
+    score = rng.permutation(n).astype(np.float64) / n
+    dets = np.concatenate([ctr - wh / 2, ctr + wh / 2, score[:, None]], 1).astype(np.float32)
+    got = gpu_nms(dets, 0.4, device_id=0)
+    want = onms.gpu_nms(dets, 0.4)
+    assert list(got) == list(want) and len(got) > 50
+
+
+def test_fed_uint8_pipeline_equals_detect_batch_of_each_frame_set():
+    from lib.rpn_util import detect_batch
+    from m3dssd_amd.pipeline import PipelinedDetector
+    dev = _dev()
+    net, conf = _net_dev()
+    B, fh, fw = 2, 120, 310                                 # frames smaller than the crop: the stem pads them (Preprocess)
+    rng = np.random.RandomState(3)
+    sets = [torch.from_numpy(rng.randint(0, 256, size=(B, fh, fw, 3)).astype(np.uint8)).pin_memory() for _ in range(5)]
+    want = []
+    for fr in sets:
+        d, c = detect_batch(net, fr.to(dev), conf)
+        want.append((d.clone(), c.clone()))
+    pipe = PipelinedDetector(net, conf, B, CROP[0], CROP[1], u8_frame=(fh, fw))
+    got = []
+    pipe.feed(sets[0])
+    for k in range(len(sets)):
+        if k + 1 < len(sets):
+            pipe.feed(sets[k + 1])                          # upload of batch k + 1 overlaps the graph of batch k
+        r = pipe.step_fed()
+        if r is not None:
+            got.append((r[0].clone(), r[1].clone()))
+    r = pipe.flush()
+    got.append((r[0].clone(), r[1].clone()))
+    assert len(got) == len(sets)
+    for k, ((d, c), (wd, wc)) in enumerate(zip(got, want)):
+        assert torch.equal(c, wc), "batch %d: counts differ" % k
+        assert torch.equal(d, wd), "batch %d: detections differ" % k
+    assert any(int(c.sum()) > 0 for _, c in want)
+    # the float input form of the same detector still works next to it and agrees with the uint8 path
+    with pytest.raises(RuntimeError):
+        pipe.feed(sets[0].to(torch.float32))
+    pipe.feed(sets[0])
+    pipe.feed(sets[1])
+    with pytest.raises(RuntimeError):
+        pipe.feed(sets[2])                                  # both buffers hold unsubmitted batches
 
 
 @pytest.mark.parametrize("crop,B", [((128, 320), 3), ((384, 1280), 2)])
@@ -35,7 +432,7 @@ def test_planar_keys_and_decode_equal_bundled_form(crop, B):
     from m3dssd_amd.host.detect import detect_from_outputs, detect_from_planar, score_keys_planar
     dev = _dev()
     L = _hip.lib()
-    net, conf = _net(crop, B)
+    net, conf = _net_dt(crop, B)
     x = synth.synth_frames(B, crop, 77).to(dev)
     with torch.no_grad():
         cls, prob, b2, b3, _, rois = net(x)
@@ -85,7 +482,7 @@ def test_pipelined_detector_planar_and_bundled_forms_equal_detect_batch(planar, 
     from lib.rpn_util import detect_batch
     from m3dssd_amd.pipeline import PipelinedDetector
     dev = _dev()
-    net, conf = _net((128, 320), 2, dtype)
+    net, conf = _net_dt((128, 320), 2, dtype)
     xs = [synth.synth_frames(2, (128, 320), 40 + i).to(dev) for i in range(4)]
     ref = []
     for x in xs:
@@ -104,3 +501,4 @@ def test_pipelined_detector_planar_and_bundled_forms_equal_detect_batch(planar, 
     for (gd, gc), (rd, rc) in zip(got, ref):
         assert torch.equal(gc, rc) and torch.equal(gd, rd)
         assert int(gc.sum()) > 0
+
