@@ -35,7 +35,7 @@ PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29
 CROP = (384, 1280)
 PER_GPU_BATCH = 8
 MFMA_FAMILIES = ("igemm", "wino", "head_mlp", "conv_wave", "bf16_conv", "bf16_halo", "bf16_wide", "bf16_anab", "bf16_dcn_patch",
-                 "bf16_head_mlp", "bf16_head2", "bf16_tail2", "bf16_frontend")
+                 "bf16_head_mlp", "bf16_head2", "bf16_tail2", "bf16_qkvs", "bf16_tree_entry", "bf16_frontend")
 # SURVEY 8d, per image: 105.8 GFLOP; activations 1003.6 MB (fp32) + outputs 21 MB + input 5.9 MB; weights 82.6 MB (fp32) per batch
 ALG_GFLOP_PER_IMAGE = 105.8
 ALG_MB_PER_IMAGE_F32 = 1003.6 + 21.0 + 5.9
@@ -157,6 +157,10 @@ def kernel_symbol(label):
         return "bf16_head2_kernel(Head2Args)"
     if label.startswith("bf16_tail2"):
         return "bf16_tail2_kernel(Tail2Args)"
+    if label.startswith("bf16_qkvs"):
+        return "bf16_qkvs_kernel(QkvsArgs)"
+    if label.startswith("bf16_tree_entry"):
+        return "void bf16_tree_entry_kernel<4, 2>(TreeEntryArgs)"
     if label.startswith("bf16_head_mlp"):
         return "bf16_head_mlp_kernel(HeadArgs)"
     if label.startswith("bf16_frontend2"):
@@ -198,7 +202,8 @@ def kernel_symbol(label):
 
 
 # engine family label prefix -> the kernel sources whose edit invalidates a PMC pass of that family (plus the shared headers)
-FAMILY_SOURCES = (("bf16_anab", ("bf16_anab.hip",)), ("bf16_head2", ("bf16_head_mlp2.hip",)), ("bf16_tail2", ("bf16_head_mlp2.hip",)), ("bf16_head_mlp", ("bf16_head_mlp.hip",)),
+FAMILY_SOURCES = (("bf16_anab", ("bf16_anab.hip",)), ("bf16_head2", ("bf16_head_mlp2.hip",)), ("bf16_tail2", ("bf16_head_mlp2.hip",)), ("bf16_qkvs", ("bf16_head_mlp2.hip",)),
+                  ("bf16_tree_entry", ("bf16_tree_entry.hip",)), ("bf16_head_mlp", ("bf16_head_mlp.hip",)),
                   ("bf16_frontend2", ("bf16_frontend2.hip",)), ("bf16_frontend", ("bf16_frontend.hip",)),
                   ("bf16_dcn_patch", ("bf16_dcn_patch.hip", "bf16_conv.hip")), ("bf16_wide", ("bf16_conv_wide.hip",)),
                   ("bf16_halo", ("bf16_conv.hip",)), ("bf16_conv", ("bf16_conv.hip",)), ("wino44", ("wino44_conv.hip",)),

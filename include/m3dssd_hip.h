@@ -231,6 +231,24 @@ int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t stream);
  * 5 = 3x3 with 128 x 128 wave tiles (bf16_conv3x3_wide_kernel; needs wgt_wave). */
 int m3d_conv_bf16_variant(const m3d_conv_bf16_desc *d);
 
+/* Entry of a DLA tree of the bf16 path in one launch (model/pose_dla_dcn.py:314-327, :107-121): bottom = MaxPool2d(2, 2)(x) (written
+ * when `bottom` is not NULL), res = affine(Conv1x1(bottom)) (Tree.project), t = LeakyReLU(affine(Conv3x3 stride 2 pad 1 (x)))
+ * (tree1.conv1) -- x is read once.  Cin % 32 == 0, Cout % 64 == 0, even H / W.  wfrag fp16 [Cout/32][Cin/32][10][2][64 lanes][8]:
+ * slice ws, chunk c, tap t (0..8 = 3x3 taps row-major, 9 = the 1x1), block b, lane l (row r = l % 16, k-group l / 16), element e =
+ * scale[ch] * W[ch][32 c + 8 (l / 16) + e][tap] with ch = 32 ws + 8 (r / 4) + 4 b + r % 4 (m3dssd_amd/engine_bf16.py:
+ * pack_tree_entry); shift1 / shiftp fp32 [Cout]; all views bf16 NHWC with pixel strides in elements (% 8 == 0). */
+typedef struct m3d_tree_entry_bf16_desc {
+    const void *in;
+    int in_cs, N, H, W, Cin, Cout;
+    const void *wfrag;
+    const float *shift1, *shiftp;
+    void *t; int t_cs;
+    void *res; int res_cs;
+    void *bottom; int bottom_cs;
+} m3d_tree_entry_bf16_desc;
+int m3d_tree_entry_bf16_applicable(const m3d_tree_entry_bf16_desc *d);
+int m3d_tree_entry_bf16_forward(const m3d_tree_entry_bf16_desc *d, m3d_stream_t stream);
+
 /* Fused 3-layer RPN head of the bf16 path (model/M3d_inference_align.py:77-210): [1x1 128 -> 256, affine, LeakyReLU] ->
  * [1x1 256 -> 256, affine, LeakyReLU] -> [1x1 256 -> Cout, affine] per 128-pixel tile in ONE launch, hidden activations in LDS.
  * `groups` heads that read the same map share the launch: weights bf16 row-major [groups][256][128], [groups][256][256],
@@ -286,6 +304,20 @@ typedef struct m3d_tail2_bf16_desc {
     int HW;
 } m3d_tail2_bf16_desc;
 int m3d_head_tail2_bf16_forward(const m3d_tail2_bf16_desc *d, m3d_stream_t stream);
+/* The bias-free 1x1 projections of ANAB (model/module/attention.py:169-173, 183-200) over one 128-channel input in one launch:
+ * wf bf16 fragments [16 row blocks][8 K-steps][64 lanes][8] (the layout of w1f above with the row blocks in the place of the waves)
+ * of the stacked matrix [query rows padded with zeros to q_rows | key | value (kv_rows in all) | gates (s_rows) | zeros up to 512];
+ * q bf16 [M][q_cs] gets all q_rows (the padding rows as zeros), kv bf16 [M][kv_cs], s fp32 [M][s_cs] = sigmoid(gates). */
+typedef struct m3d_qkvs_bf16_desc {
+    const void *in;
+    int in_cs;
+    long long M;
+    const void *wf;
+    void *q; int q_cs, q_rows;
+    void *kv; int kv_cs, kv_rows;
+    float *s; int s_cs, s_rows;
+} m3d_qkvs_bf16_desc;
+int m3d_anab_qkvs_bf16_forward(const m3d_qkvs_bf16_desc *d, m3d_stream_t stream);
 
 /* HBM-bound helpers of the bf16 path: NHWC bf16 views (pixel strides in bf16 elements, multiples of 8), fp32 arithmetic.
  * m3d_stem_conv7x7_bf16: DLA.base_layer from the fp32 [N][3][H][W] image (is_u8 = 0; img_h/img_w/mean3/stds3 ignored) or

@@ -104,6 +104,25 @@ class Tail2Bf16Desc(ctypes.Structure):
     ]
 
 
+class TreeEntryBf16Desc(ctypes.Structure):
+    """Mirror of ``m3d_tree_entry_bf16_desc``."""
+    _fields_ = [
+        ("inp", c_void_p), ("in_cs", c_int), ("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("Cout", c_int),
+        ("wfrag", c_void_p), ("shift1", c_void_p), ("shiftp", c_void_p),
+        ("t", c_void_p), ("t_cs", c_int), ("res", c_void_p), ("res_cs", c_int), ("bottom", c_void_p), ("bottom_cs", c_int),
+    ]
+
+
+class QkvsBf16Desc(ctypes.Structure):
+    """Mirror of ``m3d_qkvs_bf16_desc``."""
+    _fields_ = [
+        ("inp", c_void_p), ("in_cs", c_int), ("M", c_ll), ("wf", c_void_p),
+        ("q", c_void_p), ("q_cs", c_int), ("q_rows", c_int),
+        ("kv", c_void_p), ("kv_cs", c_int), ("kv_rows", c_int),
+        ("s", c_void_p), ("s_cs", c_int), ("s_rows", c_int),
+    ]
+
+
 P = c_void_p
 # name -> (restype, argtypes); every name here must be declared in include/m3dssd_hip.h
 SIGNATURES = {
@@ -115,6 +134,9 @@ SIGNATURES = {
     "m3d_conv_bf16_variant": (c_int, [ctypes.POINTER(ConvBf16Desc)]),
     "m3d_head_mlp_bf16_forward": (c_int, [ctypes.POINTER(HeadBf16Desc), P]),
     "m3d_head_mlp2_bf16_forward": (c_int, [ctypes.POINTER(Head2Bf16Desc), P]),
+    "m3d_tree_entry_bf16_applicable": (c_int, [ctypes.POINTER(TreeEntryBf16Desc)]),
+    "m3d_tree_entry_bf16_forward": (c_int, [ctypes.POINTER(TreeEntryBf16Desc), P]),
+    "m3d_anab_qkvs_bf16_forward": (c_int, [ctypes.POINTER(QkvsBf16Desc), P]),
     "m3d_head_tail2_bf16_forward": (c_int, [ctypes.POINTER(Tail2Bf16Desc), P]),
     "m3d_stem_conv7x7_bf16": (c_int, [P, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                       P, P, P, P, c_int, c_int, c_int, c_int, P]),

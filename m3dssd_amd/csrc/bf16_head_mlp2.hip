@@ -27,6 +27,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 #ifdef BF16_TRACE
 static long long *g_head2_trace = nullptr;
@@ -477,6 +478,132 @@ extern "C" int m3d_head_tail2_bf16_forward(const m3d_tail2_bf16_desc *d, m3d_str
     }
     M3D_REQUIRE(scratch == 0, "head_tail2_bf16: the kernel was built with register spills (%d bytes of scratch)", scratch);
     hipLaunchKernelGGL(bf16_tail2_kernel, dim3(std::max(1, std::min(a.tiles_m, ncu))), dim3(512), 0, (hipStream_t)stream, a);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The four bias-free 1x1 projections of ANAB (model/module/attention.py:169-173, 183-200: query 128 -> 168, key 128 -> 168, value
+// 128 -> 128, spatial gates 128 -> 4 + sigmoid) as ONE launch over the shared input: the stacked weight matrix [q | k | v | s] is
+// padded to 512 rows, wave w owns row blocks w and w + 8 (2 x 8 fragments = 64 registers, resident), a tile of 128 pixels runs as
+// two halves, and the epilogue writes every 8-row piece where it belongs: q bf16 [px][q_cs] (rows [168, 192) come out as exact zeros:
+// the logits GEMM reads them as K padding), k|v bf16 [px][kv_cs], gates fp32 [px][s_cs] through a sigmoid.  Three implicit-GEMM
+// launches (0.31 ms at bs 64, each re-reading the 126 MB input at 11-210 TFLOP/s) become one that is bound by its 0.6 GB of stores.
+#define QK_IN 0                     // [128 px][128 ch] bf16, 256-byte rows, swizzled
+#define QK_LDS 32768
+
+struct QkvsArgs {
+    const void *in;                 // bf16 [M][in_cs], first 128 channels
+    const void *wf;                 // bf16 fragments [16 row blocks][8 K-steps][64 lanes][8]
+    void *q, *kv;                   // bf16
+    float *s;                       // fp32
+    int in_cs, q_cs, kv_cs, s_cs, M, tiles_m;
+    int q_rows, kv_rows, s_rows;    // q_rows = padded query rows (multiple of 8), kv_rows multiple of 8, s_rows <= 8
+};
+
+__global__ __launch_bounds__(512) void bf16_qkvs_kernel(const QkvsArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[QK_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    bf16x8 w[2][8];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const bf16x8 *p = reinterpret_cast<const bf16x8 *>(a.wf) + ((size_t)(wave + 8 * b) * 8) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) w[b][s] = p[s * 64];
+    }
+    const int c16 = tid & 15, r0 = tid >> 4;
+    u32x4 vin[4];
+    auto load_input = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int m = tile * 128 + p * 32 + r0;
+            vin[p] = u32x4{0u, 0u, 0u, 0u};
+            if (tile < a.tiles_m && m < a.M) vin[p] = *reinterpret_cast<const u32x4 *>((const __bf16 *)a.in + (size_t)m * a.in_cs + c16 * 8);
+        }
+    };
+    load_input(blockIdx.x);
+    const int lanepart = (lh ^ (l31 & 15)) << 4;
+    const unsigned char *inrow = lds + QK_IN + l31 * 256;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int kv0 = a.q_rows, s0 = a.q_rows + a.kv_rows;
+
+    for (int tile = blockIdx.x; tile < a.tiles_m; tile += gridDim.x) {
+        const int m0 = tile * 128;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4 *>(lds + QK_IN + h2_off(p * 32 + r0, c16, 256)) = vin[p];
+        load_input(tile + gridDim.x);
+        __syncthreads();
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x16 acc[2][2];                                   // [row block][pixel block]
+            bf16x8 qf[4];                                       // B fragments: step i = (K-step, pixel block), ring of 4, 3 ahead
+#pragma unroll
+            for (int i = 0; i < 3; ++i) qf[i] = *reinterpret_cast<const bf16x8 *>(inrow + (2 * half + (i & 1)) * (32 * 256) + (lanepart ^ ((2 * (i >> 1)) << 4)));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int cb = i & 1, s = i >> 1;
+                if (i + 3 < 16)
+                    qf[(i + 3) & 3] = *reinterpret_cast<const bf16x8 *>(inrow + (2 * half + ((i + 3) & 1)) * (32 * 256) + (lanepart ^ ((2 * ((i + 3) >> 1)) << 4)));
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0][s], qf[i & 3], s == 0 ? zero16 : acc[0][cb], 0, 0, 0);
+                acc[1][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1][s], qf[i & 3], s == 0 ? zero16 : acc[1][cb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the lane holds rows 32 * blk + 16 * lh + (0..15) of pixel m0 + 64 * half + 32 * cb + l31: two pieces of 8 rows
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const int m = m0 + 64 * half + 32 * cb + l31;
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) {
+                        const int row = 32 * (wave + 8 * b) + 16 * lh + 8 * pc;      // first row of the piece
+                        if (m < a.M) {
+                            if (row < s0) {
+                                u32x4 o;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const f32x2 v = {acc[b][cb][8 * pc + 2 * e], acc[b][cb][8 * pc + 2 * e + 1]};
+                                    o[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+                                }
+                                __bf16 *dst = row < kv0 ? (__bf16 *)a.q + (size_t)m * a.q_cs + row : (__bf16 *)a.kv + (size_t)m * a.kv_cs + (row - kv0);
+                                global_store_u32x4_nop(dst, o);
+                            } else if (row == s0) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e)
+                                    if (e < a.s_rows) a.s[(size_t)m * a.s_cs + e] = sigmoidf_(acc[b][cb][8 * pc + e]);
+                            }
+                        }
+                    }
+                }
+        }
+        __syncthreads();                                        // the input tile is free
+    }
+}
+
+extern "C" int m3d_anab_qkvs_bf16_forward(const m3d_qkvs_bf16_desc *d, m3d_stream_t stream)
+{
+    M3D_REQUIRE(d && d->in && d->wf && d->q && d->kv && d->s, "anab_qkvs_bf16: null pointer");
+    M3D_REQUIRE(d->in_cs % 8 == 0 && d->in_cs >= 128 && ((uintptr_t)d->in & 15) == 0, "anab_qkvs_bf16: 128 input channels, 16-byte aligned rows");
+    M3D_REQUIRE(d->q_rows % 8 == 0 && d->kv_rows % 8 == 0 && d->s_rows >= 1 && d->s_rows <= 8 && d->q_rows + d->kv_rows + 8 <= 512,
+                "anab_qkvs_bf16: q_rows / kv_rows multiples of 8, s_rows <= 8, at most 512 rows in all");
+    M3D_REQUIRE(d->q_cs % 8 == 0 && d->q_cs >= d->q_rows && d->kv_cs % 8 == 0 && d->kv_cs >= d->kv_rows && d->s_cs >= d->s_rows &&
+                (((uintptr_t)d->q | (uintptr_t)d->kv | (uintptr_t)d->wf) & 15) == 0, "anab_qkvs_bf16: output strides / alignment");
+    M3D_REQUIRE(d->M >= 1, "anab_qkvs_bf16: empty input");
+    QkvsArgs a;
+    a.in = d->in; a.wf = d->wf; a.q = d->q; a.kv = d->kv; a.s = d->s;
+    a.in_cs = d->in_cs; a.q_cs = d->q_cs; a.kv_cs = d->kv_cs; a.s_cs = d->s_cs; a.M = (int)d->M; a.tiles_m = cdiv(d->M, 128);
+    a.q_rows = d->q_rows; a.kv_rows = d->kv_rows; a.s_rows = d->s_rows;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    }
+    hipLaunchKernelGGL(bf16_qkvs_kernel, dim3(std::max(1, std::min(a.tiles_m, ncu))), dim3(512), 0, (hipStream_t)stream, a);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
 }

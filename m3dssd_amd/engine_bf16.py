@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _hip
-from ._hip import ConvBf16Desc, Head2Bf16Desc, HeadBf16Desc, Tail2Bf16Desc
+from ._hip import ConvBf16Desc, Head2Bf16Desc, HeadBf16Desc, QkvsBf16Desc, Tail2Bf16Desc, TreeEntryBf16Desc
 from .engine import BN_EPS, PSP_SIZES, Engine, OpCost, _Plan, _rup
 
 BF16 = torch.bfloat16
@@ -30,6 +30,7 @@ KV_BF16 = os.environ.get("M3D_BF16_KV_BF16", "1") != "0"
 FUSED_HEADS = os.environ.get("M3D_BF16_FUSED_HEADS", "1") != "0"
 USE_WIDE = os.environ.get("M3D_BF16_WIDE", "1") != "0"       # 3x3 layers on the 128 x 128 wave-tile kernel where it applies
 FUSED_FRONT = os.environ.get("M3D_BF16_FUSED_FRONT", "1") != "0"
+TREE_ENTRY = os.environ.get("M3D_BF16_TREE_ENTRY", "1") != "0"   # max-pool + project + stride-2 conv1 of a tree in one launch (csrc/bf16_tree_entry.hip)
 HEADS2 = os.environ.get("M3D_BF16_HEADS2", "1") != "0"         # round-5 form of the fused heads (csrc/bf16_head_mlp2.hip)
 FRONT2 = os.environ.get("M3D_BF16_FRONT2", "1") != "0"         # round-5 form of the fused front end (csrc/bf16_frontend2.hip)
 
@@ -123,6 +124,25 @@ def pack_tail2(wa, sa, ta, wb, sb, tb, device):
     t2[:co] = f(tb)
     return (_head2_frag(f(wa).reshape(256, 256) * f(sa)[:, None], BF16).to(device), _head2_frag(wbp, torch.float16).to(device),
             f(ta).to(device).contiguous(), t2.to(device).contiguous())
+
+
+def pack_tree_entry(w1, s1, wp, sp, device):
+    """Weights of m3d_tree_entry_bf16_forward: w1 [Cout, Cin, 3, 3] (tree1.conv1, + scale s1), wp [Cout, Cin, 1, 1] (project, + scale
+    sp) fp32 -> fp16 fragments [Cout/32][Cin/32][10 taps][2 blocks][64 lanes][8]: row r = lane % 16 of block b of slice ws is channel
+    32 ws + 8 (r / 4) + 4 b + r % 4; element e of lane l is input channel 32 c + 8 (l / 16) + e; taps 0..8 = the 3x3 taps row-major,
+    tap 9 = the 1x1; scales folded."""
+    f = lambda t: t.detach().float().cpu()                    # noqa: E731
+    co, ci = w1.shape[0], w1.shape[1]
+    wall = torch.cat([f(w1).reshape(co, ci, 9) * f(s1)[:, None, None], f(wp).reshape(co, ci, 1) * f(sp)[:, None, None]], 2)   # [Co, Ci, 10]
+    lane = torch.arange(64)
+    r, kgl = lane % 16, lane // 16
+    ws = torch.arange(co // 32)
+    b = torch.arange(2)
+    ch = 32 * ws[:, None, None] + 8 * (r // 4)[None, None, :] + 4 * b[None, :, None] + (r % 4)[None, None, :]      # [WS, 2, 64]
+    cin = 32 * torch.arange(ci // 32)[:, None, None] + 8 * kgl[None, :, None] + torch.arange(8)[None, None, :]      # [C, 64, 8]
+    # out[ws, c, tap, b, lane, e] = wall[ch[ws, b, lane], cin[c, lane, e], tap]
+    out = wall[ch[:, None, None, :, :, None], cin[None, :, None, None, :, :], torch.arange(10)[None, None, :, None, None, None]]
+    return out.to(torch.float16).contiguous().to(device)
 
 
 class View16:
@@ -429,10 +449,47 @@ class EngineBF16(Engine):
             self._pconv(plan, p + ".conv1", P[p + ".conv1"], x, t, stride, 1, act=1)
             self._pconv(plan, p + ".conv2", P[p + ".conv2"], t, out, 1, 1, act=1, res=res)
 
+        def tree_entry(p, x, co, bottom, res, t):
+            """maxpool (-> bottom view or None) + project (-> res) + tree1.conv1 (stride 2, -> t) as ONE launch; False = not applicable."""
+            if not (TREE_ENTRY and (p + ".project") in P and x.c % 32 == 0 and co % 64 == 0):
+                return False
+            key = "tree_entry:" + p
+            if key not in P:
+                sd = self.sd
+                P[key] = pack_tree_entry(sd[p + ".tree1.conv1.weight"], P[p + ".tree1.conv1"].scale, sd[p + ".project.0.weight"],
+                                         P[p + ".project"].scale, self.device)
+            d = TreeEntryBf16Desc()
+            d.inp, d.in_cs, d.N, d.H, d.W, d.Cin, d.Cout = x.ptr, x.cs, x.n, x.h, x.w, x.c, co
+            d.wfrag, d.shift1, d.shiftp = P[key].data_ptr(), P[p + ".tree1.conv1"].shift.data_ptr(), P[p + ".project"].shift.data_ptr()
+            d.t, d.t_cs, d.res, d.res_cs = t.ptr, t.cs, res.ptr, res.cs
+            if bottom is not None:
+                d.bottom, d.bottom_cs = bottom.ptr, bottom.cs
+            ref = ctypes.byref(d)
+            if not L.m3d_tree_entry_bf16_applicable(ref):
+                return False
+            plan.keep += [P[key], P[p + ".tree1.conv1"].shift, P[p + ".project"].shift]
+            ho, wo = x.h // 2, x.w // 2
+            flops = 2.0 * x.n * ho * wo * co * x.c * 10
+            nbytes = x.n * (x.h * x.w * x.c + ho * wo * (2 * co + (x.c if bottom is not None else 0))) * 2 + co * x.c * 10 * 2
+            plan.ops.append((p + ".entry", "bf16_tree_entry", flops,
+                             lambda st: _hip.check(L.m3d_tree_entry_bf16_forward(ref, st)), OpCost(nbytes)))
+            return True
+
         def tree1(p, x, co, stride, out, bottom=None):
             h, w = x.h // stride, x.w // stride
             cat = self._buf16(plan, B, h, w, 2 * co)
             x2v, x1v = cat.slice(0, co), cat.slice(co, co)
+            if stride == 2 and (p + ".project") in P:
+                # fused entry: bottom (only materialised when a root reads it: `bottom` given by the caller), project, conv1
+                res = self._buf16(plan, B, h, w, co)
+                t = self._buf16(plan, B, h, w, co)
+                if tree_entry(p, x, co, bottom, res, t):
+                    self._pconv(plan, p + ".tree1.conv2", P[p + ".tree1.conv2"], t, x1v, 1, 1, act=1, res=res)
+                    block(p + ".tree2", x1v, x1v, x2v, 1)
+                    self._pconv(plan, p + ".root", P[p + ".root"], cat, out, 1, 0, act=1)
+                    return
+                if bottom is not None:
+                    maxpool(p + ".downsample", x, bottom)
             if stride == 1:
                 bottom = x
             elif bottom is None:
@@ -456,8 +513,7 @@ class EngineBF16(Engine):
             catb = self._buf16(plan, B, h, w, 2 * co + ci + co)
             bottom = catb.slice(2 * co, ci)
             X1 = catb.slice(2 * co + ci, co)
-            maxpool(p + ".downsample", x, bottom)
-            tree1(p + ".tree1", x, co, 2, X1, bottom=bottom)
+            tree1(p + ".tree1", x, co, 2, X1, bottom=bottom)      # (writes `bottom` itself: fused entry or its own max-pool launch)
             x2v, x1v = catb.slice(0, co), catb.slice(co, co)
             block(p + ".tree2.tree1", X1, X1, x1v, 1)
             block(p + ".tree2.tree2", x1v, x1v, x2v, 1)
@@ -471,10 +527,14 @@ class EngineBF16(Engine):
         h5, w5 = H // 32, W // 32
         cat5 = self._buf16(plan, B, h5, w5, 1024 + 256)
         bottom5 = cat5.slice(1024, 256)
-        maxpool(b + ".level5.downsample", l4, bottom5)
         res5 = self._buf16(plan, B, h5, w5, 512)
-        self._pconv(plan, b + ".level5.project", P[b + ".level5.project"], bottom5, res5, 1, 0, act=0)
-        block(b + ".level5.tree1", l4, res5, cat5.slice(512, 512), 2)
+        t5 = self._buf16(plan, B, h5, w5, 512)
+        if tree_entry(b + ".level5", l4, 512, bottom5, res5, t5):
+            self._pconv(plan, b + ".level5.tree1.conv2", P[b + ".level5.tree1.conv2"], t5, cat5.slice(512, 512), 1, 1, act=1, res=res5)
+        else:
+            maxpool(b + ".level5.downsample", l4, bottom5)
+            self._pconv(plan, b + ".level5.project", P[b + ".level5.project"], bottom5, res5, 1, 0, act=0)
+            block(b + ".level5.tree1", l4, res5, cat5.slice(512, 512), 2)
         block(b + ".level5.tree2", cat5.slice(512, 512), cat5.slice(512, 512), cat5.slice(0, 512), 1)
         self._pconv(plan, b + ".level5.root", P[b + ".level5.root"], cat5, l5, 1, 0, act=1)
 
@@ -670,10 +730,36 @@ class EngineBF16(Engine):
         n_bins = sum(s * s for s in PSP_SIZES)
         keys_pad = _rup(n_bins, 64)
         q = self._buf16(plan, B, fh, fw, ck_pad, zero=True)       # channels [ck, ck_pad) are never written: they must be 0, not NaN
-        self._pconv(plan, "anab.q", P["anab.q"], x, q, 1, 0, affine=False)
         ckvs = ck + cv + ns
         kv16 = KV_BF16 and nested and (ck + cv) % 8 == 0
-        if kv16:
+        qkvs1 = (kv16 and HEADS2 and x.c == 128 and ck_pad % 8 == 0 and ns <= 8 and ck_pad + ck + cv + 8 <= 512)
+        if not qkvs1:
+            self._pconv(plan, "anab.q", P["anab.q"], x, q, 1, 0, affine=False)
+        if qkvs1:
+            # query | key | value | gates as ONE launch over the shared input (csrc/bf16_head_mlp2.hip: bf16_qkvs_kernel)
+            kvb = self._buf16(plan, B, fh, fw, ck + cv)
+            sg = self._buf16(plan, B, fh, fw, ns, _rup(ns, 4), dtype=torch.float32)
+            if "anab.qkvs_frag" not in P:
+                a0 = "bbox_z3d_gl.0"
+                wq, wk, wv, ws_ = (self.sd[a0 + n].detach().cpu().float().reshape(-1, 128) for n in
+                                   (".query_conv.weight", ".key_conv.weight", ".value_conv.weight", ".spatial_conv.weight"))
+                stack = torch.zeros(512, 128)
+                stack[:ck] = wq
+                stack[ck_pad:ck_pad + ck] = wk
+                stack[ck_pad + ck:ck_pad + ck + cv] = wv
+                stack[ck_pad + ck + cv:ck_pad + ck + cv + ns] = ws_
+                P["anab.qkvs_frag"] = torch.cat([_head2_frag(stack[256 * i:256 * (i + 1)], BF16) for i in range(2)], 0).contiguous().to(self.device)
+            d = QkvsBf16Desc()
+            d.inp, d.in_cs, d.M, d.wf = x.ptr, x.cs, B * HW, P["anab.qkvs_frag"].data_ptr()
+            d.q, d.q_cs, d.q_rows = q.ptr, q.cs, ck_pad
+            d.kv, d.kv_cs, d.kv_rows = kvb.ptr, kvb.cs, ck + cv
+            d.s, d.s_cs, d.s_rows = sg.ptr, sg.cs, ns
+            ref = ctypes.byref(d)
+            plan.keep.append(P["anab.qkvs_frag"])
+            plan.ops.append(("anab.qkvs", "bf16_qkvs", 2.0 * B * HW * 128 * (ck + ck + cv + ns),
+                             lambda st: _hip.check(L.m3d_anab_qkvs_bf16_forward(ref, st)),
+                             OpCost(B * HW * (128 * 2 + (ck_pad + ck + cv) * 2 + 4 * sg.cs) + 512 * 128 * 2)))
+        elif kv16:
             # K|V as bf16 NHWC (half the bytes written here and read by the pooling: 590 -> 300 MB at bs = 64), gates in fp32
             kvb = self._buf16(plan, B, fh, fw, ck + cv)
             sg = self._buf16(plan, B, fh, fw, ns, _rup(ns, 4), dtype=torch.float32)

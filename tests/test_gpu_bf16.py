@@ -443,6 +443,90 @@ def test_fused_head_mlp_bf16_matches_torch_chain(G, n, h, w, cout, form):
         assert e < 4e-3 * (1.0 + ref.abs().max().item()), (gi, e)      # a hidden value may round to the neighbouring bf16
 
 
+@pytest.mark.parametrize("n,cin,H,W,with_bottom", [(2, 32, 32, 64, False), (1, 64, 48, 96, True), (2, 128, 16, 32, True), (1, 256, 24, 80, True),
+                                                   (3, 32, 192, 640, False), (1, 64, 20, 36, True)])
+def test_tree_entry_bf16_matches_torch(n, cin, H, W, with_bottom):
+    """m3d_tree_entry_bf16_forward (max-pool + 1x1 project + 3x3 stride-2 conv1 of a DLA tree in one launch) against torch on the
+    bf16-rounded input / weights: bottom bit-exact (a max of bf16 values), t / res to one bf16 ulp of the result (the kernel folds
+    the scales into fp16 weights: + 2^-9 relative).  Every level's channel pair, image borders, partial tiles (24 x 80 -> 12 x 40,
+    20 x 36 -> 10 x 18), channel slices of a wider buffer, the full-size level2 map."""
+    from m3dssd_amd import _hip
+    from m3dssd_amd.engine_bf16 import pack_tree_entry
+    L, dev = _hip.lib(), _dev()
+    co = 2 * cin
+    g = torch.Generator().manual_seed(cin + H)
+    x = _r(torch.randn(n, cin, H, W, generator=g))
+    w1 = _r(torch.randn(co, cin, 3, 3, generator=g) / (9 * cin) ** 0.5)
+    wp = _r(torch.randn(co, cin, 1, 1, generator=g) / cin ** 0.5)
+    s1, t1 = torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.1
+    sp, tp = torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.1
+    xin = _nhwc16(x, cin + 8)
+    Ho, Wo = H // 2, W // 2
+    t = torch.full((n, Ho, Wo, co + 8), 512.0, device=dev, dtype=BF16)
+    res = torch.full((n, Ho, Wo, co), 512.0, device=dev, dtype=BF16)
+    bot = torch.full((n, Ho, Wo, cin + 16), 512.0, device=dev, dtype=BF16)
+    wf = pack_tree_entry(w1, s1, wp, sp, dev)
+    dv = [v.to(dev).contiguous() for v in (t1, tp)]
+    d = _hip.TreeEntryBf16Desc()
+    d.inp, d.in_cs, d.N, d.H, d.W, d.Cin, d.Cout = xin.data_ptr(), cin + 8, n, H, W, cin, co
+    d.wfrag, d.shift1, d.shiftp = wf.data_ptr(), dv[0].data_ptr(), dv[1].data_ptr()
+    d.t, d.t_cs, d.res, d.res_cs = t.data_ptr(), co + 8, res.data_ptr(), co
+    if with_bottom:
+        d.bottom, d.bottom_cs = bot.data_ptr() + 2 * 8, cin + 16          # a channel slice [8, 8 + cin) of a wider buffer
+    assert L.m3d_tree_entry_bf16_applicable(ctypes.byref(d)) == 1
+    _hip.check(L.m3d_tree_entry_bf16_forward(ctypes.byref(d), _st()))
+    torch.cuda.synchronize()
+    pooled = F.max_pool2d(x, 2, 2)
+    ref_t = F.leaky_relu(F.conv2d(x, w1, None, stride=2, padding=1) * s1.view(1, -1, 1, 1) + t1.view(1, -1, 1, 1), 0.01)
+    ref_r = F.conv2d(pooled, wp) * sp.view(1, -1, 1, 1) + tp.view(1, -1, 1, 1)
+    assert (t[..., co:].float() == 512.0).all()
+    for name, got, ref in (("t", t[..., :co], ref_t), ("res", res, ref_r)):
+        gotf = got.float().permute(0, 3, 1, 2).cpu()
+        err = (gotf - ref).abs()
+        tol = 2.0 ** -7 * ref.abs() + 2e-3 * ref.abs().max()
+        assert (err <= tol).all(), (name, err.max().item(), ref.abs().max().item(), int((err > tol).sum()))
+    if with_bottom:
+        assert torch.equal(bot[..., 8:8 + cin].float().permute(0, 3, 1, 2).cpu(), pooled)
+        assert (bot[..., :8].float() == 512.0).all() and (bot[..., 8 + cin:].float() == 512.0).all()
+    else:
+        assert (bot.float() == 512.0).all()
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 8, 16), (1, 13, 21), (3, 48, 160)])
+def test_anab_qkvs_bf16_matches_torch(n, h, w):
+    """m3d_anab_qkvs_bf16_forward (query | key | value | gates of ANAB in one launch) against torch on the bf16-rounded operands: q and
+    k|v to one bf16 ulp, the padding rows of q exact zeros, gates = sigmoid in fp32 to 2e-4; ragged tiles, untouched neighbours."""
+    from m3dssd_amd import _hip
+    from m3dssd_amd.engine_bf16 import _head2_frag
+    L, dev = _hip.lib(), _dev()
+    ck, cv, ns, ckp = 168, 128, 4, 192
+    g = torch.Generator().manual_seed(h * 7 + w)
+    x = _r(torch.randn(n, 128, h, w, generator=g))
+    M = n * h * w
+    wq, wk, wv, ws = (_r(torch.randn(c, 128, generator=g) / 11) for c in (ck, ck, cv, ns))
+    stack = torch.zeros(512, 128)
+    stack[:ck], stack[ckp:ckp + ck], stack[ckp + ck:ckp + ck + cv], stack[ckp + ck + cv:ckp + ck + cv + ns] = wq, wk, wv, ws
+    wf = torch.cat([_head2_frag(stack[256 * i:256 * (i + 1)], BF16) for i in range(2)], 0).contiguous().to(dev)
+    xin = _nhwc16(x, 136)
+    q = torch.full((M, ckp + 8), 512.0, device=dev, dtype=BF16)
+    kv = torch.full((M, ck + cv + 8), 512.0, device=dev, dtype=BF16)
+    sg = torch.full((M, 8), 512.0, device=dev)
+    d = _hip.QkvsBf16Desc()
+    d.inp, d.in_cs, d.M, d.wf = xin.data_ptr(), 136, M, wf.data_ptr()
+    d.q, d.q_cs, d.q_rows = q.data_ptr(), ckp + 8, ckp
+    d.kv, d.kv_cs, d.kv_rows = kv.data_ptr(), ck + cv + 8, ck + cv
+    d.s, d.s_cs, d.s_rows = sg.data_ptr(), 8, ns
+    _hip.check(L.m3d_anab_qkvs_bf16_forward(ctypes.byref(d), _st()))
+    torch.cuda.synchronize()
+    xf = x.permute(0, 2, 3, 1).reshape(M, 128)
+    for name, got, ref in (("q", q[:, :ck], xf @ wq.T), ("kv", kv[:, :ck + cv], xf @ torch.cat([wk, wv]).T)):
+        e = (got.float().cpu() - ref).abs()
+        assert (e <= 2.0 ** -8 * ref.abs() + 1e-4).all(), (name, e.max().item())
+    assert (q[:, ck:ckp].float() == 0).all() and (q[:, ckp:].float() == 512.0).all() and (kv[:, ck + cv:].float() == 512.0).all()
+    es = (sg[:, :ns].cpu() - torch.sigmoid(xf @ ws.T)).abs().max().item()
+    assert es < 2e-4 and (sg[:, ns:] == 512.0).all(), es
+
+
 @pytest.mark.parametrize("n,h,w,cout", [(2, 8, 16, 144), (1, 13, 21, 144), (3, 48, 160, 144), (1, 8, 8, 256), (2, 4, 16, 20)])
 def test_head_tail2_bf16_matches_torch_chain(n, h, w, cout):
     """m3d_head_tail2_bf16_forward (cls.3 + cls.6: 256 -> 256 + affine + LeakyReLU -> 256 -> Cout + affine in one launch) against the
@@ -1020,6 +1104,7 @@ def test_bf16_engine_alternative_paths_agree(monkeypatch):
     crop, B = (128, 320), 2
     x = synth.synth_frames(B, crop, 99).to(_dev())
     ref = None
+    monkeypatch.setattr(engine_bf16, "TREE_ENTRY", True)
     # (fused ANAB, bf16 K|V, fused heads, fused front end, round-5 heads, round-5 front end)
     for fused, kv16, heads, front, heads2, front2 in [(True, True, True, True, True, True), (False, True, True, True, True, True),
                                                       (True, False, True, True, True, True), (False, False, True, True, True, True),
@@ -1031,6 +1116,7 @@ def test_bf16_engine_alternative_paths_agree(monkeypatch):
         monkeypatch.setattr(engine_bf16, "FUSED_FRONT", front)
         monkeypatch.setattr(engine_bf16, "HEADS2", heads2)
         monkeypatch.setattr(engine_bf16, "FRONT2", front2)
+        monkeypatch.setattr(engine_bf16, "TREE_ENTRY", front2)       # (the unfused tree entry rides with the round-4 front end)
         net, _ = _net(crop, B, "bf16")
         with torch.no_grad():
             out = [t.float().cpu() for t in net(x)[:4]]
