@@ -15,6 +15,13 @@
 //   [Cout/32][Cin/32][10][2 blocks][64 lanes][8] (m3dssd_amd/engine_bf16.py: pack_tree_entry), streamed global -> register two
 //   taps ahead; the shifts are the C operands of the chains.  MFMA rows are mapped to channels so that a lane ends up with 8
 //   consecutive channels of its pixel: one 16-byte store per pixel row and output.
+//
+// Measured (bs 64, tools/tree_entry_trace.py): level2 0.25 ms (was 0.45 for the three launches), level3 0.17 (0.26), level4 0.12 (0.17),
+// level5 0.135 (0.136).  Tried and not kept (round 5): all 20 weight fragments of a chunk up-front on 64-channel blocks (the MFMA phase
+// of a tile drops from 5 700 to 2 600 cycles, but two workgroups per CU instead of three and twice the channel blocks: 0.29 / 0.23 /
+// 0.16 / 0.19 ms), and persistent workgroups with the next tile's loads in flight under the MFMAs on top of that (0.25 / 0.21 / 0.16
+// / 0.23 ms): the per-tile VALU work -- piece addresses, bf16 -> fp16, store addresses: ~600 instructions per wave against 80-160
+// MFMAs -- is what bounds the kernel, not the exposed latencies.
 #include <stdlib.h>
 
 #include <type_traits>

@@ -782,18 +782,18 @@ def test_bf16_helpers_match_torch():
     _hip.check(L.m3d_maxpool2x2_bf16(xin.data_ptr(), 48, out.data_ptr(), 40, 2, 8, 12, 32, _st()))
     assert torch.equal(out[..., :32].float().permute(0, 3, 1, 2).cpu(), F.max_pool2d(x, 2, 2))
     assert (out[..., 32:] == 0).all()
-    # depthwise ConvTranspose2d(4, 2, 1) + skip
-    c = 16
-    x = _r(torch.randn(2, c, 5, 7, generator=g))
-    wt = torch.rand(c, 1, 4, 4, generator=g)
-    skip = _r(torch.randn(2, c, 10, 14, generator=g))
-    ref = F.conv_transpose2d(x, wt, None, stride=2, padding=1, groups=c) + skip
-    xin, sk = _nhwc16(x), _nhwc16(skip)
-    wd = wt[:, 0].permute(1, 2, 0).contiguous().to(dev)
-    out = torch.zeros(2, 10, 14, c, device=dev, dtype=BF16)
-    _hip.check(L.m3d_upsample2x_add_bf16(xin.data_ptr(), c, wd.data_ptr(), sk.data_ptr(), c, out.data_ptr(), c, 2, 5, 7, c, _st()))
-    got = out.float().permute(0, 3, 1, 2).cpu()
-    assert ((got - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-6).all()
+    # depthwise ConvTranspose2d(4, 2, 1) + skip: the grid-stride form (16 channels) and the row form (64 / 128 / 256 channels, ragged widths)
+    for c, h, w in ((16, 5, 7), (128, 5, 7), (256, 3, 9), (64, 6, 5)):
+        x = _r(torch.randn(2, c, h, w, generator=g))
+        wt = torch.rand(c, 1, 4, 4, generator=g)
+        skip = _r(torch.randn(2, c, 2 * h, 2 * w, generator=g))
+        ref = F.conv_transpose2d(x, wt, None, stride=2, padding=1, groups=c) + skip
+        xin, sk = _nhwc16(x), _nhwc16(skip)
+        wd = wt[:, 0].permute(1, 2, 0).contiguous().to(dev)
+        out = torch.zeros(2, 2 * h, 2 * w, c, device=dev, dtype=BF16)
+        _hip.check(L.m3d_upsample2x_add_bf16(xin.data_ptr(), c, wd.data_ptr(), sk.data_ptr(), c, out.data_ptr(), c, 2, h, w, c, _st()))
+        got = out.float().permute(0, 3, 1, 2).cpu()
+        assert ((got - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-6).all(), (c, h, w)
     # fp32 -> bf16 (round to nearest even, like torch)
     v = torch.randn(4096, generator=g) * 100
     o = torch.zeros(4096, device=dev, dtype=BF16)
