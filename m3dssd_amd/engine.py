@@ -902,6 +902,26 @@ class Engine:
         st = _Stream.current(self.device)
         ops = plan.ops[start:end]
         if self.profile is None:
+            br = getattr(plan, "branch", None)
+            lo, hi = start, (len(plan.ops) if end is None else end)
+            if br is not None and lo <= br[0] and br[2] <= hi:
+                # a side branch: ops [b0, b1) run on a second stream beside ops [b1, join) (no data dependence between the two
+                # groups: the plan builder vouches for that); fork / join by stream waits, so the pattern is captured by a hipGraph
+                b0, b1, join = br
+                main = torch.cuda.current_stream(self.device)
+                if getattr(self, "_side", None) is None:
+                    self._side = torch.cuda.Stream(self.device)
+                side = self._side
+                for i in range(lo, hi):
+                    if i == b0:
+                        side.wait_stream(main)
+                        sst = ctypes.c_void_p(side.cuda_stream)
+                    if i == join:
+                        main.wait_stream(side)
+                    plan.ops[i][3](sst if b0 <= i < b1 else st)
+                if join == hi:
+                    main.wait_stream(side)
+                return
             for op in ops:
                 op[3](st)
             return

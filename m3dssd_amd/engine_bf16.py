@@ -30,6 +30,7 @@ KV_BF16 = os.environ.get("M3D_BF16_KV_BF16", "1") != "0"
 FUSED_HEADS = os.environ.get("M3D_BF16_FUSED_HEADS", "1") != "0"
 USE_WIDE = os.environ.get("M3D_BF16_WIDE", "1") != "0"       # 3x3 layers on the 128 x 128 wave-tile kernel where it applies
 FUSED_FRONT = os.environ.get("M3D_BF16_FUSED_FRONT", "1") != "0"
+BRANCH = os.environ.get("M3D_BF16_BRANCH", "1") != "0"         # ANAB + z3d head as a side branch beside the size heads
 TREE_ENTRY = os.environ.get("M3D_BF16_TREE_ENTRY", "1") != "0"   # max-pool + project + stride-2 conv1 of a tree in one launch (csrc/bf16_tree_entry.hip)
 HEADS2 = os.environ.get("M3D_BF16_HEADS2", "1") != "0"         # round-5 form of the fused heads (csrc/bf16_head_mlp2.hip)
 FRONT2 = os.environ.get("M3D_BF16_FRONT2", "1") != "0"         # round-5 form of the fused front end (csrc/bf16_frontend2.hip)
@@ -698,12 +699,18 @@ class EngineBF16(Engine):
         center_align("center_align2d", feats, 0, 1, 0, f2d)
         f3d = self._buf16(plan, B, fh, fw, 128, name="feats_align3d")
         center_align("center_align3d", feats, 4, 5, 4, f3d)
-        heads(["bbox_w", "bbox_h"], f2d, 2)
-        heads(["bbox_w3d", "bbox_h3d", "bbox_l3d", "bbox_rY3d"], f3d, 7)
-
+        # ANAB + the z3d head (reads feats_align3d, writes its own planar rows) next to the six size / orientation heads: the pooling and
+        # attention launches leave most of the chip idle (a reduction over pixels, 337 keys) -- as a side branch of the plan they run
+        # beside the head launches (Engine._run_plan; M3D_BF16_BRANCH=0: one stream)
+        b0 = len(plan.ops)
         gl = self._buf16(plan, B, fh, fw, 128, name="feats_gl")
         self._anab_bf16(plan, f3d, gl)
         heads(["bbox_z3d"], gl, 6)
+        b1 = len(plan.ops)
+        heads(["bbox_w", "bbox_h"], f2d, 2)
+        heads(["bbox_w3d", "bbox_h3d", "bbox_l3d", "bbox_rY3d"], f3d, 7)
+        if BRANCH:
+            plan.branch = (b0, b1, len(plan.ops))
 
         cls = torch.empty(B, R, NC, device=self.device, dtype=torch.float32)
         prob = torch.empty(B, R, NC, device=self.device, dtype=torch.float32)
