@@ -36,6 +36,16 @@ HEADS2 = os.environ.get("M3D_BF16_HEADS2", "1") != "0"         # round-5 form of
 FRONT2 = os.environ.get("M3D_BF16_FRONT2", "1") != "0"         # round-5 form of the fused front end (csrc/bf16_frontend2.hip)
 
 
+
+def _f16_checked(t, what):
+    """fp16 copy of folded weights for the kernels that compute in fp16 inside a launch; a value outside fp16's range has no
+    faithful copy: refuse (the round-4 kernels of the same layer take bf16 weights: the switch named in the message)."""
+    t = t.float()
+    if not bool(torch.isfinite(t).all()) or float(t.abs().max()) > 65504.0:
+        raise RuntimeError("bf16 engine: %s with the BatchNorm scale folded in leaves the fp16 range (|w| max %g)" % (what, float(t.abs().max())))
+    return t.to(torch.float16)
+
+
 def pack_frontend_bf16(w_stem, w_l0, w_l1, device):
     """Weights of m3d_frontend_bf16_forward: stem [16,3,7,7] -> [16][7*32] (k = i*32 + j*4 + c), level0 / level1
     [Co,16,3,3] -> [Co][160] (k = (i*3 + j)*16 + c)."""
@@ -72,13 +82,13 @@ def pack_frontend_f16(w_stem, bn_stem, w_l0, bn_l0, w_l1, bn_l1, device):
                     frag[:, s, lane, e] = ws[ch, rgb, :, j]
                 elif rgb == 3 and j == 0:
                     frag[0, s, lane, e] = bn_stem[1][ch]       # the shift: slot 3 of every image-tile pixel holds 1.0
-    out = [frag.to(device, torch.float16).contiguous(), bn_stem[1].detach().float().to(device).contiguous()]
+    out = [_f16_checked(frag, "front end stem weights").to(device).contiguous(), bn_stem[1].detach().float().to(device).contiguous()]
     for w, bn in ((w_l0, bn_l0), (w_l1, bn_l1)):
         co = w.shape[0]
         wf = w.detach().float().cpu() * bn[0].detach().float().cpu()[:, None, None, None]
         t = torch.zeros(co, 160)
         t[:, :144] = wf.permute(0, 2, 3, 1).reshape(co, 144)
-        out += [t.to(device, torch.float16).contiguous(), bn[1].detach().float().to(device).contiguous()]
+        out += [_f16_checked(t, "front end level0 / level1 weights").to(device).contiguous(), bn[1].detach().float().to(device).contiguous()]
     return out
 
 
@@ -92,7 +102,7 @@ def _head2_frag(w, dtype):
     ch = (32 * torch.arange(8)[:, None] + ch_of_row[lane % 32][None, :])     # [8, 64]
     k = (16 * torch.arange(K // 16)[:, None, None] + 8 * (lane // 32)[None, :, None] + torch.arange(8)[None, None, :])   # [K/16, 64, 8]
     out = w[ch[:, None, :, None], k[None, :, :, :]]                          # [8, K/16, 64, 8]
-    return out.to(dtype).contiguous()
+    return (_f16_checked(out, "head weights") if dtype == torch.float16 else out.to(dtype)).contiguous()
 
 
 def pack_head2(heads, device):
@@ -107,7 +117,7 @@ def pack_head2(heads, device):
         co = w3.shape[0]
         w3s = torch.zeros(64, 256)
         w3s[:co] = f(w3).reshape(co, 256) * f(s3)[:, None]
-        w3p.append(w3s.to(torch.float16))
+        w3p.append(_f16_checked(w3s, "head output weights"))
         t1.append(f(b1)); t2.append(f(b2))
         tt = torch.zeros(64)
         tt[:co] = f(b3)
@@ -143,7 +153,7 @@ def pack_tree_entry(w1, s1, wp, sp, device):
     cin = 32 * torch.arange(ci // 32)[:, None, None] + 8 * kgl[None, :, None] + torch.arange(8)[None, None, :]      # [C, 64, 8]
     # out[ws, c, tap, b, lane, e] = wall[ch[ws, b, lane], cin[c, lane, e], tap]
     out = wall[ch[:, None, None, :, :, None], cin[None, :, None, None, :, :], torch.arange(10)[None, None, :, None, None, None]]
-    return out.to(torch.float16).contiguous().to(device)
+    return _f16_checked(out, "tree entry weights").contiguous().to(device)
 
 
 class View16:

@@ -474,7 +474,7 @@ import ctypes, sys, torch
 sys.path.insert(0, %r)
 sys.path.insert(0, %r)
 from m3dssd_amd import _hip
-from test_gpu_round4 import _w44_case
+from gpu_common import _w44_case
 L = _hip.lib()
 d, out, ref, keep = _w44_case(128, 128, 16, 48, 2, res=True)
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -96,3 +96,19 @@ def test_data_parallel_replica_does_not_share_the_engine(net_and_sd):
 def test_lib_rpn_util_keeps_the_reference_name_for_the_test_driver():
     import lib.rpn_util as r
     assert callable(r.test_kitti_3d) and r.test_kitti_3d.__module__ == "m3dssd_amd.host.kitti_test"
+
+
+def test_bf16_packers_refuse_weights_outside_the_fp16_range():
+    """The round-5 bf16 kernels compute in fp16 inside a launch: a folded weight beyond +-65504 has no faithful copy and must not be
+    packed silently (INTEGRATION.md "Limits worth knowing")."""
+    import pytest
+    import torch
+    from m3dssd_amd import engine_bf16 as E
+    w1, wp = torch.randn(64, 32, 3, 3), torch.randn(64, 32, 1, 1)
+    ok = E.pack_tree_entry(w1, torch.ones(64), wp, torch.ones(64), "cpu")
+    assert ok.dtype == torch.float16 and tuple(ok.shape) == (2, 1, 10, 2, 64, 8)
+    with pytest.raises(RuntimeError, match="fp16 range"):
+        E.pack_tree_entry(w1, torch.full((64,), 1e6), wp, torch.ones(64), "cpu")
+    with pytest.raises(RuntimeError, match="fp16 range"):
+        E._head2_frag(torch.full((256, 256), 7e4), torch.float16)
+    assert E._head2_frag(torch.full((256, 256), 7e4), E.BF16).dtype == E.BF16          # bf16 has fp32's range
