@@ -28,9 +28,82 @@ __device__ __forceinline__ float dev_iou(const float *a, const float *b)
     return interS / (Sa + Sb - interS);
 }
 
+// Mask tile without the division in all but a sliver of cases, same bits as dev_iou(a, b) > thresh (correctly rounded fp32 division,
+// strict '>'): q = RN(interS / U) > t holds when interS >= next(t) * U and fails when interS <= t * U in the reals; p = RN(t * U)
+// is within 2^-24 of t * U (p normal), so outside the band p * (1 -+ 2^-20) the comparison of interS with p decides.  A lane (row
+// box) that meets a pair inside the band -- or a non-positive U or threshold (degenerate boxes) -- redoes its row with the exact
+// expression afterwards.  The 64 column boxes (+ their areas) sit in LDS; the loop is fully unrolled and branch-free, the "redo"
+// flags accumulate in an SGPR pair.  v_max / v_min are issued directly: on loaded values fmaxf costs a canonicalising extra
+// instruction each (same result for the non-NaN boxes the exact path does not take over: a NaN makes the band test fail).
+__device__ __forceinline__ float nms_vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float nms_vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 __global__ __launch_bounds__(NMS_TPB) void nms_mask_kernel(int n, int box_stride, float thresh,
                                                           const float *__restrict__ boxes_all,
                                                           unsigned long long *__restrict__ mask_all)
+{
+#pragma clang fp contract(off)
+    const int row_start = blockIdx.y, col_start = blockIdx.x, img = blockIdx.z;
+    if (col_start < row_start) return;
+    const int col_blocks = (n + NMS_TPB - 1) / NMS_TPB;
+    const float *boxes = boxes_all + (size_t)img * n * box_stride;
+    unsigned long long *mask = mask_all + (size_t)img * n * col_blocks;
+    const int row_size = min(n - row_start * NMS_TPB, NMS_TPB);
+    const int col_size = min(n - col_start * NMS_TPB, NMS_TPB);
+    __shared__ __attribute__((aligned(16))) float bb[NMS_TPB * 4];
+    __shared__ float bs[NMS_TPB];
+    const int t = threadIdx.x;
+    {
+        float x0 = 0.f, y0 = 0.f, x1 = 0.f, y1 = 0.f;            // past the end: a unit box (its bits are masked off below)
+        if (t < col_size) {
+            const float *s = boxes + (size_t)(NMS_TPB * col_start + t) * box_stride;
+            x0 = s[0]; y0 = s[1]; x1 = s[2]; y1 = s[3];
+        }
+        *reinterpret_cast<f32x4 *>(bb + t * 4) = f32x4{x0, y0, x1, y1};
+        bs[t] = (x1 - x0 + 1) * (y1 - y0 + 1);
+    }
+    __syncthreads();
+    const int cur = NMS_TPB * row_start + min(t, row_size - 1);
+    const float *cp = boxes + (size_t)cur * box_stride;
+    const float cb[4] = {cp[0], cp[1], cp[2], cp[3]};
+    const int start = (row_start == col_start) ? t + 1 : 0;
+    unsigned long long bits = 0;
+    unsigned long long redo = thresh > 0.f ? 0ULL : ~0ULL;       // wave-uniform lane mask
+    if (redo == 0) {
+        const float Sa = (cb[2] - cb[0] + 1) * (cb[3] - cb[1] + 1);
+        unsigned int lo = 0, hi = 0;
+#pragma unroll
+        for (int i = 0; i < NMS_TPB; ++i) {
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(bb + i * 4);
+            const float Sb = bs[i];
+            const float w = fmaxf(nms_vmin(cb[2], b[2]) - nms_vmax(cb[0], b[0]) + 1, 0.f);
+            const float h = fmaxf(nms_vmin(cb[3], b[3]) - nms_vmax(cb[1], b[1]) + 1, 0.f);
+            const float interS = w * h;
+            const float U = Sa + Sb - interS;
+            const float p = thresh * U;
+            const bool decided = (p > 1e-30f) & (fabsf(interS - p) > p * 9.5367431640625e-07f);   // 2^-20
+            redo |= __builtin_amdgcn_ballot_w64(!decided);
+            if (i < 32) lo |= interS > p ? 1u << (i & 31) : 0u;
+            else hi |= interS > p ? 1u << (i & 31) : 0u;
+        }
+        bits = ((unsigned long long)hi << 32) | lo;
+    }
+    if (redo >> t & 1ULL) {                                         // rare: this row with the reference's own expression
+        bits = 0;
+        for (int i = 0; i < col_size; ++i)
+            if (dev_iou(cb, bb + i * 4) > thresh) bits |= 1ULL << i;
+    }
+    if (t < row_size) {
+        unsigned long long valid = col_size < NMS_TPB ? (1ULL << col_size) - 1ULL : ~0ULL;
+        valid &= start < NMS_TPB ? ~0ULL << start : 0ULL;
+        mask[(size_t)cur * col_blocks + col_start] = bits & valid;
+    }
+}
+
+// Round 1-4 form (one correctly rounded division per pair), kept as the A/B baseline: M3D_NMS_DIV=1.
+__global__ __launch_bounds__(NMS_TPB) void nms_mask_div_kernel(int n, int box_stride, float thresh,
+                                                              const float *__restrict__ boxes_all,
+                                                              unsigned long long *__restrict__ mask_all)
 {
     const int row_start = blockIdx.y, col_start = blockIdx.x, img = blockIdx.z;
     if (col_start < row_start) return;
@@ -148,8 +221,11 @@ extern "C" int m3d_nms_sorted_dev(const float *boxes_dev, int B, int n, int box_
     M3D_REQUIRE(boxes_dev && mask_ws && keep_dev, "nms: null pointer");
     M3D_REQUIRE(box_stride >= 4, "nms: box_stride must be >= 4");
     const int cb = (n + NMS_TPB - 1) / NMS_TPB;
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, B), dim3(NMS_TPB), 0, stream, n, box_stride, thresh, boxes_dev,
-                       (unsigned long long *)mask_ws);
+    static const int div_form = []() { const char *e = getenv("M3D_NMS_DIV"); return e ? atoi(e) : 0; }();
+    if (div_form) hipLaunchKernelGGL(nms_mask_div_kernel, dim3(cb, cb, B), dim3(NMS_TPB), 0, stream, n, box_stride, thresh, boxes_dev,
+                                     (unsigned long long *)mask_ws);
+    else hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, B), dim3(NMS_TPB), 0, stream, n, box_stride, thresh, boxes_dev,
+                            (unsigned long long *)mask_ws);
     M3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(256), 0, stream, n, (const unsigned long long *)mask_ws, keep_dev,
                        num_keep_dev);

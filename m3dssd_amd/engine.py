@@ -186,6 +186,12 @@ class OpCost:
         self.hbm_bytes = int(hbm_bytes)
 
 
+def lo_hi_contains(start, end, n, br):
+    """Is the side branch (b0, b1, join) wholly inside ops[start:end]?  (A partial range runs its ops in line.)"""
+    lo, hi = start, (n if end is None else end)
+    return lo <= br[0] and br[2] <= hi
+
+
 class _Plan:
     """Buffers + launch list for one input shape."""
 
@@ -194,6 +200,7 @@ class _Plan:
         self.keep = []         # tensors kept alive
         self.named = {}        # name -> View / tensor (taps for tests)
         self.w44_prev = None   # (index into ops, touch record) of the latest F(4x4) launch: it warms the cache for the next one
+        self.branches = []     # (b0, b1, join): ops [b0, b1) on a side stream beside ops [b1, join) (Engine._run_plan)
 
 
 class Engine:
@@ -902,24 +909,28 @@ class Engine:
         st = _Stream.current(self.device)
         ops = plan.ops[start:end]
         if self.profile is None:
-            br = getattr(plan, "branch", None)
-            lo, hi = start, (len(plan.ops) if end is None else end)
-            if br is not None and lo <= br[0] and br[2] <= hi:
-                # a side branch: ops [b0, b1) run on a second stream beside ops [b1, join) (no data dependence between the two
+            brs = [br for br in getattr(plan, "branches", ()) if lo_hi_contains(start, end, len(plan.ops), br)]
+            if brs:
+                # side branches: ops [b0, b1) run on a second stream beside ops [b1, join) (no data dependence between the two
                 # groups: the plan builder vouches for that); fork / join by stream waits, so the pattern is captured by a hipGraph
-                b0, b1, join = br
+                lo, hi = start, (len(plan.ops) if end is None else end)
                 main = torch.cuda.current_stream(self.device)
                 if getattr(self, "_side", None) is None:
                     self._side = torch.cuda.Stream(self.device)
                 side = self._side
+                sst = ctypes.c_void_p(side.cuda_stream)
+                forks = {br[0] for br in brs}
+                joins = {br[2] for br in brs}
+                on_side = set()
+                for b0, b1, _ in brs:
+                    on_side.update(range(b0, b1))
                 for i in range(lo, hi):
-                    if i == b0:
-                        side.wait_stream(main)
-                        sst = ctypes.c_void_p(side.cuda_stream)
-                    if i == join:
+                    if i in joins:
                         main.wait_stream(side)
-                    plan.ops[i][3](sst if b0 <= i < b1 else st)
-                if join == hi:
+                    if i in forks:
+                        side.wait_stream(main)
+                    plan.ops[i][3](sst if i in on_side else st)
+                if hi in joins:
                     main.wait_stream(side)
                 return
             for op in ops:

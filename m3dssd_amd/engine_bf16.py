@@ -712,6 +712,9 @@ class EngineBF16(Engine):
         # ANAB + the z3d head (reads feats_align3d, writes its own planar rows) next to the six size / orientation heads: the pooling and
         # attention launches leave most of the chip idle (a reduction over pixels, 337 keys) -- as a side branch of the plan they run
         # beside the head launches (Engine._run_plan; M3D_BF16_BRANCH=0: one stream)
+        # Measured again with the planar detector (tools/ab_replay.sh, one lease): 10.35-10.40 ms with the branch, without it, and with a
+        # reordered tail that puts the pooling beside the x / y heads + the 2-D alignment: the head kernel is persistent and owns every
+        # register of every CU, so a side branch only fills the wind-down of its launches -- the step is the SUM of its kernels.
         b0 = len(plan.ops)
         gl = self._buf16(plan, B, fh, fw, 128, name="feats_gl")
         self._anab_bf16(plan, f3d, gl)
@@ -720,7 +723,7 @@ class EngineBF16(Engine):
         heads(["bbox_w", "bbox_h"], f2d, 2)
         heads(["bbox_w3d", "bbox_h3d", "bbox_l3d", "bbox_rY3d"], f3d, 7)
         if BRANCH:
-            plan.branch = (b0, b1, len(plan.ops))
+            plan.branches.append((b0, b1, len(plan.ops)))
 
         cls = torch.empty(B, R, NC, device=self.device, dtype=torch.float32)
         prob = torch.empty(B, R, NC, device=self.device, dtype=torch.float32)

@@ -81,6 +81,12 @@ class PipelinedDetector:
         n = self.plan.named
         # planar form: the side branch must be done before the first launch that overwrites the planar staging
         self.n_join = int(n["planar_first_op"]) if self.planar else self.n_fwd
+        # where the side branch forks off (experiment switch M3D_PIPE_FORK = op index; default: at the first launch).  In the bf16 graph
+        # the persistent front end is stretched from 0.83 to 1.09 ms by detect(k-1) beside it (tools/graph_timeline.py), but forking
+        # behind it moves the cost, it does not remove it: 10.48 / 10.58 / 10.61 / 10.52 ms for forks at op 0 / 1 / 2 / 3 on one lease
+        # (fp32: 6.00 / 6.01 / 5.99 / 6.04, later forks worse) -- detect's 0.3 ms of mask arithmetic is work, not latency.
+        fork = os.environ.get("M3D_PIPE_FORK")
+        self.n_fork = min(int(fork) if fork is not None else int(n.get("pipe_fork_op", 0)), self.n_join)
         self._outs = (n["prob"], n["bbox_2d"], n["bbox_3d"])
         self._rois = net.rois.to(dev)
         self._pending = False
@@ -140,6 +146,8 @@ class PipelinedDetector:
     def _capture_step(self, cap, side, buf):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=cap):
+            if self.n_fork:                          # launches of batch k in front of the fork (they do not share the chip well)
+                self._forward(0, self.n_fork, buf)
             side.wait_stream(cap)                    # fork
             with torch.cuda.stream(side):
                 outs = self._detect()                # batch k-1
@@ -147,7 +155,7 @@ class PipelinedDetector:
                     _hip.check(_hip.lib().m3d_upload_indirect(
                         ctypes.c_void_p(self._slots.data_ptr() + 8 * buf), ctypes.c_void_p(self._u8_flat[buf ^ 1].data_ptr()),
                         self._u8_bytes, ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
-            self._forward(0, self.n_join, buf)       # batch k, everything in front of the first write of what the side branch reads
+            self._forward(self.n_fork, self.n_join, buf)   # batch k, everything in front of the first write of what the side branch reads
             cap.wait_stream(side)                    # join: outputs may now be overwritten
             self._finish(buf)
         return g, outs

@@ -81,6 +81,36 @@ def test_nms_batched_device_api_and_properties():
     assert gpu_nms_empty() == []
 
 
+def test_nms_thresholds_on_and_one_ulp_around_actual_ious():
+    """The mask kernel decides IoU > t by comparing interS with t * U outside a 2^-20 band and by the reference's division inside it
+    (csrc/nms.hip): thresholds that ARE the fp32 IoU of a pair of the set, and their fp32 neighbours, land in or next to the band."""
+    from m3dssd_amd.host import ops
+    from oracle import nms as onms
+    dev = _dev()
+    rng = np.random.RandomState(7)
+    for trial in range(6):
+        n = 200
+        xy = rng.randint(0, 60, size=(n, 2)).astype(np.float32)
+        wh = rng.randint(8, 40, size=(n, 2)).astype(np.float32)
+        if trial >= 3:                                               # fractional coordinates as the decode produces them
+            xy += rng.rand(n, 2).astype(np.float32); wh += rng.rand(n, 2).astype(np.float32)
+        dets = np.concatenate([xy, xy + wh, np.sort(rng.rand(n, 1).astype(np.float32), 0)[::-1]], 1).astype(np.float32)
+        one = np.float32(1)
+        for _ in range(6):
+            i, j = rng.randint(0, n, 2)
+            a, b = dets[i], dets[j]
+            w = max(min(a[2], b[2]) - max(a[0], b[0]) + one, np.float32(0)); h = max(min(a[3], b[3]) - max(a[1], b[1]) + one, np.float32(0))
+            inter = np.float32(w * h)
+            u = np.float32(np.float32((a[2] - a[0] + one) * (a[3] - a[1] + one)) + np.float32((b[2] - b[0] + one) * (b[3] - b[1] + one))) - inter
+            t0 = np.float32(inter / u)
+            if not (0 < t0 < 1):
+                continue
+            for thr in (t0, np.nextafter(t0, np.float32(0)), np.nextafter(t0, np.float32(1))):
+                ref = onms.nms_sorted(dets, float(thr))
+                keep, num = ops.nms_sorted(torch.from_numpy(dets).to(dev), float(thr))
+                assert int(num[0]) == len(ref) and np.array_equal(keep[0, :len(ref)].cpu().numpy(), ref), (trial, float(thr))
+
+
 # ------------------------------------------------------------------------------------ detection
 def test_detect_matches_oracle_given_same_network_outputs():
     """decode + top-k + NMS on the device vs oracle/detect.py fed with the ENGINE's network outputs:
