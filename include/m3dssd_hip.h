@@ -249,6 +249,28 @@ typedef struct m3d_tree_entry_bf16_desc {
 int m3d_tree_entry_bf16_applicable(const m3d_tree_entry_bf16_desc *d);
 int m3d_tree_entry_bf16_forward(const m3d_tree_entry_bf16_desc *d, m3d_stream_t stream);
 
+/* 3x3 stride-1 pad-1 convolution of the bf16 path by Winograd F(2x2, 3x3) on fp16 MFMA (csrc/bf16_wino2.hip; replaces nn.Conv2d +
+ * BatchNorm2d (+ residual) + activation of model/pose_dla_dcn.py:107-121 and model/M3d_inference_align.py:66-75 where it applies:
+ * Cin % 32 == 0 (>= 64), Cout % 128 == 0, H % 8 == 0, W % 16 == 0):  out = act(conv3x3(in) * scale + shift (+ res)), 2.25x fewer
+ * MFMA passes than the direct kernels -- and operand-bound: measured slower than m3d_conv_bf16_forward's wave-tile kernel, NOT used
+ * by the engine (see the source header).  bf16 -> fp16 input conversion is exact, the transforms run in fp16 (input) / fp32 (weights,
+ * output), products accumulate in fp32.  wfrag = G g G^T * scale[cout] in fp16, fragment order [Cout/32][Cin/32][16 positions]
+ * [2 K steps][64 lanes][8]: lane l, element e of (slice ws, chunk c, position p = 4 i + j, step s) is U[i][j] of output channel
+ * 32 ws + 16 ((r % 8) / 4) + 4 (r / 8) + r % 4 (r = l % 32) and input channel 32 c + 16 s + 8 (l / 32) + e
+ * (m3dssd_amd/engine_bf16.py: pack_wino2); shift fp32 [Cout]; views bf16 NHWC, pixel strides in elements (% 8 == 0); act 0 none,
+ * 1 LeakyReLU(0.01). */
+typedef struct m3d_wino2_bf16_desc {
+    const void *in;
+    int in_cs, N, H, W, Cin, Cout;
+    const void *wfrag;
+    const float *shift;
+    const void *res; int res_cs;     /* optional residual (added before the activation) */
+    void *out; int out_cs;
+    int act;
+} m3d_wino2_bf16_desc;
+int m3d_wino2_bf16_applicable(const m3d_wino2_bf16_desc *d);
+int m3d_wino2_bf16_forward(const m3d_wino2_bf16_desc *d, m3d_stream_t stream);
+
 /* Fused 3-layer RPN head of the bf16 path (model/M3d_inference_align.py:77-210): [1x1 128 -> 256, affine, LeakyReLU] ->
  * [1x1 256 -> 256, affine, LeakyReLU] -> [1x1 256 -> Cout, affine] per 128-pixel tile in ONE launch, hidden activations in LDS.
  * `groups` heads that read the same map share the launch: weights bf16 row-major [groups][256][128], [groups][256][256],

@@ -113,6 +113,15 @@ class TreeEntryBf16Desc(ctypes.Structure):
     ]
 
 
+class Wino2Bf16Desc(ctypes.Structure):
+    """Mirror of ``m3d_wino2_bf16_desc``."""
+    _fields_ = [
+        ("inp", c_void_p), ("in_cs", c_int), ("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("Cout", c_int),
+        ("wfrag", c_void_p), ("shift", c_void_p), ("res", c_void_p), ("res_cs", c_int), ("out", c_void_p), ("out_cs", c_int),
+        ("act", c_int),
+    ]
+
+
 class QkvsBf16Desc(ctypes.Structure):
     """Mirror of ``m3d_qkvs_bf16_desc``."""
     _fields_ = [
@@ -134,6 +143,8 @@ SIGNATURES = {
     "m3d_conv_bf16_variant": (c_int, [ctypes.POINTER(ConvBf16Desc)]),
     "m3d_head_mlp_bf16_forward": (c_int, [ctypes.POINTER(HeadBf16Desc), P]),
     "m3d_head_mlp2_bf16_forward": (c_int, [ctypes.POINTER(Head2Bf16Desc), P]),
+    "m3d_wino2_bf16_applicable": (c_int, [ctypes.POINTER(Wino2Bf16Desc)]),
+    "m3d_wino2_bf16_forward": (c_int, [ctypes.POINTER(Wino2Bf16Desc), P]),
     "m3d_tree_entry_bf16_applicable": (c_int, [ctypes.POINTER(TreeEntryBf16Desc)]),
     "m3d_tree_entry_bf16_forward": (c_int, [ctypes.POINTER(TreeEntryBf16Desc), P]),
     "m3d_anab_qkvs_bf16_forward": (c_int, [ctypes.POINTER(QkvsBf16Desc), P]),

@@ -156,6 +156,25 @@ def pack_tree_entry(w1, s1, wp, sp, device):
     return _f16_checked(out, "tree entry weights").contiguous().to(device)
 
 
+def pack_wino2(w, scale, device):
+    """Weights of m3d_wino2_bf16_forward (csrc/bf16_wino2.hip): w [Cout, Cin, 3, 3] fp32, scale [Cout] (folded BatchNorm) ->
+    U = G g G^T * scale in fp32, rounded once to fp16, in the A-fragment order [Cout/32][Cin/32][16 positions p = 4 i + j][2 K steps]
+    [64 lanes][8]: lane l, element e holds output channel 32 ws + 16 ((r % 8) / 4) + 4 (r / 8) + r % 4 (r = l % 32) and input channel
+    32 c + 16 s + 8 (l / 32) + e."""
+    co, ci = w.shape[0], w.shape[1]
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    g = w.detach().double().cpu() * scale.detach().double().cpu()[:, None, None, None]
+    U = torch.einsum("ik,ockl,jl->ocij", G, g, G).reshape(co, ci, 16).float()                # [Co, Ci, p]
+    lane = torch.arange(64)
+    r = lane % 32
+    ch = 32 * torch.arange(co // 32)[:, None] + (16 * ((r % 8) // 4) + 4 * (r // 8) + r % 4)[None, :]                  # [WS, 64]
+    cin = (32 * torch.arange(ci // 32)[:, None, None, None] + 16 * torch.arange(2)[None, :, None, None]
+           + 8 * (lane // 32)[None, None, :, None] + torch.arange(8)[None, None, None, :])                               # [C, 2, 64, 8]
+    # out[ws, c, p, s, l, e] = U[ch[ws, l], cin[c, s, l, e], p]
+    out = U[ch[:, None, None, None, :, None], cin[None, :, None, :, :, :], torch.arange(16)[None, None, :, None, None, None]]
+    return _f16_checked(out, "Winograd-transformed 3x3 weights").contiguous().to(device)
+
+
 class View16:
     """NHWC bf16 view (possibly a channel slice) of a device buffer; strides in elements."""
     __slots__ = ("t", "ptr", "n", "h", "w", "c", "cs", "esize")

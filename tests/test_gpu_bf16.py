@@ -492,6 +492,53 @@ def test_tree_entry_bf16_matches_torch(n, cin, H, W, with_bottom):
         assert (bot.float() == 512.0).all()
 
 
+@pytest.mark.parametrize("n,cin,cout,H,W,with_res,act", [(2, 64, 128, 8, 16, False, 1), (1, 128, 128, 16, 32, True, 1), (2, 256, 256, 24, 80, True, 1),
+                                                         (1, 128, 256, 48, 160, False, 1), (3, 96, 128, 40, 48, True, 0)])
+def test_wino2_bf16_matches_torch(n, cin, cout, H, W, with_res, act):
+    """m3d_wino2_bf16_forward (Winograd F(2x2,3x3) on fp16 MFMA, csrc/bf16_wino2.hip) against torch's direct convolution on the
+    bf16-rounded input / weights: one bf16 ulp of the result + the fp16 roundings of the transformed operands (2^-11 relative each on
+    sums of four inputs / nine weights: bounded by 3e-3 of the largest output).  Borders (zero padding through the halo), every
+    channel-block / chunk count of the plan's layers, channel slices of wider buffers, residual and activation forms."""
+    from m3dssd_amd import _hip
+    from m3dssd_amd.engine_bf16 import pack_wino2
+    L, dev = _hip.lib(), _dev()
+    g = torch.Generator().manual_seed(cin + H + cout)
+    x = _r(torch.randn(n, cin, H, W, generator=g))
+    w = _r(torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5)
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    res = _r(torch.randn(n, cout, H, W, generator=g)) if with_res else None
+    xin = _nhwc16(x, cin + 8)
+    out = torch.full((n, H, W, cout + 8), 512.0, device=dev, dtype=BF16)
+    rin = _nhwc16(res, cout + 16) if with_res else None
+    wf = pack_wino2(w, sc, dev)
+    shd = sh.to(dev).contiguous()
+    d = _hip.Wino2Bf16Desc()
+    d.inp, d.in_cs, d.N, d.H, d.W, d.Cin, d.Cout = xin.data_ptr(), cin + 8, n, H, W, cin, cout
+    d.wfrag, d.shift, d.out, d.out_cs, d.act = wf.data_ptr(), shd.data_ptr(), out.data_ptr(), cout + 8, act
+    if with_res:
+        d.res, d.res_cs = rin.data_ptr(), cout + 16
+    assert L.m3d_wino2_bf16_applicable(ctypes.byref(d)) == 1
+    _hip.check(L.m3d_wino2_bf16_forward(ctypes.byref(d), _st()))
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.double(), w.double(), None, padding=1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    if with_res:
+        ref = ref + res.double()
+    if act:
+        ref = F.leaky_relu(ref, 0.01)
+    ref = ref.float()
+    got = out[..., :cout].float().permute(0, 3, 1, 2).cpu()
+    assert (out[..., cout:].float() == 512.0).all()
+    err = (got - ref).abs()
+    tol = 2.0 ** -7 * ref.abs() + 3e-3 * ref.abs().max()
+    _log("wino2_bf16", {"shape": [n, cin, cout, H, W], "err": err.max().item(), "scale": ref.abs().max().item(),
+                        "rms": (err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()})
+    assert (err <= tol).all(), (err.max().item(), ref.abs().max().item(), int((err > tol).sum()))
+    bad = _hip.Wino2Bf16Desc()
+    ctypes.pointer(bad)[0] = d
+    bad.H = H + 1
+    assert L.m3d_wino2_bf16_applicable(ctypes.byref(bad)) == 0 and L.m3d_wino2_bf16_forward(ctypes.byref(bad), _st()) != 0
+
+
 @pytest.mark.parametrize("n,h,w", [(2, 8, 16), (1, 13, 21), (3, 48, 160)])
 def test_anab_qkvs_bf16_matches_torch(n, h, w):
     """m3d_anab_qkvs_bf16_forward (query | key | value | gates of ANAB in one launch) against torch on the bf16-rounded operands: q and
