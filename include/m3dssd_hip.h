@@ -478,6 +478,10 @@ int m3d_upsample2x_add(const float *in, int in_cs, const float *wgt, const float
  * index among equals), its fg probability, and fg_all [B][A][HW] (may be NULL). */
 int m3d_anchor_select(const float *cls_planar, int B, int A, int num_classes, int HW, int *sel_idx,
                       float *sel_prob, float *fg_all, m3d_stream_t stream);
+/* The same selection for 4 classes that also writes the detection stage's sort keys score_bits [B][A*HW] (the bits
+ * m3d_score_keys_planar / m3d_bundle_outputs produce) while the logits are in registers. */
+int m3d_anchor_select_keys(const float *cls_planar, int B, int A, int HW, int *sel_idx, float *sel_prob,
+                           unsigned int *score_bits, m3d_stream_t stream);
 /* Top-1 over anchors of a given fg-probability map [B][A][HW] (lowest index among equals). */
 int m3d_fg_top1(const float *prob, int B, int A, int HW, int *idx, float *val, m3d_stream_t stream);
 /* mode 0 = shape_align (table [A][2*kk] -> offmask [B*HW][3*kk], kk=9), mode 1 = center_align
@@ -516,6 +520,11 @@ int m3d_anab_pool_nested(const float *kv, int kv_cs, const float *s, int s_cs, i
  * fp32 conv); fp32 sums, same outputs up to the rounding of the features. */
 int m3d_anab_pool_nested_bf16(const void *kv, int kv_cs, const float *s, int s_cs, int B, int H, int W, int Ck, int Cv,
                               float *scratch, float *khat, int keys_pad, int ck_pad, float *vhatT, int frag, m3d_stream_t stream);
+/* ... that also writes bf16 twins of khat / vhatT (same element order; either may be NULL): the operands of m3d_anab_attend_bf16,
+ * without the two m3d_f32_to_bf16 launches. */
+int m3d_anab_pool_nested_bf16_ex(const void *kv, int kv_cs, const float *s, int s_cs, int B, int H, int W, int Ck, int Cv,
+                                 float *scratch, float *khat, int keys_pad, int ck_pad, float *vhatT, int frag,
+                                 void *khat16, void *vhat16, m3d_stream_t stream);
 /* In-place softmax over the first `valid` columns of each row; columns [valid, cs) are zeroed. */
 int m3d_softmax_rows(float *x, int rows, int valid, int cs, m3d_stream_t stream);
 

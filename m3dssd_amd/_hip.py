@@ -197,6 +197,7 @@ SIGNATURES = {
     "m3d_maxpool2x2": (c_int, [P, c_int, P, c_int] + [c_int] * 4 + [P]),
     "m3d_upsample2x_add": (c_int, [P, c_int, P, P, c_int, P, c_int] + [c_int] * 4 + [P]),
     "m3d_anchor_select": (c_int, [P] + [c_int] * 4 + [P, P, P, P]),
+    "m3d_anchor_select_keys": (c_int, [P] + [c_int] * 3 + [P, P, P, P]),
     "m3d_fg_top1": (c_int, [P, c_int, c_int, c_int, P, P, P]),
     "m3d_align_offsets": (c_int, [c_int, P, P, c_float, P, P, P, P] + [c_float] * 4 + [P] + [c_int] * 5 + [c_ll, P]),
     "m3d_anab_pool_partial": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, P] + [c_int] * 5 + [P]),
@@ -204,6 +205,7 @@ SIGNATURES = {
     "m3d_anab_pool_nested_scratch_bytes": (c_ll, [c_int, c_int]),
     "m3d_anab_pool_nested": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P, c_int, P]),
     "m3d_anab_pool_nested_bf16": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P, c_int, P]),
+    "m3d_anab_pool_nested_bf16_ex": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P, c_int, P, P, P]),
     "m3d_softmax_rows": (c_int, [P, c_int, c_int, c_int, P]),
     "m3d_bundle_outputs": (c_int, [P] * 7 + [c_int] * 3 + [P]),
     "m3d_decode_rows": (c_int, [P] * 9 + [c_int] * 3 + [P]),

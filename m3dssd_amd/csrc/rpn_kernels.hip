@@ -42,8 +42,12 @@ __global__ void anchor_select_kernel(const float *__restrict__ cls, int A, int N
 // merged in that order with a strict '>' -> the same "lowest index wins" tie rule as the sequential kernel above, and each
 // fg value is computed by the same expression (bit-identical).  The one-thread-per-pixel loop above serialised 36 x 4
 // dependent load latencies on 960 waves (60 us for 35 MB).
+// `key` (optional): the detection stage's sort keys [B][A][HW] -- f32_sortable(max foreground class probability), the bits
+// score_keys_planar_kernel / bundle_outputs produce -- written on the way: the logits are in registers here, and the separate key
+// pass re-read all of them (283 MB at bs 64).
 __global__ __launch_bounds__(256) void anchor_select4_kernel(const float *__restrict__ cls, int A, int HW, int *__restrict__ sel_idx,
-                                                             float *__restrict__ sel_prob, float *__restrict__ fg_all)
+                                                             float *__restrict__ sel_prob, float *__restrict__ fg_all,
+                                                             unsigned int *__restrict__ key)
 {
     __shared__ float sbest[4][64];
     __shared__ int sidx[4][64];
@@ -54,16 +58,12 @@ __global__ __launch_bounds__(256) void anchor_select4_kernel(const float *__rest
     const float *base = cls + (size_t)b * 4 * A * HW + (pv ? p : 0);
     float best = -1.f;
     int bi = 0;
-    auto fg_of = [&](const float (&l)[4]) {
-        const float mx = fmaxf(fmaxf(fmaxf(l[0], l[1]), l[2]), l[3]);
-        float sum = 0.f, e0 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float e = expf(l[c] - mx);
-            if (c == 0) e0 = e;
-            sum += e;
-        }
-        return 1.f - e0 / sum;
+    unsigned int *kb = key ? key + (size_t)b * A * HW + (pv ? p : 0) : nullptr;
+    auto fg_of = [&](const float (&l)[4], int an) {
+        // class_softmax4: the same maximum, the same exponentials and the same left-to-right sum as this kernel always used
+        const f32x4 pr = class_softmax4(f32x4{l[0], l[1], l[2], l[3]});
+        if (kb && pv) kb[(size_t)an * HW] = f32_sortable(fg_score(pr));
+        return 1.f - pr[0];
     };
     int a = a0;
     for (; a + 3 <= a1; a += 3) {
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void anchor_select4_kernel(const float *__rest
             for (int c = 0; c < 4; ++c) l[u][c] = base[(size_t)(c * A + a + u) * HW];
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-            const float fg = fg_of(l[u]);
+            const float fg = fg_of(l[u], a + u);
             if (fg_all && pv) fg_all[((size_t)b * A + a + u) * HW + p] = fg;
             if (fg > best) { best = fg; bi = a + u; }
         }
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void anchor_select4_kernel(const float *__rest
         float l[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) l[c] = base[(size_t)(c * A + a) * HW];
-        const float fg = fg_of(l);
+        const float fg = fg_of(l, a);
         if (fg_all && pv) fg_all[((size_t)b * A + a) * HW + p] = fg;
         if (fg > best) { best = fg; bi = a; }
     }
@@ -105,10 +105,20 @@ extern "C" int m3d_anchor_select(const float *cls_planar, int B, int A, int num_
     M3D_REQUIRE(cls_planar && sel_idx && sel_prob && num_classes >= 2 && num_classes <= 8, "anchor_select: bad arguments");
     if (num_classes == 4 && A >= 4)
         hipLaunchKernelGGL(anchor_select4_kernel, dim3(cdiv(HW, 64), B), dim3(256), 0, (hipStream_t)stream, cls_planar, A, HW,
-                           sel_idx, sel_prob, fg_all);
+                           sel_idx, sel_prob, fg_all, (unsigned int *)nullptr);
     else
         hipLaunchKernelGGL(anchor_select_kernel, dim3(cdiv(HW, 256), B), dim3(256), 0, (hipStream_t)stream, cls_planar, A,
                            num_classes, HW, sel_idx, sel_prob, fg_all);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
+extern "C" int m3d_anchor_select_keys(const float *cls_planar, int B, int A, int HW, int *sel_idx, float *sel_prob,
+                                      unsigned int *score_bits, m3d_stream_t stream)
+{
+    M3D_REQUIRE(cls_planar && sel_idx && sel_prob && score_bits && A >= 4, "anchor_select_keys: bad arguments (4 classes, A >= 4)");
+    hipLaunchKernelGGL(anchor_select4_kernel, dim3(cdiv(HW, 64), B), dim3(256), 0, (hipStream_t)stream, cls_planar, A, HW, sel_idx,
+                       sel_prob, (float *)nullptr, score_bits);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
 }
@@ -323,8 +333,10 @@ __global__ void anab_pool_nested_kernel(const T *__restrict__ kv, int kv_cs, con
 
 __global__ void anab_pool_nested_finish_kernel(const float *__restrict__ fine, int H, int W, int Ck, int Cv,
                                                float *__restrict__ khat, int keys_pad, int ck_pad, float *__restrict__ vhatT,
-                                               int frag)
+                                               int frag, __bf16 *__restrict__ khat16, __bf16 *__restrict__ vhat16)
 {
+    // khat16 / vhat16 (optional): bf16 twins of the two outputs (same element order) for the bf16 attention kernel -- what two
+    // m3d_f32_to_bf16 launches produced before
     const int bin = blockIdx.x, b = blockIdx.y;       // bins in scale-major order: 1 + 16 + 64 + 256
     const int C = Ck + Cv;
     int si, sz, local;
@@ -353,11 +365,13 @@ __global__ void anab_pool_nested_finish_kernel(const float *__restrict__ fine, i
         float acc = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
         acc *= inv;
         if (c < Ck) {
-            if (frag & 1) khat[(size_t)b * keys_pad * ck_pad + frag_index(bin, c, ck_pad)] = acc;
-            else khat[((size_t)b * keys_pad + bin) * ck_pad + c] = acc;
+            const size_t o = (frag & 1) ? (size_t)b * keys_pad * ck_pad + frag_index(bin, c, ck_pad) : ((size_t)b * keys_pad + bin) * ck_pad + c;
+            khat[o] = acc;
+            if (khat16) khat16[o] = (__bf16)acc;
         } else {
-            if (frag & 2) vhatT[(size_t)b * Cv * keys_pad + frag_index(c - Ck, bin, keys_pad)] = acc;
-            else vhatT[((size_t)b * Cv + (c - Ck)) * keys_pad + bin] = acc;
+            const size_t o = (frag & 2) ? (size_t)b * Cv * keys_pad + frag_index(c - Ck, bin, keys_pad) : ((size_t)b * Cv + (c - Ck)) * keys_pad + bin;
+            vhatT[o] = acc;
+            if (vhat16) vhat16[o] = (__bf16)acc;
         }
     }
 }
@@ -366,7 +380,8 @@ extern "C" long long m3d_anab_pool_nested_scratch_bytes(int B, int C) { return (
 
 template <typename T>
 static int anab_pool_nested_launch(const T *kv, int kv_cs, const float *s, int s_cs, int B, int H, int W, int Ck, int Cv,
-                                   float *scratch, float *khat, int keys_pad, int ck_pad, float *vhatT, int frag, m3d_stream_t stream)
+                                   float *scratch, float *khat, int keys_pad, int ck_pad, float *vhatT, int frag, m3d_stream_t stream,
+                                   void *khat16 = nullptr, void *vhat16 = nullptr)
 {
     M3D_REQUIRE(!frag || (keys_pad % 32 == 0 && ck_pad % 8 == 0 && Cv % 32 == 0), "anab_pool_nested: fragment layout needs "
                 "keys_pad %% 32 == 0, ck_pad %% 8 == 0, Cv %% 32 == 0");
@@ -379,7 +394,7 @@ static int anab_pool_nested_launch(const T *kv, int kv_cs, const float *s, int s
                        H, W, C);
     M3D_LAUNCH_CHECK();
     hipLaunchKernelGGL(anab_pool_nested_finish_kernel, dim3(337, B), dim3(256), 0, (hipStream_t)stream, scratch, H, W, Ck, Cv,
-                       khat, keys_pad, ck_pad, vhatT, frag);
+                       khat, keys_pad, ck_pad, vhatT, frag, (__bf16 *)khat16, (__bf16 *)vhat16);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
 }
@@ -397,6 +412,14 @@ extern "C" int m3d_anab_pool_nested_bf16(const void *kv, int kv_cs, const float 
 {
     return anab_pool_nested_launch<__bf16>(static_cast<const __bf16 *>(kv), kv_cs, s, s_cs, B, H, W, Ck, Cv, scratch, khat, keys_pad,
                                            ck_pad, vhatT, frag, stream);
+}
+
+extern "C" int m3d_anab_pool_nested_bf16_ex(const void *kv, int kv_cs, const float *s, int s_cs, int B, int H, int W, int Ck, int Cv,
+                                            float *scratch, float *khat, int keys_pad, int ck_pad, float *vhatT, int frag,
+                                            void *khat16, void *vhat16, m3d_stream_t stream)
+{
+    return anab_pool_nested_launch<__bf16>(static_cast<const __bf16 *>(kv), kv_cs, s, s_cs, B, H, W, Ck, Cv, scratch, khat, keys_pad,
+                                           ck_pad, vhatT, frag, stream, khat16, vhat16);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -24,6 +24,7 @@ from . import _hip
 from ._hip import ConvDesc, MlpDesc
 
 BN_EPS = 1e-5
+SELECT_KEYS = os.environ.get("M3D_SELECT_KEYS", "1") != "0"     # anchor_select also writes the detection stage's sort keys
 PSP_SIZES = (1, 4, 8, 16)
 
 
@@ -687,9 +688,16 @@ class Engine:
         sel_prob = torch.empty(B * HW, device=self.device, dtype=torch.float32)
         plan.keep += [sel_idx, sel_prob]
         plan.named["sel_idx"], plan.named["sel_prob"] = sel_idx, sel_prob
-        self._op(plan, "anchor_select", "select", lambda st: _hip.check(L.m3d_anchor_select(
-            cls_pl.data_ptr(), B, A, NC, HW, sel_idx.data_ptr(), sel_prob.data_ptr(), None, st)),
-            nbytes=B * HW * (A * NC + 2) * 4)
+        if NC == 4 and A >= 4 and SELECT_KEYS:
+            # + the detection stage's sort keys (plan.named["score_bits"], created below) while the logits are in registers
+            plan.named["keys_by_select"] = True
+            self._op(plan, "anchor_select", "select", lambda st: _hip.check(L.m3d_anchor_select_keys(
+                cls_pl.data_ptr(), B, A, HW, sel_idx.data_ptr(), sel_prob.data_ptr(), plan.named["score_bits"].data_ptr(), st)),
+                nbytes=B * HW * (A * NC + 2 + A) * 4)
+        else:
+            self._op(plan, "anchor_select", "select", lambda st: _hip.check(L.m3d_anchor_select(
+                cls_pl.data_ptr(), B, A, NC, HW, sel_idx.data_ptr(), sel_prob.data_ptr(), None, st)),
+                nbytes=B * HW * (A * NC + 2) * 4)
 
         means = np.asarray(self.conf.bbox_means, dtype=np.float32).reshape(-1)
         stds = np.asarray(self.conf.bbox_stds, dtype=np.float32).reshape(-1)

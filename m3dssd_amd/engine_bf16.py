@@ -22,7 +22,7 @@ import torch
 
 from . import _hip
 from ._hip import ConvBf16Desc, Head2Bf16Desc, HeadBf16Desc, QkvsBf16Desc, Tail2Bf16Desc, TreeEntryBf16Desc
-from .engine import BN_EPS, PSP_SIZES, Engine, OpCost, _Plan, _rup
+from .engine import BN_EPS, PSP_SIZES, SELECT_KEYS, Engine, OpCost, _Plan, _rup
 
 BF16 = torch.bfloat16
 FUSED_ANAB = os.environ.get("M3D_BF16_FUSED_ANAB", "1") != "0"
@@ -697,9 +697,16 @@ class EngineBF16(Engine):
         sel_prob = torch.empty(B * HW, device=self.device, dtype=torch.float32)
         plan.keep += [sel_idx, sel_prob]
         plan.named["sel_idx"], plan.named["sel_prob"] = sel_idx, sel_prob
-        self._op(plan, "anchor_select", "select", lambda st: _hip.check(L.m3d_anchor_select(
-            cls_pl.data_ptr(), B, A, NC, HW, sel_idx.data_ptr(), sel_prob.data_ptr(), None, st)),
-            nbytes=B * HW * (A * NC + 2) * 4)
+        if NC == 4 and A >= 4 and SELECT_KEYS:
+            # + the detection stage's sort keys (plan.named["score_bits"], created below) while the logits are in registers
+            plan.named["keys_by_select"] = True
+            self._op(plan, "anchor_select", "select", lambda st: _hip.check(L.m3d_anchor_select_keys(
+                cls_pl.data_ptr(), B, A, HW, sel_idx.data_ptr(), sel_prob.data_ptr(), plan.named["score_bits"].data_ptr(), st)),
+                nbytes=B * HW * (A * NC + 2 + A) * 4)
+        else:
+            self._op(plan, "anchor_select", "select", lambda st: _hip.check(L.m3d_anchor_select(
+                cls_pl.data_ptr(), B, A, NC, HW, sel_idx.data_ptr(), sel_prob.data_ptr(), None, st)),
+                nbytes=B * HW * (A * NC + 2) * 4)
         means = np.asarray(self.conf.bbox_means, dtype=np.float32).reshape(-1)
         stds = np.asarray(self.conf.bbox_stds, dtype=np.float32).reshape(-1)
 
@@ -816,9 +823,10 @@ class EngineBF16(Engine):
         if kv16:
             scratch = torch.empty(L.m3d_anab_pool_nested_scratch_bytes(B, ck + cv) // 4, device=self.device, dtype=torch.float32)
             plan.keep.append(scratch)
-            self._op(plan, "anab.pool_nested", "anab_pool", lambda st: _hip.check(L.m3d_anab_pool_nested_bf16(
+            # (+ the bf16 twins of khat / vhatT the attention kernel reads: no separate conversion launches)
+            self._op(plan, "anab.pool_nested", "anab_pool", lambda st: _hip.check(L.m3d_anab_pool_nested_bf16_ex(
                 kvb.ptr, kvb.cs, sg.ptr, sg.cs, B, fh, fw, ck, cv, scratch.data_ptr(), khat.data_ptr(), keys_pad, ck_pad,
-                vhatT.data_ptr(), 0, st)))
+                vhatT.data_ptr(), 0, khat16.data_ptr(), vhat16.data_ptr(), st)))
         elif nested:      # the windows of the four scales nest (48x160 map): one pass over the features
             kv_ptr, s_ptr = kvs.ptr, kvs.ptr + 4 * (ck + cv)
             scratch = torch.empty(L.m3d_anab_pool_nested_scratch_bytes(B, ck + cv) // 4, device=self.device, dtype=torch.float32)
@@ -840,10 +848,11 @@ class EngineBF16(Engine):
             self._op(plan, "anab.pool_finish", "anab_pool", lambda st: _hip.check(L.m3d_anab_pool_finish(
                 partial.data_ptr(), d_bslots.data_ptr(), d_binv.data_ptr(), n_bins, max_slots, ck, cv, khat.data_ptr(),
                 keys_pad, ck_pad, vhatT.data_ptr(), B, 0, st)))
-        self._op(plan, "anab.khat_bf16", "convert", lambda st: _hip.check(L.m3d_f32_to_bf16(
-            khat.data_ptr(), khat16.data_ptr(), khat.numel(), st)))
-        self._op(plan, "anab.vhat_bf16", "convert", lambda st: _hip.check(L.m3d_f32_to_bf16(
-            vhatT.data_ptr(), vhat16.data_ptr(), vhatT.numel(), st)))
+        if not kv16:
+            self._op(plan, "anab.khat_bf16", "convert", lambda st: _hip.check(L.m3d_f32_to_bf16(
+                khat.data_ptr(), khat16.data_ptr(), khat.numel(), st)))
+            self._op(plan, "anab.vhat_bf16", "convert", lambda st: _hip.check(L.m3d_f32_to_bf16(
+                vhatT.data_ptr(), vhat16.data_ptr(), vhatT.numel(), st)))
         if FUSED_ANAB and ck_pad == 192 and cv == 128:
             # logits + softmax + P.V in one launch: the fp32 logits / bf16 probabilities (1.1 GB at bs = 64) never reach HBM
             sc, sh = P["anab.bn.scale"], P["anab.bn.shift"]

@@ -139,7 +139,8 @@ class PipelinedDetector:
         if self.planar:
             if self.n_join < self.n_fwd:
                 self._forward(self.n_join, self.n_fwd, buf)
-            score_keys_planar(self.eng, self.plan)
+            if not self.plan.named.get("keys_by_select"):    # else anchor_select wrote them on the way (engine: SELECT_KEYS)
+                score_keys_planar(self.eng, self.plan)
         else:
             self._forward(self.n_join, None, buf)
 

@@ -472,6 +472,18 @@ def test_planar_keys_and_decode_equal_bundled_form(crop, B):
     plan.named["score_bits"].zero_()
     score_keys_planar(eng, plan)
     assert torch.equal(plan.named["score_bits"], bits_bundle)
+    # the keys m3d_anchor_select_keys writes on the way (what the pipelined detector uses): the same bits, and the same selection
+    assert plan.named.get("keys_by_select")
+    HW = R0 = plan.named["score_bits"].shape[1] // eng.A
+    si, sp = plan.named["sel_idx"].clone(), plan.named["sel_prob"].clone()
+    plan.named["score_bits"].zero_()
+    st0 = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ti, tp = torch.empty_like(si), torch.empty_like(sp)
+    _hip.check(L.m3d_anchor_select_keys(plan.named["cls_planar"].data_ptr(), B, eng.A, HW, ti.data_ptr(), tp.data_ptr(),
+                                        plan.named["score_bits"].data_ptr(), st0))
+    assert torch.equal(plan.named["score_bits"], bits_bundle) and torch.equal(ti, si) and torch.equal(tp, sp)
+    _hip.check(L.m3d_anchor_select(plan.named["cls_planar"].data_ptr(), B, eng.A, 4, HW, ti.data_ptr(), tp.data_ptr(), None, st0))
+    assert torch.equal(ti, si) and torch.equal(tp, sp)
     for scale in (None, torch.tensor([1.0, 0.75, 1.3][:B], device=dev)):
         a0, k0, n0 = detect_from_outputs(eng, plan, prob, b2, b3, rois, conf, scale)
         a1, k1, n1 = detect_from_planar(eng, plan, rois, conf, scale)
