@@ -209,11 +209,11 @@ typedef struct m3d_conv_bf16_desc {
     long long in_group_off, wgt_group_off, out_group_off;
     int ss_group_off;
     /* Deformable 3x3 / stride 1 / pad 1 only, all three optional (NULL / 0 = implicit-GEMM kernel as before): an fp16 copy of
-     * `wgt` (same [Cout_pad][Kpad] layout; bf16 -> fp16 is exact for |w| in [6.1e-5, 65504]) and >= 1024 bytes of device
-     * scratch enable the LDS-patch kernel (csrc/bf16_dcn_patch.hip): the launch's largest |offset| is reduced on the device
-     * into dcn_ws, and the sampling runs from an LDS-resident fp16 window when it fits (|offset| <= 9 on maps with
-     * H % 16 == 0, <= 6 with H % 8 == 0; W % 16 == 0, Cin % 32 == 0, Cout_pad % 128 == 0), else the implicit-GEMM kernel
-     * does the launch's work -- decided on the device, no host synchronisation. */
+     * `wgt` (same [Cout_pad][Kpad] layout; bf16 -> fp16 is exact for |w| in [6.1e-5, 65504]) and m3d_conv_bf16_dcn_ws_bytes(N, Ho,
+     * Wo) bytes of device scratch enable the LDS-patch kernel (csrc/bf16_dcn_patch.hip): every 16 x 16 (H % 16 == 0) or 8 x 16
+     * (H % 8 == 0) pixel tile samples from an LDS-resident fp16 window sized to its own largest |offset| when that is <= 9 (<= 6)
+     * and raises its word in dcn_ws otherwise; the implicit-GEMM kernel launched behind it recomputes the tiles that did
+     * (W % 16 == 0, Cin % 32 == 0, Cout_pad % 128 == 0) -- decided on the device per tile, no host synchronisation. */
     const void *wgt_f16;
     void *dcn_ws;
     long long dcn_ws_bytes;
@@ -227,8 +227,10 @@ int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t stream);
 /* Which kernel m3d_conv_bf16_forward launches for `d` (profiling labels; no launch): 0 = implicit-GEMM tile
  * (bf16_conv_kernel), 1 = 3x3 halo tile of 8 x 16 pixels, 2 = 3x3 halo tile of 8 x 32 pixels (bf16_conv3x3_halo_kernel),
  * 3 / 4 = deformable 3x3 with the sampling window in LDS, 8 x 16 / 16 x 16 pixel patches (bf16_dcn_patch_kernel; the
- * implicit-GEMM kernel is launched behind it and takes over on the device when the launch's offsets do not fit),
+ * implicit-GEMM kernel is launched behind it and recomputes, on the device, the tiles whose offsets do not fit),
  * 5 = 3x3 with 128 x 128 wave tiles (bf16_conv3x3_wide_kernel; needs wgt_wave). */
+/* Bytes of dcn_ws the LDS-patch DCNv2 kernel needs for N x Ho x Wo output pixels (one flag word per pixel tile; 0 = the map does not tile). */
+long long m3d_conv_bf16_dcn_ws_bytes(int N, int Ho, int Wo);
 int m3d_conv_bf16_variant(const m3d_conv_bf16_desc *d);
 
 /* Entry of a DLA tree of the bf16 path in one launch (model/pose_dla_dcn.py:314-327, :107-121): bottom = MaxPool2d(2, 2)(x) (written

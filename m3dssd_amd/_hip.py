@@ -140,6 +140,7 @@ SIGNATURES = {
     "m3d_source_hashes": (ctypes.c_char_p, []),
     "m3d_conv2d_forward": (c_int, [ctypes.POINTER(ConvDesc), P]),
     "m3d_conv_bf16_forward": (c_int, [ctypes.POINTER(ConvBf16Desc), P]),
+    "m3d_conv_bf16_dcn_ws_bytes": (c_ll, [c_int, c_int, c_int]),
     "m3d_conv_bf16_variant": (c_int, [ctypes.POINTER(ConvBf16Desc)]),
     "m3d_head_mlp_bf16_forward": (c_int, [ctypes.POINTER(HeadBf16Desc), P]),
     "m3d_head_mlp2_bf16_forward": (c_int, [ctypes.POINTER(Head2Bf16Desc), P]),

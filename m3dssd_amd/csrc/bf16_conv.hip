@@ -55,9 +55,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
     const int wm = (wave / WN) * (TM * 32), wn = (wave % WN) * (TN * 32);
     if constexpr (DEFORM) {
         // fallback role (bf16_dcn_patch.hip): the LDS-patch kernel has done this launch's work when the sampling window fits
+        // the patch kernel left one word per patch tile: non-zero = its window did not fit.  This workgroup's 128 pixels (linear in
+        // image, row, column) recompute whatever such tiles they touch -- the whole 128-pixel tile, the values of the neighbours
+        // from fitting tiles included (same convolution, rounding of the other kernel) -- and nothing else runs.
         if (a.gate) {
-            if (dcn_bound_radius(a.gate, reinterpret_cast<unsigned *>(lds), tid, 256) <= a.gate_rmax) return;
-            __syncthreads();
+            int need = 0;
+            if (tid < BM) {
+                const int tl = blockIdx.x;                          // (tile order: see below)
+                const int ntl = a.tiles_m * a.tiles_n;
+                const int q = ntl >> 3, r = ntl & 7, xcd = tl & 7, idx = tl >> 3;
+                const int t2 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+                const int m = (t2 / a.tiles_n) * BM + tid;
+                if (m < a.M) {
+                    const int img = m / a.HoWo, rem = m - img * a.HoWo;
+                    const int y = rem / a.Wo, x = rem - y * a.Wo;
+                    need = a.gate[(img * a.gate_tpy + y / a.gate_th) * a.gate_tpx + (x >> 4)] != 0u;
+                }
+            }
+            if (!__syncthreads_or(need)) return;
         }
     }
     BTRACE_INIT();
@@ -662,7 +677,7 @@ extern "C" int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t s
     const int bn = d->Cout_pad % 128 == 0 ? 128 : (d->Cout_pad % 64 == 0 ? 64 : 32);
     a.tiles_m = cdiv(M, 128); a.tiles_n = d->Cout_pad / bn;
     a.uniform_k = (d->Cin % 64 == 0 && K % 64 == 0) ? 1 : 0;
-    a.gate = nullptr; a.gate_rmax = 0;
+    a.gate = nullptr; a.gate_th = a.gate_tpx = a.gate_tpy = 0;
 #ifdef BF16_TRACE
     a.trace = g_bf16_trace;
 #endif
@@ -687,14 +702,13 @@ extern "C" int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t s
         M3D_LAUNCH_CHECK();
         return M3D_OK;
     }
-    // DCNv2 3x3 with an fp16 weight copy and a bound workspace: |offset| pre-pass, then the LDS-patch kernel and this file's
-    // implicit-GEMM kernel as its fallback -- both read the bound, exactly one of them does the work (bf16_dcn_patch.hip)
+    // DCNv2 3x3 with an fp16 weight copy and a flag workspace: the LDS-patch kernel, one word per patch tile ("my window did not fit"),
+    // and this file's implicit-GEMM kernel behind it for the tiles that carry the flag (bf16_dcn_patch.hip)
     const int pvar = deform ? dcn_patch_variant(d) : 0;
     if (pvar) {
         int rc;
-        if ((rc = launch_dcn_bound(d, st))) return rc;
         if ((rc = launch_dcn_patch(a, d, pvar, st))) return rc;
-        a.gate = (const unsigned *)d->dcn_ws; a.gate_rmax = dcn_patch_rmax(pvar);
+        a.gate = (const unsigned *)d->dcn_ws; a.gate_th = pvar; a.gate_tpx = d->Wo / 16; a.gate_tpy = d->Ho / pvar;
     }
 #define LAUNCH(BN_, DF_) hipLaunchKernelGGL((bf16_conv_kernel<BN_, DF_>), grid, block, 0, st, a)
     if (bn == 128) { if (deform) LAUNCH(128, true); else LAUNCH(128, false); }

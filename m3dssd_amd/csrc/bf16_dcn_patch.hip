@@ -19,9 +19,11 @@
 //   * the sampling state of a (pixel, tap) -- one LDS offset, four fp16 corner weights with the modulation mask folded in --
 //     is built once per workgroup and kept in 27 registers;
 //   * weights (fp16 copy of the packed bf16 weights, exact) are staged per (tap, chunk) as in the halo-tile kernel.
-// The offsets decide whether the window fits: a pre-pass (dcn_bound_kernel) reduces max |offset| of the launch to 256 partial
-// maxima; this kernel and the implicit-GEMM fallback both read them, exactly one of the two does the work (R <= RMAX here,
-// otherwise there).  Everything stays inside one stream / one captured graph, no host round trip.
+// The offsets decide whether the window fits, PER TILE (round 5; before: one decision per launch from a |offset| pre-pass): the
+// workgroup reduces max |offset| of its own pixels (it has fetched their offsets anyway), sizes its window to that radius, and when
+// the radius exceeds RMAX it only raises the tile's flag word in dcn_ws; the implicit-GEMM kernel launched behind this one recomputes
+// the 128-pixel tiles that touch a flagged patch tile and nothing else.  No pre-pass, no host round trip, and a few outlier pixels
+// no longer send a whole launch to the slow kernel.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -44,36 +46,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define DP_PS 80                         // bytes per patch pixel: 32 fp16 channels + 16 bytes pad
 #define DP_WKB 64                        // bytes per weight row and step (32 fp16 channels)
 
-// ---- largest |offset| of a launch -------------------------------------------------------------------------------------------
-// partial[b] = max over the pixels of block b of the bit pattern of |offset| (non-negative floats order like their bits; a NaN
-// sorts above every number and sends the launch to the fallback kernel).
-__global__ __launch_bounds__(256) void dcn_bound_kernel(const float *__restrict__ om, int M, int om_cs, int n_off, unsigned *__restrict__ partial)
-{
-    __shared__ unsigned red[4];
-    unsigned mx = 0u;
-    const int n4 = (n_off + 3) >> 2;
-    for (int m = blockIdx.x * 256 + threadIdx.x; m < M; m += gridDim.x * 256) {
-        const f32x4 *row = reinterpret_cast<const f32x4 *>(om + (size_t)m * om_cs);
-        for (int q = 0; q < n4; ++q) {
-            const f32x4 v = row[q];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (4 * q + e < n_off) mx = max(mx, __float_as_uint(v[e]) & 0x7fffffffu);
-        }
-    }
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, s, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
-}
-
 // TPS = taps per weight stage (one barrier per stage): 1 for the 4-wave tile (two workgroups per CU cover each other's
 // barriers), 3 for the 8-wave tile -- one workgroup per CU whose waves all stop at the same barrier: with a barrier per tap
 // (256 MFMA cycles per wave) the 16 x 16 tile spent 2500 cycles per (tap, chunk) on 512 cycles of MFMA per SIMD.
 template <int TH, int RMAX, int TPS>
 __global__ __launch_bounds__(TH * 32) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void bf16_dcn_patch_kernel(const Bf16Args a, const void *__restrict__ wgt16, const unsigned *__restrict__ bound)
+void bf16_dcn_patch_kernel(const Bf16Args a, const void *__restrict__ wgt16, unsigned *__restrict__ flags)
 {
     constexpr int TW = 16, BM = TH * TW, BN = 128, NT = TH * 32, WAVES = TH / 2;
     constexpr int PHMAX = TH + 3 + 2 * RMAX, PWMAX = TW + 3 + 2 * RMAX;
@@ -130,9 +108,17 @@ void bf16_dcn_patch_kernel(const Bf16Args a, const void *__restrict__ wgt16, con
         if (a.shift) ssh = a.shift[n0 + tid];
     }
 
-    // ---- does the window of this launch fit?  (uniform over the launch: the fallback kernel takes the opposite branch) --------
-    const int R = dcn_bound_radius(bound, reinterpret_cast<unsigned *>(lds), tid, NT);
+    // ---- does the window of THIS tile fit?  R = the radius its own pixels need (smaller windows where the offsets are small); a
+    // tile that does not fit raises its flag and leaves: the implicit-GEMM kernel launched behind this one recomputes it ------------
+    unsigned omx = 0u;
+    if (pvalid) {
+#pragma unroll
+        for (int q = 0; q < 18; ++q) omx = max(omx, __float_as_uint(omv[q >> 2][q & 3]) & 0x7fffffffu);
+    }
+    const int R = dcn_tile_radius(omx, reinterpret_cast<unsigned *>(lds), tid, NT);
+    if (tid == 0) flags[tile_m] = R > RMAX ? 1u : 0u;           // (the channel blocks of a pixel tile write the same word)
     if (R > RMAX) return;
+    __syncthreads();                                            // the scratch words are patch bytes from here on
     PTRACE();
     const int PH = TH + 3 + 2 * R, PW = TW + 3 + 2 * R, PWB = PW * DP_PS;
     const int py0 = y0 - 1 - R, px0 = x0 - 1 - R;               // image position of patch pixel (0, 0)
@@ -369,29 +355,23 @@ int dcn_patch_variant(const m3d_conv_bf16_desc *d)
 {
     static int on = -1;                   // M3D_BF16_DCN_PATCH=0: implicit-GEMM kernel everywhere (A/B)
     if (on < 0) { const char *e = getenv("M3D_BF16_DCN_PATCH"); on = e ? atoi(e) : 1; }
-    if (!on || !d->dcn_offmask || !d->wgt_f16 || !d->dcn_ws || d->dcn_ws_bytes < DCN_BOUND_PARTIALS * 4) return 0;
+    if (!on || !d->dcn_offmask || !d->wgt_f16 || !d->dcn_ws) return 0;
     if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->groups != 1 || d->wgt_img_stride != 0) return 0;
     if (d->Cin % 32 != 0 || d->Cout_pad % 128 != 0 || d->W % 16 != 0 || d->dcn_om_cs < 28 || d->dcn_om_cs % 4 != 0) return 0;
-    if (d->H % 16 == 0) return 16;
-    if (d->H % 8 == 0) return 8;
-    return 0;
+    const int v = d->H % 16 == 0 ? 16 : d->H % 8 == 0 ? 8 : 0;
+    return (v && d->dcn_ws_bytes >= dcn_patch_ws_bytes(d, v)) ? v : 0;      // (one flag word per pixel tile: m3d_conv_bf16_dcn_ws_bytes)
 }
-int dcn_patch_rmax(int variant) { return variant == 16 ? 9 : 6; }
 
-int launch_dcn_bound(const m3d_conv_bf16_desc *d, hipStream_t st)
+long long dcn_patch_ws_bytes(const m3d_conv_bf16_desc *d, int variant)
 {
-    const long long M = (long long)d->N * d->Ho * d->Wo;
-    hipLaunchKernelGGL(dcn_bound_kernel, dim3(DCN_BOUND_PARTIALS), dim3(256), 0, st, d->dcn_offmask, (int)M, d->dcn_om_cs, 2 * d->kh * d->kw,
-                       (unsigned *)d->dcn_ws);
-    M3D_LAUNCH_CHECK();
-    return M3D_OK;
+    return variant ? 4ll * d->N * (d->Ho / variant) * (d->Wo / 16) : 0;
 }
 
 int launch_dcn_patch(const Bf16Args &a0, const m3d_conv_bf16_desc *d, int variant, hipStream_t st)
 {
     Bf16Args a = a0;
     a.tiles_n = d->Cout_pad / 128;
-    const unsigned *bound = (const unsigned *)d->dcn_ws;
+    unsigned *bound = (unsigned *)d->dcn_ws;                      // one flag per pixel tile
     if (variant == 16) {
         a.tiles_m = d->N * (d->Ho / 16) * (d->Wo / 16);
         hipLaunchKernelGGL((bf16_dcn_patch_kernel<16, 9, 3>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, st, a, d->wgt_f16, bound);
@@ -401,4 +381,10 @@ int launch_dcn_patch(const Bf16Args &a0, const m3d_conv_bf16_desc *d, int varian
     }
     M3D_LAUNCH_CHECK();
     return M3D_OK;
+}
+
+extern "C" long long m3d_conv_bf16_dcn_ws_bytes(int N, int Ho, int Wo)
+{
+    const int v = Ho % 16 == 0 ? 16 : Ho % 8 == 0 ? 8 : 0;
+    return (v && Wo % 16 == 0) ? 4ll * N * (Ho / v) * (Wo / 16) : 0;
 }

@@ -28,21 +28,21 @@ struct Bf16Args {
     int tiles_m, tiles_n;
     int lane_perm;             // halo kernel: 1 = bank-conflict-free lane -> pixel map (0 = identity, for A/B)
     int uniform_k;             // Cin % 64 == 0 (or 1x1 with K % 64 == 0): every K-step lies in one tap, channel offset is wave-uniform
-    const unsigned *gate;      // deformable implicit-GEMM kernel as the FALLBACK of the LDS-patch kernel (bf16_dcn_patch.hip): the
-    int gate_rmax;             // launch's |offset| maxima; this kernel works only when the window does not fit (radius > gate_rmax)
+    const unsigned *gate;      // deformable implicit-GEMM kernel as the FALLBACK of the LDS-patch kernel (bf16_dcn_patch.hip): one word per
+    int gate_th, gate_tpx, gate_tpy;   // patch tile (gate_th x 16 pixels, gate_tpx x gate_tpy tiles per image), non-zero = "my window did
+                               // not fit": this kernel works on the 128-pixel tiles that touch such a patch tile and on nothing else
 #ifdef BF16_TRACE
     long long *trace;
 #endif
 };
 
-// ---- largest |offset| of a deformable launch (bf16_dcn_patch.hip) ---------------------------------------------------------------
-// `partial`: DCN_BOUND_PARTIALS bit patterns of max |offset| written by dcn_bound_kernel.  Returns the radius R = ceil(max) the
-// sampling window has to cover beyond the 3x3 taps, uniform over the workgroup; a NaN / inf offset gives 2^20 (never fits).
-// `scratch`: >= 32 bytes of LDS, free again after the NEXT barrier of the caller.  nt = threads of the workgroup (>= 256).
-#define DCN_BOUND_PARTIALS 256
-__device__ __forceinline__ int dcn_bound_radius(const unsigned *partial, unsigned *scratch, int tid, int nt)
+// ---- largest |offset| of a patch tile (bf16_dcn_patch.hip) ---------------------------------------------------------------------
+// Returns the radius R = ceil(max |offset|) the sampling window of the workgroup's pixels has to cover beyond the 3x3 taps, uniform
+// over the workgroup; a NaN / inf offset gives 2^20 (never fits).  `scratch`: >= 32 bytes of LDS, free again after the NEXT barrier
+// of the caller.  nt = threads of the workgroup (>= 256).
+// mx = largest |offset| bit pattern among this thread's pixels (0 for none).  -> the radius shared by the workgroup.
+__device__ __forceinline__ int dcn_tile_radius(unsigned mx, unsigned *scratch, int tid, int nt)
 {
-    unsigned mx = partial[tid & (DCN_BOUND_PARTIALS - 1)];
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, s, 64));
     if ((tid & 63) == 0) scratch[tid >> 6] = mx;
@@ -51,9 +51,8 @@ __device__ __forceinline__ int dcn_bound_radius(const unsigned *partial, unsigne
     for (int w = 0; w < nt / 64; ++w) m = max(m, scratch[w]);
     return m >= 0x7f800000u ? (1 << 20) : (int)ceilf(__uint_as_float(m));
 }
+long long dcn_patch_ws_bytes(const m3d_conv_bf16_desc *d, int variant);
 int dcn_patch_variant(const m3d_conv_bf16_desc *d);
-int dcn_patch_rmax(int variant);
-int launch_dcn_bound(const m3d_conv_bf16_desc *d, hipStream_t st);
 struct Bf16Args;
 int launch_dcn_patch(const Bf16Args &a0, const m3d_conv_bf16_desc *d, int variant, hipStream_t st);
 int conv_wide_applicable(const m3d_conv_bf16_desc *d);                                  // bf16_conv_wide.hip

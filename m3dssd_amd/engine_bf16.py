@@ -388,9 +388,9 @@ class EngineBF16(Engine):
         if om is not None:
             d.dcn_offmask, d.dcn_om_cs = om.ptr, om.cs
             if wgt_f16 is not None:
-                # LDS-patch DCNv2 kernel (csrc/bf16_dcn_patch.hip): fp16 copy of the packed weights + the device scratch of the
-                # |offset| bound; the library decides per launch, on the device, whether the sampling window fits
-                ws = torch.zeros(256, device=self.device, dtype=torch.int32)
+                # LDS-patch DCNv2 kernel (csrc/bf16_dcn_patch.hip): fp16 copy of the packed weights + one flag word per pixel tile; the
+                # library decides per tile, on the device, whether the sampling window fits
+                ws = torch.zeros(max(256, self.L.m3d_conv_bf16_dcn_ws_bytes(x.n, out.h, out.w) // 4), device=self.device, dtype=torch.int32)
                 plan.keep += [wgt_f16, ws]
                 d.wgt_f16, d.dcn_ws, d.dcn_ws_bytes = wgt_f16.data_ptr(), ws.data_ptr(), ws.numel() * 4
         elif wgt_wave is not None:

@@ -123,8 +123,9 @@ def _run_conv(x, wt, bias=None, bn=None, stride=1, pad=0, act=0, res=None, res_m
         d.dcn_offmask, d.dcn_om_cs = o.data_ptr(), o.shape[-1]
         keep.append(o)
         if patch:           # LDS-patch DCNv2 kernel: fp16 weight copy + the device scratch of the |offset| bound
-            w16, ws = wp.float().to(torch.float16).contiguous(), torch.zeros(256, device=dev, dtype=torch.int32)
-            d.wgt_f16, d.dcn_ws, d.dcn_ws_bytes = w16.data_ptr(), ws.data_ptr(), 1024
+            nws = max(256, _hip.lib().m3d_conv_bf16_dcn_ws_bytes(n, ho, wo) // 4)
+            w16, ws = wp.float().to(torch.float16).contiguous(), torch.full((nws,), 7, device=dev, dtype=torch.int32)
+            d.wgt_f16, d.dcn_ws, d.dcn_ws_bytes = w16.data_ptr(), ws.data_ptr(), 4 * nws
             keep += [w16, ws]
     if out_mode == 0:
         ocs = (co + 7) // 8 * 8 + 8
@@ -725,9 +726,9 @@ def test_dcn_bf16_patch_kernel_matches_oracle(shape, variant, off_std, clamp):
 
 
 def test_dcn_bf16_patch_kernel_hands_over_when_the_window_does_not_fit():
-    """The decision is taken on the device from the launch's largest |offset|: inside the radius the patch kernel does the work,
-    one offset beyond it (or a NaN) and the implicit-GEMM kernel behind it does -- the results are then bit-identical to a
-    launch without the patch kernel."""
+    """The decision is taken on the device PER PIXEL TILE from the tile's largest |offset|: inside the radius the patch kernel does the
+    tile, one offset beyond it (or a NaN) and the tile raises its flag -- the implicit-GEMM kernel behind it then recomputes the
+    128-pixel tiles that touch it, bit-identical to a launch without the patch kernel, and leaves the rest of the map alone."""
     from oracle import dcn as odcn
     shape = (2, 64, 16, 32, 128)
     x, wt, b, off, m, om = _dcn_case(shape, 1.0, 2, 4.0)
@@ -736,10 +737,26 @@ def test_dcn_bf16_patch_kernel_hands_over_when_the_window_does_not_fit():
     assert not torch.equal(fit, base)                           # a different kernel did the work (fp16 sample vs bf16 sample)
     for bad in (10.25, -37.0, float("nan")):
         om2 = om.clone()
-        om2[1, 7, 9, 5] = bad                                   # dw of tap 2 at one pixel
+        om2[1, 7, 9, 5] = bad                                   # dw of tap 2 at one pixel of image 1, patch tile (rows 0-15, columns 0-15)
         base2 = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 0, om2, variant=0)
         got2 = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 0, om2, variant=4, patch=True)
-        assert torch.equal(got2, base2), bad
+        # image 1: every 128-pixel tile (4 rows of 32) touches the flagged patch tile -> the implicit-GEMM kernel's bits;
+        # image 0: untouched -> the patch kernel's bits
+        assert torch.equal(got2[1], base2[1]), bad
+        assert torch.equal(got2[0], fit[0]) and not torch.equal(got2[0], base2[0]), bad
+    # a flagged tile on a map with several 128-pixel tiles per patch-tile row: only the touching ones are recomputed, every pixel
+    # carries one of the two kernels' bits, the flagged tile itself the implicit-GEMM kernel's
+    shape = (1, 64, 32, 160, 128)
+    x, wt, b, off, m, om = _dcn_case(shape, 1.0, 3, 4.0)
+    om2 = om.clone()
+    om2[0, 20, 100, 3] = 15.5                                   # patch tile rows 16-31, columns 96-111
+    base2 = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 0, om2, variant=0)
+    fit = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 0, om, variant=4, patch=True)
+    got2 = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 0, om2, variant=4, patch=True)
+    assert torch.equal(got2[0, :, 16:32, 96:112], base2[0, :, 16:32, 96:112])
+    assert torch.equal(got2[0, :, 0:16], fit[0, :, 0:16])       # rows 0-15: no 128-pixel tile of theirs reaches row 16
+    same_base, same_fit = (got2 == base2).all(1), (got2 == fit).all(1)
+    assert bool((same_base | same_fit).all()) and not bool(same_base.all())
     # exactly at the radius it still fits
     om3 = om.clone()
     om3[0, 3, 4, 0] = 9.0
