@@ -1131,11 +1131,13 @@ def test_bf16_decoded_boxes_in_physical_units(crop, B):
     assert rep["kept_score"] < BF16_PROB_TOL
 
 
-def test_anab_pool_nested_bf16_matches_fp32_kernel():
-    """m3d_anab_pool_nested_bf16 (K|V map stored as bf16) against m3d_anab_pool_nested on the widened values: same sums."""
+@pytest.mark.parametrize("B,H,W", [(2, 16, 32), (2, 48, 160)])
+def test_anab_pool_nested_bf16_matches_fp32_kernel(B, H, W):
+    """m3d_anab_pool_nested_bf16[_ex] (K|V map stored as bf16) against m3d_anab_pool_nested on the widened values: the same fp32 sums
+    in the same order (bit-identical), and the bf16 twins of the _ex entry == the rounded fp32 outputs."""
     from m3dssd_amd import _hip
     L, dev = _hip.lib(), _dev()
-    B, H, W, ck, cv = 2, 16, 32, 168, 128
+    ck, cv = 168, 128
     g = torch.Generator().manual_seed(5)
     kv = _r(torch.randn(B * H * W, ck + cv, generator=g))
     sg = torch.rand(B * H * W, 4, generator=g)
@@ -1148,8 +1150,16 @@ def test_anab_pool_nested_bf16_matches_fp32_kernel():
         d_s = sg.to(dev).contiguous()
         if use16:
             d_kv = kv.to(BF16).to(dev).contiguous()
+            k16, v16 = torch.zeros(B * kp * ckp, device=dev, dtype=BF16), torch.zeros(B * cv * kp, device=dev, dtype=BF16)
+            _hip.check(L.m3d_anab_pool_nested_bf16_ex(d_kv.data_ptr(), ck + cv, d_s.data_ptr(), 4, B, H, W, ck, cv, scratch.data_ptr(),
+                                                      khat.data_ptr(), kp, ckp, vhat.data_ptr(), 0, k16.data_ptr(), v16.data_ptr(), _st()))
+            torch.cuda.synchronize()
+            assert torch.equal(k16, khat.to(BF16)) and torch.equal(v16, vhat.to(BF16))
+            k2, v2 = torch.zeros_like(khat), torch.zeros_like(vhat)
             _hip.check(L.m3d_anab_pool_nested_bf16(d_kv.data_ptr(), ck + cv, d_s.data_ptr(), 4, B, H, W, ck, cv, scratch.data_ptr(),
-                                                   khat.data_ptr(), kp, ckp, vhat.data_ptr(), 0, _st()))
+                                                   k2.data_ptr(), kp, ckp, v2.data_ptr(), 0, _st()))
+            torch.cuda.synchronize()
+            assert torch.equal(k2, khat) and torch.equal(v2, vhat)
         else:
             d_kv = kv.to(dev).contiguous()
             _hip.check(L.m3d_anab_pool_nested(d_kv.data_ptr(), ck + cv, d_s.data_ptr(), 4, B, H, W, ck, cv, scratch.data_ptr(),
