@@ -816,8 +816,8 @@ def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=N
                                                                      "accumulation / epilogues" if bf16 else "fp32"),
                        "per_gpu_batch": B, "global_batch": B * world, "resolution": [CROP[1], CROP[0]],
                        "parallelism": "dp%d (batch sharded, 1 all-gather of [B,40,14] detections)" % world},
-            "launch": ("hipGraph replay, detect(k-1) overlapped with forward(k); the timed graph runs m3d_score_keys_planar + planar decode "
-                       "where the eager per-kernel breakdown below shows `bundle`" if use_pipe else
+            "launch": ("hipGraph replay, detect(k-1) overlapped with forward(k); the timed graph decodes from the planar head outputs (sort keys "
+                       "written by anchor_select) where the eager per-kernel breakdown below shows `bundle`" if use_pipe else
                        "hipGraph replay" if use_graph else "eager"),
             # Winograd F(2x2,3x3) launches: `achieved` counts the MFMA FLOPs the kernel EXECUTES (16 multiplies per 2x2 output
             # tile and channel pair = the direct-convolution count / 2.25), so frac is the MFMA-pipe utilisation and cannot
