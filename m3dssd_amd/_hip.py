@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "build", "libm3dssd_hip.so")
+SO_PATH = os.environ.get("M3D_HIP_LIB") or os.path.join(CSRC, "build", "libm3dssd_hip.so")   # (override: diagnostic builds only)
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "m3dssd_hip.h")
 
 c_int, c_float, c_ll, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_longlong, ctypes.c_void_p

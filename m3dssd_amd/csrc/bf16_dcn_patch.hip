@@ -32,6 +32,10 @@
 
 #include "bf16_tile.h"
 
+#ifndef DP_ABL
+#define DP_ABL 0                         // diagnostic builds: operand ablations of the K loop (timing only)
+#endif
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #ifdef BF16_TRACE
@@ -204,11 +208,20 @@ void bf16_dcn_patch_kernel(const Bf16Args a, const void *__restrict__ wgt16, uns
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const u32x4 c00 = *reinterpret_cast<const u32x4 *>(P0 + s * 32), c01 = *reinterpret_cast<const u32x4 *>(P0 + s * 32 + DP_PS);
+#if DP_ABL & 2                     // diagnostic: two of the four corners not read
+            const u32x4 c10 = c00, c11 = c01;
+#else
             const u32x4 c10 = *reinterpret_cast<const u32x4 *>(P1 + s * 32), c11 = *reinterpret_cast<const u32x4 *>(P1 + s * 32 + DP_PS);
+#endif
             const int co = ((2 * s + lh) ^ swk) << 4;
             f16x8 fw[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const f16x8 *>(Wb + j * 32 * DP_WKB + co);
+            for (int j = 0; j < 4; ++j) {
+#if DP_ABL & 1                     // diagnostic: half of the weight fragments not read (wrong results, timing only)
+                if (j >= 2) { fw[j] = fw[j - 2]; continue; }
+#endif
+                fw[j] = *reinterpret_cast<const f16x8 *>(Wb + j * 32 * DP_WKB + co);
+            }
             // (1-lh)(1-lw) v1 + (1-lh) lw v2 + lh (1-lw) v3 + lh lw v4 (dcn_v2_im2col_cuda.cu:44-46), mask folded into the
             // weights, on fp16 pairs (v_pk_mul_f16 / v_pk_fma_f16).  Plain vector code, not inline asm: the fragment feeds the
             // MFMA right behind it, and the wait states a VALU result needs before a matrix instruction reads it are only

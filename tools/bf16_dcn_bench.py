@@ -22,7 +22,7 @@ for cin, cout, H, W, B in SHAPES:
     x = torch.randn(B * H * W, cin, generator=g).to(torch.bfloat16).to(dev)
     wp, kpad = pack_conv_bf16(torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5, None, None, dev)
     w16 = wp.float().to(torch.float16).contiguous()
-    ws = torch.zeros(256, device=dev, dtype=torch.int32)
+    ws = torch.zeros(max(256, L.m3d_conv_bf16_dcn_ws_bytes(B, H, W) // 4), device=dev, dtype=torch.int32)   # one flag word per pixel tile
     fl = 2.0 * B * H * W * cout * 9 * cin
     for std, clamp in CASES:
         om = torch.cat([(torch.randn(B * H * W, 18, generator=g) * std).clamp(-clamp, clamp), torch.rand(B * H * W, 9, generator=g),
@@ -38,7 +38,7 @@ for cin, cout, H, W, B in SHAPES:
             d.out, d.out_cs, d.out_mode, d.act, d.sigmoid_from, d.groups = out.data_ptr(), cout, 0, 1, -1, 1
             d.dcn_offmask, d.dcn_om_cs = om.data_ptr(), 32
             if patch:
-                d.wgt_f16, d.dcn_ws, d.dcn_ws_bytes = w16.data_ptr(), ws.data_ptr(), 1024
+                d.wgt_f16, d.dcn_ws, d.dcn_ws_bytes = w16.data_ptr(), ws.data_ptr(), ws.numel() * 4
             var = L.m3d_conv_bf16_variant(ctypes.byref(d))
             for _ in range(3):
                 _hip.check(L.m3d_conv_bf16_forward(ctypes.byref(d), st))

@@ -23,7 +23,7 @@ g = torch.Generator().manual_seed(1)
 x = torch.randn(B * H * W, cin, generator=g).to(torch.bfloat16).to(dev)
 wp, kpad = pack_conv_bf16(torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5, None, None, dev)
 w16 = wp.float().to(torch.float16).contiguous()
-ws = torch.zeros(256, device=dev, dtype=torch.int32)
+ws = torch.zeros(max(256, L.m3d_conv_bf16_dcn_ws_bytes(B, H, W) // 4), device=dev, dtype=torch.int32)   # one flag word per pixel tile
 om = torch.cat([(torch.randn(B * H * W, 18, generator=g) * std).clamp(-clamp, clamp), torch.rand(B * H * W, 9, generator=g),
                 torch.zeros(B * H * W, 5)], 1).contiguous().to(dev)
 out = torch.zeros(B * H * W, cout, device=dev, dtype=torch.bfloat16)
@@ -34,7 +34,7 @@ d.kh = d.kw = 3
 d.stride, d.pad, d.Ho, d.Wo = 1, 1, H, W
 d.out, d.out_cs, d.out_mode, d.act, d.sigmoid_from, d.groups = out.data_ptr(), cout, 0, 1, -1, 1
 d.dcn_offmask, d.dcn_om_cs = om.data_ptr(), 32
-d.wgt_f16, d.dcn_ws, d.dcn_ws_bytes = w16.data_ptr(), ws.data_ptr(), 1024
+d.wgt_f16, d.dcn_ws, d.dcn_ws_bytes = w16.data_ptr(), ws.data_ptr(), ws.numel() * 4
 grid = B * (H // 16) * (W // 16)
 trace = torch.zeros(max(grid, B * H * W // 128) * 160, dtype=torch.int64, device=dev)
 st = torch.cuda.current_stream().cuda_stream
