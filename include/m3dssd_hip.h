@@ -547,7 +547,7 @@ int m3d_score_keys_planar(const float *cls_planar, unsigned int *score_bits, int
  * per image: radix select of the k rows with the largest (score, -row) -- descending score, ascending row among equal
  * scores: a total order, unlike the reference's unstable argsort -- bitonic sort of those k, decode of exactly those rows
  * -> aboxes [B][k][14] (x1,y1,x2,y2,score,cls,x3d,y3d,z3d,w3d,h3d,l3d,ry3d,anchor), score-descending; rows_out [B][k]
- * (optional) gets the selected row ids.  1 <= k <= min(R, 4096), R < 2^22; workspace: m3d_topk_decode_workspace_bytes. */
+ * (optional) gets the selected row ids.  1 <= k <= min(R, 16384), R < 2^22; workspace: m3d_topk_decode_workspace_bytes. */
 long long m3d_topk_decode_workspace_bytes(int B, int R);
 int m3d_topk_decode(const unsigned int *score_bits, const float *prob, const float *bbox_2d, const float *bbox_3d,
                     const float *rois /*[R][5]*/, const float *anchors /*[A][9]*/, const float *means /*[11]*/,
@@ -577,8 +577,9 @@ int m3d_decode_rows(const long long *rows /*[B][n_rows] row ids*/, const float *
 
 /* Greedy NMS on device.  boxes_dev [B][n][box_stride>=4] sorted by descending score; mask_ws needs
  * B*n*ceil(n/64) uint64.  keep_dev [B][n] int32 (kept positions, ascending), num_keep_dev [B].
- * n <= 4096 (the reference's _nms is unbounded; the path calls it with nms_topN_pre = 3000 rows): larger n returns
- * M3D_E_ARG -- one wave holds the whole "removed" bit set of an image in registers, 64 lanes x 64 bits. */
+ * n <= 16384 (the reference's _nms is unbounded -- the host-pointer twin `_nms` below is too; the path calls this with
+ * nms_topN_pre = 3000 rows): up to 4096 rows one wave holds the whole "removed" bit set of an image in registers (64 lanes x 64
+ * bits), up to 16384 it lives in LDS; larger n returns M3D_E_ARG. */
 long long m3d_nms_workspace_bytes(int B, int n);
 int m3d_nms_sorted_dev(const float *boxes_dev, int B, int n, int box_stride, float thresh, void *mask_ws,
                        int *keep_dev, int *num_keep_dev, m3d_stream_t stream);

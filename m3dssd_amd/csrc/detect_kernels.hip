@@ -14,7 +14,7 @@
 #include "common.h"
 
 #define TOPK_NT 1024
-#define TOPK_MAXK 4096
+#define TOPK_MAXK 16384                  // keys of the final sort in LDS: 8 bytes each, next power of two of k (dynamic allocation)
 
 // Decode (lib/rpn_util.py:1442-1521 + bbox_transform_inv :1137-1186), scale_factor = 1.
 // Row layout out: x1,y1,x2,y2,score,cls,x3d,y3d,z3d,w3d,h3d,l3d,ry3d,anchor  (rpn_util.py:1550)
@@ -153,7 +153,7 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned *wave_t
 __global__ __launch_bounds__(TOPK_NT) void topk_decode_kernel(TopkArgs a)
 {
     __shared__ unsigned hist[2048];
-    __shared__ unsigned long long sel[TOPK_MAXK];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sel[];      // P = next power of two >= k keys
     __shared__ unsigned wave_tot[16];
     __shared__ unsigned s_bin, s_above, s_nsel, s_ncand;
     const int img = blockIdx.x, tid = threadIdx.x;
@@ -285,6 +285,23 @@ __global__ __launch_bounds__(TOPK_NT) void topk_decode_kernel(TopkArgs a)
     }
 }
 
+static int topk_launch(const TopkArgs &a, int B, hipStream_t stream)
+{
+    int P = 1;
+    while (P < a.k) P <<= 1;
+    const int lds = P * (int)sizeof(unsigned long long);             // <= 128 KB (+ 8 KB of static LDS)
+    static const int big_ok = []() {
+        const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            TOPK_MAXK * (int)sizeof(unsigned long long)) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        return ok ? 1 : 0;
+    }();
+    M3D_REQUIRE(big_ok || lds <= 32768, "topk_decode: cannot reserve %d bytes of LDS for k = %d", lds, a.k);
+    hipLaunchKernelGGL(topk_decode_kernel, dim3(B), dim3(TOPK_NT), lds, stream, a);
+    M3D_LAUNCH_CHECK();
+    return M3D_OK;
+}
+
 extern "C" long long m3d_topk_decode_workspace_bytes(int B, int R)
 {
     return (long long)B * 2 * R * (long long)sizeof(unsigned long long);
@@ -316,9 +333,7 @@ extern "C" int m3d_topk_decode_scaled(const unsigned int *score_bits, const floa
     a.score_bits = score_bits; a.prob = prob; a.b2 = bbox_2d; a.b3 = bbox_3d; a.rois = rois; a.anchors = anchors;
     a.means = means; a.stds = stds; a.aboxes = aboxes; a.rows_out = rows_out; a.cand = (unsigned long long *)workspace;
     a.R = R; a.k = k; a.scale = scale; a.A = 0; a.HW = 0;
-    hipLaunchKernelGGL(topk_decode_kernel, dim3(B), dim3(TOPK_NT), 0, (hipStream_t)stream, a);
-    M3D_LAUNCH_CHECK();
-    return M3D_OK;
+    return topk_launch(a, B, (hipStream_t)stream);
 }
 
 extern "C" int m3d_topk_decode_planar(const unsigned int *score_bits, const float *cls_planar, const float *box_planar,
@@ -339,9 +354,7 @@ extern "C" int m3d_topk_decode_planar(const unsigned int *score_bits, const floa
     a.score_bits = score_bits; a.prob = cls_planar; a.b2 = box_planar; a.b3 = nullptr; a.rois = rois; a.anchors = anchors;
     a.means = means; a.stds = stds; a.aboxes = aboxes; a.rows_out = rows_out; a.cand = (unsigned long long *)workspace;
     a.R = R; a.k = k; a.scale = scale; a.A = A; a.HW = HW;
-    hipLaunchKernelGGL(topk_decode_kernel, dim3(B), dim3(TOPK_NT), 0, (hipStream_t)stream, a);
-    M3D_LAUNCH_CHECK();
-    return M3D_OK;
+    return topk_launch(a, B, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -6,7 +6,7 @@
 //    (nms_kernel.cu:24-32,71); this file is compiled with -ffp-contract=off and HIP's default
 //    correctly-rounded fp32 division, so kept indices are bit-identical to the CPU oracle.
 //  * nms_reduce_kernel: one workgroup per image replaces the host loop of nms_kernel.cu:124-141.
-//    Lane j of wave 0 owns the 64-bit "removed" word of column tile j (n <= 4096; the host-pointer
+//    Lane j of wave 0 owns the 64-bit "removed" word of column tile j (n <= 4096; nms_reduce_big_kernel up to 16384; the host-pointer
 //    twin `_nms` takes larger inputs over the reference's own route: device masks + greedy pass on the host).  Per row tile: the
 //    64 sequential decisions run on scalar-broadcast words (v_readlane) while the four waves already
 //    hold the tile's 64 mask rows (prefetched one tile ahead) and OR in those whose box was kept.
@@ -202,6 +202,56 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(int n, const unsigned l
     if (tid == 0) num_keep[img] = base;
 }
 
+// More than 4096 boxes per image (up to 16384: not the path's configuration -- nms_topN_pre is 3000 -- but the reference has no
+// limit): the same greedy pass with the "removed" words in LDS instead of one per lane, the diagonal word of a tile read when
+// the tile is decided, and the 256 threads OR-ing the kept rows into one column tile each.  No prefetch: a few ms at 16384 boxes.
+__global__ __launch_bounds__(256) void nms_reduce_big_kernel(int n, const unsigned long long *__restrict__ mask_all,
+                                                             int *__restrict__ keep_all, int *__restrict__ num_keep)
+{
+    __shared__ unsigned long long remv_s[256];
+    __shared__ unsigned long long keep_s;
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col_blocks = (n + NMS_TPB - 1) / NMS_TPB;
+    const unsigned long long *mask = mask_all + (size_t)img * n * col_blocks;
+    int *keep = keep_all + (size_t)img * n;
+    remv_s[tid] = 0ULL;
+    int base = 0;
+    __syncthreads();
+    for (int blk = 0; blk < col_blocks; ++blk) {
+        const int nb = min(NMS_TPB, n - blk * NMS_TPB);
+        if (wave == 0) {
+            const unsigned long long diag = lane < nb ? mask[(size_t)(blk * NMS_TPB + lane) * col_blocks + blk] : 0ULL;
+            const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
+            unsigned long long r = remv_s[blk];
+            if (nb < NMS_TPB) r |= ~0ULL << nb;
+            unsigned long long keepbits = 0;
+#pragma unroll
+            for (int i = 0; i < NMS_TPB; ++i) {
+                const unsigned long long d = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, i) << 32) |
+                                             (unsigned int)__builtin_amdgcn_readlane((int)dlo, i);
+                const bool alive = !((r >> i) & 1ULL);
+                keepbits |= alive ? (1ULL << i) : 0ULL;
+                r |= alive ? d : 0ULL;
+            }
+            if ((keepbits >> lane) & 1ULL)
+                keep[base + __popcll(keepbits & ((1ULL << lane) - 1ULL))] = blk * NMS_TPB + lane;
+            base += __popcll(keepbits);
+            if (lane == 0) keep_s = keepbits;
+        }
+        __syncthreads();
+        const unsigned long long kb = keep_s;
+        for (int c = blk + 1 + tid; c < col_blocks; c += 256) {
+            unsigned long long acc = 0ULL;
+            for (int r = 0; r < nb; ++r)
+                if ((kb >> r) & 1ULL) acc |= mask[(size_t)(blk * NMS_TPB + r) * col_blocks + c];
+            remv_s[c] |= acc;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) num_keep[img] = base;
+}
+
 extern "C" long long m3d_nms_workspace_bytes(int B, int n)
 {
     const long long cb = (n + NMS_TPB - 1) / NMS_TPB;
@@ -213,7 +263,7 @@ extern "C" int m3d_nms_sorted_dev(const float *boxes_dev, int B, int n, int box_
 {
     hipStream_t stream = (hipStream_t)stream_;
     M3D_REQUIRE(num_keep_dev && B >= 1, "nms: null pointer / bad batch");
-    M3D_REQUIRE(n >= 0 && n <= 64 * NMS_TPB, "nms: n (%d) must be <= 4096", n);
+    M3D_REQUIRE(n >= 0 && n <= 256 * NMS_TPB, "nms: n (%d) must be <= 16384", n);
     if (n == 0) {   // empty input: nothing kept (boxes/keep may legitimately be null)
         M3D_HIP(hipMemsetAsync(num_keep_dev, 0, sizeof(int) * B, stream));
         return M3D_OK;
@@ -227,8 +277,10 @@ extern "C" int m3d_nms_sorted_dev(const float *boxes_dev, int B, int n, int box_
     else hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, B), dim3(NMS_TPB), 0, stream, n, box_stride, thresh, boxes_dev,
                             (unsigned long long *)mask_ws);
     M3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(256), 0, stream, n, (const unsigned long long *)mask_ws, keep_dev,
-                       num_keep_dev);
+    if (n <= 64 * NMS_TPB)
+        hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(256), 0, stream, n, (const unsigned long long *)mask_ws, keep_dev, num_keep_dev);
+    else
+        hipLaunchKernelGGL(nms_reduce_big_kernel, dim3(B), dim3(256), 0, stream, n, (const unsigned long long *)mask_ws, keep_dev, num_keep_dev);
     M3D_LAUNCH_CHECK();
     return M3D_OK;
 }
@@ -259,9 +311,9 @@ extern "C" void _nms(int *keep_out, int *num_out, const float *boxes_host, int b
               hip_ok(hipMalloc(&keep_dev, sizeof(int) * boxes_num), "hipMalloc(keep)") &&
               hip_ok(hipMalloc(&num_dev, sizeof(int)), "hipMalloc(num)");
     ok = ok && hip_ok(hipMemcpy(boxes_dev, boxes_host, bbytes, hipMemcpyHostToDevice), "hipMemcpy(boxes -> device)");
-    if (ok && boxes_num > 64 * NMS_TPB) {
+    if (ok && boxes_num > 256 * NMS_TPB) {
         // The reference has no row limit (nms_kernel.cu:91-144); the on-device greedy reduce keeps one 64-bit "removed" word per
-        // lane (4096 boxes).  Larger inputs take the reference's own route: bitmask tiles on the device, greedy pass on the host
+        // lane (4096 boxes) or in LDS (16384).  Larger inputs take the reference's own route: bitmask tiles on the device, greedy pass on the host
         // over the upper triangle (nms_kernel.cu:124-141) -- the only words the pass reads are the ones the mask kernel writes.
         const int cb = (boxes_num + NMS_TPB - 1) / NMS_TPB;
         hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, 1), dim3(NMS_TPB), 0, nullptr, boxes_num, boxes_dim, nms_overlap_thresh,

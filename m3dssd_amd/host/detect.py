@@ -16,7 +16,7 @@ import torch
 
 from .. import _hip
 
-NMS_MAX_PRE = 4096        # m3d_nms_sorted_dev / m3d_topk_decode: one 64-bit "removed" word per lane, k keys in LDS
+NMS_MAX_PRE = 16384       # m3d_nms_sorted_dev / m3d_topk_decode: "removed" words and the k sort keys live in LDS
 
 
 def _stream(dev):

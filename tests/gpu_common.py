@@ -214,7 +214,7 @@ def _sortable_bits(score):
 
 
 TOPK_CASES = [
-    ("random", 276480, 3000), ("ragged_R", 10007, 3000), ("k_equals_R", 1500, 1500), ("k1", 4097, 1), ("k_max", 50000, 4096),
+    ("random", 276480, 3000), ("ragged_R", 10007, 3000), ("k_equals_R", 1500, 1500), ("k1", 4097, 1), ("k_4096", 50000, 4096), ("k_10000", 60000, 10000), ("k_max", 50000, 16384),
     ("all_equal", 20000, 3000), ("16_levels", 276480, 3000), ("ties_at_cut", 30000, 3000), ("negative_and_zero", 9000, 2000),
 ]
 

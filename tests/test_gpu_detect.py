@@ -112,15 +112,19 @@ def test_nms_thresholds_on_and_one_ulp_around_actual_ious():
 
 
 # ------------------------------------------------------------------------------------ detection
-def test_detect_matches_oracle_given_same_network_outputs():
+@pytest.mark.parametrize("pre", [None, 6000])
+def test_detect_matches_oracle_given_same_network_outputs(pre):
     """decode + top-k + NMS on the device vs oracle/detect.py fed with the ENGINE's network outputs:
-    kept anchors/classes identical, coordinates to fp32 roundoff."""
+    kept anchors/classes identical, coordinates to fp32 roundoff.  pre = 6000: nms_topN_pre beyond the 4096 rows one wave's
+    registers hold (round 5: sort keys / "removed" words in LDS up to 16384; the reference has no limit)."""
     from lib.rpn_util import im_detect_3d, detect_batch
     from model.M3d_inference_align import build
     from oracle import detect as odet
     dev = _dev()
     crop, B = (128, 320), 2
     conf = synth.synth_conf(crop, 0, batch_size=B, device="cuda:0")
+    if pre:
+        conf.nms_topN_pre = pre
     net = build(conf, "test")
     net.load_state_dict(synth.synth_state_dict(0))
     net = net.to(dev)
@@ -319,8 +323,8 @@ def test_topk_decode_batched_and_argument_checks():
         assert np.array_equal(rows[b].cpu().numpy(), order)
         assert torch.equal(ab[b, :, 4].cpu(), scores[b][order])
     args = [bits.data_ptr(), *[t.data_ptr() for t in d], ab.data_ptr(), None, ws.data_ptr()]
-    assert L.m3d_topk_decode(*args, nb, B, R, 4097, _stream()) == -1          # k > 4096
-    assert L.m3d_topk_decode(*args, nb, B, R, R + 1, _stream()) == -1         # k > R  (R = 5000 > 4096 anyway)
+    assert L.m3d_topk_decode(*args, nb, B, R, 16385, _stream()) == -1         # k > 16384
+    assert L.m3d_topk_decode(*args, nb, B, R, R + 1, _stream()) == -1         # k > R
     assert L.m3d_topk_decode(*args, nb - 8, B, R, k, _stream()) == -3         # workspace too small
     assert b"workspace" in L.m3d_last_error()
 
@@ -351,7 +355,7 @@ def test_select_post_blocks():
 def test_conf_limits_are_checked_at_build_time():
     from model.M3d_inference_align import build
     conf = synth.synth_conf((128, 320), 0, batch_size=1, device="cuda:0")
-    conf.nms_topN_pre = 5000
+    conf.nms_topN_pre = 20000
     with pytest.raises(ValueError, match="nms_topN_pre"):
         build(conf, "test")
 
@@ -399,11 +403,12 @@ def test_two_ranks_detect_and_gather_equal_single_process(tmp_path, backend):
     _log("two_ranks_" + backend, dict(status="ok"))
 
 
-# ------------------------------------------------------------------------------------ NMS beyond the device reduce's 4096 rows
-@pytest.mark.parametrize("n", [4097, 6000, 12000])
+# ------------------------------------------------------------------------------------ NMS beyond the 4096 rows of the one-wave reduce
+@pytest.mark.parametrize("n", [4097, 6000, 12000, 16384, 17000])
 def test_nms_twin_has_no_row_limit(n):
-    """`_nms` (lib/nms/gpu_nms.hpp:1-2) has no row limit in the reference (nms_kernel.cu:91-144).  The on-device greedy reduce holds
-    4096 rows; larger inputs go through device masks + the reference's host pass and must give the oracle's keep list bit for bit."""
+    """`_nms` (lib/nms/gpu_nms.hpp:1-2) has no row limit in the reference (nms_kernel.cu:91-144).  The one-wave greedy reduce holds
+    4096 rows, the LDS form 16384; larger inputs go through device masks + the reference's host pass.  All must give the oracle's
+    keep list bit for bit."""
     import numpy as np
     from lib.nms.gpu_nms import gpu_nms
     from oracle import nms as onms
@@ -415,6 +420,27 @@ def test_nms_twin_has_no_row_limit(n):
     got = gpu_nms(dets, 0.4, device_id=0)
     want = onms.gpu_nms(dets, 0.4)
     assert list(got) == list(want) and len(got) > 50
+
+
+def test_nms_batched_device_api_beyond_4096_rows():
+    """m3d_nms_sorted_dev with n = 5000 / 9000 rows per image (nms_reduce_big_kernel) == the oracle per image; n = 16385 is refused."""
+    from m3dssd_amd import _hip
+    from m3dssd_amd.host import ops
+    from oracle import nms as onms
+    dev = _dev()
+    for n in (5000, 9000):
+        B = 2
+        dets = np.stack([synth.synth_boxes(n, seed=300 + i) for i in range(B)])
+        srt = np.stack([d[onms.order_desc_stable(d[:, 4])] for d in dets])
+        keep, num = ops.nms_sorted(torch.from_numpy(srt).to(dev), 0.4)
+        for i in range(B):
+            ref = onms.nms_sorted(srt[i], 0.4)
+            assert int(num[i]) == len(ref) and np.array_equal(keep[i, :len(ref)].cpu().numpy(), ref)
+    L = _hip.lib()
+    x = torch.zeros(1, 16385, 5, device=dev)
+    ws = torch.empty(L.m3d_nms_workspace_bytes(1, 16385), device=dev, dtype=torch.uint8)
+    k, nk = torch.empty(16385, device=dev, dtype=torch.int32), torch.empty(1, device=dev, dtype=torch.int32)
+    assert L.m3d_nms_sorted_dev(x.data_ptr(), 1, 16385, 5, 0.4, ws.data_ptr(), k.data_ptr(), nk.data_ptr(), _stream()) != 0
 
 
 def test_fed_uint8_pipeline_equals_detect_batch_of_each_frame_set():
