@@ -240,6 +240,9 @@ void bf16_dcn_patch_kernel(const Bf16Args a, const void *__restrict__ wgt16, uns
                 r = __builtin_elementwise_fma(__builtin_bit_cast(h2, d10), w10, r);
                 r = __builtin_elementwise_fma(__builtin_bit_cast(h2, d11), w11, r);
                 fb[e] = __builtin_bit_cast(unsigned, r);
+#if DP_ABL & 4                     // diagnostic: no bilinear combine (the first corner is the fragment)
+                fb[e] = d00;
+#endif
             }
             const f16x8 fp = __builtin_bit_cast(f16x8, fb);
 #pragma unroll
