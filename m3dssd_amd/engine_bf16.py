@@ -33,6 +33,7 @@ FUSED_FRONT = os.environ.get("M3D_BF16_FUSED_FRONT", "1") != "0"
 BRANCH = os.environ.get("M3D_BF16_BRANCH", "1") != "0"         # ANAB + z3d head as a side branch beside the size heads
 TREE_ENTRY = os.environ.get("M3D_BF16_TREE_ENTRY", "1") != "0"   # max-pool + project + stride-2 conv1 of a tree in one launch (csrc/bf16_tree_entry.hip)
 HEADS2 = os.environ.get("M3D_BF16_HEADS2", "1") != "0"         # round-5 form of the fused heads (csrc/bf16_head_mlp2.hip)
+SHAPE_PATCH = os.environ.get("M3D_BF16_SHAPE_PATCH", "0") != "0"   # shape_align through the LDS-patch DCNv2 kernel (per-tile decision)
 FRONT2 = os.environ.get("M3D_BF16_FRONT2", "1") != "0"         # round-5 form of the fused front end (csrc/bf16_frontend2.hip)
 
 
@@ -719,7 +720,7 @@ class EngineBF16(Engine):
             1.0, om_sa.ptr, om_sa.cs, B, A, HW, 9, 0, st)))
         feats = self._buf16(plan, B, fh, fw, 128, name="feats")
         self._pconv(plan, "shape_align.dcn", P["shape_align"], feats0, feats, 1, 1, act=0, res=feats0, om=om_sa,
-                    patch=False)    # anchor-shaped offsets (up to half an anchor) never fit the LDS window: skip the bound pass
+                    patch=SHAPE_PATCH)   # anchor-shaped offsets (up to half an anchor): which tiles fit the LDS window is decided per tile
         heads(["bbox_x", "bbox_y"], feats, 0)
         heads(["bbox_x3d", "bbox_y3d"], feats, 4)
 
