@@ -261,13 +261,93 @@ __global__ __launch_bounds__(256) void upsample2x_add_bf16_rows_kernel(const __b
     *reinterpret_cast<u32x4 *>(out + o * out_cs + c8 * 8) = pack8(acc);
 }
 
+// Row form with the weights in registers (round 5, second half): workgroup = one output row of one image, thread = (8 channels, a
+// segment of the row); the 2 x 4 x 8 weights an output row needs are loaded ONCE per thread and the thread walks its segment in
+// output PAIRS (2i, 2i + 1), which read input columns i - 1, i, i + 1 of two input rows -- a sliding window, 2 new 16-byte loads per
+// pair.  Per output pixel: one input load, one skip load, one store, 32 FMAs (the form above: 4 input + 8 weight loads per pixel).
+template <int LOG2C8>
+__global__ __launch_bounds__(256) void upsample2x_add_bf16_seg_kernel(const __bf16 *__restrict__ in, int in_cs, const float *__restrict__ wgt,
+                                                                      const __bf16 *__restrict__ skip, int skip_cs, __bf16 *__restrict__ out,
+                                                                      int out_cs, int H, int W, int P)
+{
+    constexpr int C8 = 1 << LOG2C8, C = C8 * 8;
+    const int c8 = threadIdx.x & (C8 - 1), seg = threadIdx.x >> LOG2C8;
+    const int y = blockIdx.x, n = blockIdx.y;
+    const int Wo = 2 * W;
+    const int iy_hi = (y + 1) >> 1, ky_hi = y + 1 - 2 * iy_hi;              // rows iy_hi (tap ky_hi) and iy_hi - 1 (tap ky_hi + 2)
+    float w[2][4][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            const float *wp = wgt + ((ky_hi + 2 * a) * 4 + kx) * C + c8 * 8;
+            const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wp), w1 = *reinterpret_cast<const f32x4 *>(wp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { w[a][kx][e] = w0[e]; w[a][kx][4 + e] = w1[e]; }
+        }
+    const bool rok[2] = {iy_hi < H, iy_hi - 1 >= 0};                         // (block-uniform)
+    const __bf16 *rin[2] = {in + ((size_t)(n * H + iy_hi) * W) * in_cs + c8 * 8, in + ((size_t)(n * H + iy_hi - 1) * W) * in_cs + c8 * 8};
+    auto col = [&](int a, int ix) __attribute__((always_inline)) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (rok[a] && ix >= 0 && ix < W) v = *reinterpret_cast<const u32x4 *>(rin[a] + (size_t)ix * in_cs);
+        return v;
+    };
+    const int i0 = seg * P, i1 = min(W, i0 + P);
+    if (i0 >= i1) return;
+    u32x4 cm[2], cc[2];                                                      // columns i - 1 and i of the two rows
+#pragma unroll
+    for (int a = 0; a < 2; ++a) { cm[a] = col(a, i0 - 1); cc[a] = col(a, i0); }
+    const size_t orow = (size_t)(n * 2 * H + y) * Wo;
+    for (int i = i0; i < i1; ++i) {
+        u32x4 cp[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) cp[a] = col(a, i + 1);
+        u32x4 s0 = {0u, 0u, 0u, 0u}, s1 = s0;
+        if (skip) {
+            s0 = *reinterpret_cast<const u32x4 *>(skip + (orow + 2 * i) * skip_cs + c8 * 8);
+            s1 = *reinterpret_cast<const u32x4 *>(skip + (orow + 2 * i + 1) * skip_cs + c8 * 8);
+        }
+        float a0[8], a1[8];
+        unpack8(s0, a0);
+        unpack8(s1, a1);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float vm[8], vc[8], vp[8];
+            unpack8(cm[a], vm);
+            unpack8(cc[a], vc);
+            unpack8(cp[a], vp);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                a0[e] += vc[e] * w[a][1][e] + vm[e] * w[a][3][e];            // x = 2i:     column i tap 1, column i - 1 tap 3
+                a1[e] += vp[e] * w[a][0][e] + vc[e] * w[a][2][e];            // x = 2i + 1: column i + 1 tap 0, column i tap 2
+            }
+        }
+        global_store_u32x4_nop(out + (orow + 2 * i) * out_cs + c8 * 8, pack8(a0));
+        global_store_u32x4_nop(out + (orow + 2 * i + 1) * out_cs + c8 * 8, pack8(a1));
+#pragma unroll
+        for (int a = 0; a < 2; ++a) { cm[a] = cc[a]; cc[a] = cp[a]; }
+    }
+}
+
 extern "C" int m3d_upsample2x_add_bf16(const void *in, int in_cs, const float *wgt, const void *skip, int skip_cs, void *out,
                                        int out_cs, int N, int H, int W, int C, m3d_stream_t stream)
 {
     M3D_REQUIRE(in && wgt && out && C % 8 == 0 && in_cs % 8 == 0 && out_cs % 8 == 0 && (!skip || skip_cs % 8 == 0),
                 "upsample2x_add_bf16: C and strides must be x8");
     static const int rows_form = []() { const char *e = getenv("M3D_UPSAMPLE_ROWS"); return e ? atoi(e) : 1; }();
-    if (rows_form && (C == 128 || C == 256 || C == 64) && 2 * H <= 65535 && N <= 65535) {
+    if (rows_form == 1 && (C == 128 || C == 256 || C == 64) && N <= 65535) {
+        const int nseg = 256 / (C / 8), P = cdiv(W, nseg);
+        const dim3 grid(2 * H, N);
+#define UPS_SEG(L2) hipLaunchKernelGGL(upsample2x_add_bf16_seg_kernel<L2>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16 *)in, in_cs, \
+                                       wgt, (const __bf16 *)skip, skip_cs, (__bf16 *)out, out_cs, H, W, P)
+        if (C == 64) UPS_SEG(3);
+        else if (C == 128) UPS_SEG(4);
+        else UPS_SEG(5);
+#undef UPS_SEG
+        M3D_LAUNCH_CHECK();
+        return M3D_OK;
+    }
+    if (rows_form && (C == 128 || C == 256 || C == 64) && 2 * H <= 65535 && N <= 65535) {     // M3D_UPSAMPLE_ROWS=2: a thread per pixel and 8 channels
         const int px = 256 / (C / 8);
         const dim3 grid(cdiv(2 * W, px), 2 * H, N);
 #define UPS_ROWS(L2) hipLaunchKernelGGL(upsample2x_add_bf16_rows_kernel<L2>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16 *)in, in_cs, \
