@@ -536,6 +536,8 @@ extern "C" int m3d_upsample2x_add(const float *in, int in_cs, const float *wgt, 
 {
     M3D_REQUIRE(in && wgt && out && C % 4 == 0 && in_cs % 4 == 0 && out_cs % 4 == 0 && (!skip || skip_cs % 4 == 0),
                 "upsample2x_add: C and strides must be x4");
+    // (the row / segment form of the bf16 twin -- weights in registers, output pairs over a sliding window, csrc/bf16_kernels.hip -- was
+    // ported and measured neutral at bs 8: 6.002 vs 6.005 ms per step; not kept)
     const long long total = (long long)N * 4 * H * W * (C / 4);
     // the int form's grid-stride increment (at most 8192 x 256) must not carry the index past 2^31 on its last step
     if (total < (1ll << 31) - 8192ll * 256)

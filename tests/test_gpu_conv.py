@@ -493,3 +493,34 @@ torch.save(out.cpu(), sys.argv[1])
             outs.append(torch.load(path))
     assert torch.equal(outs[0], outs[1])
 
+
+
+@pytest.mark.parametrize("c,n,h,w", [(16, 2, 5, 7), (64, 2, 6, 5), (128, 1, 5, 7), (256, 2, 3, 9), (128, 2, 24, 80), (256, 1, 12, 40)])
+def test_upsample2x_add_matches_torch(c, n, h, w):
+    """m3d_upsample2x_add (depthwise ConvTranspose2d(4, 2, 1) of IDAUp + the skip sum, model/pose_dla_dcn.py:261-269) against torch:
+    16 to 256 channels, ragged widths, the plan's sizes, channel-sliced views with untouched neighbours."""
+    from m3dssd_amd import _hip
+    L, dev = _hip.lib(), _dev()
+    g = torch.Generator().manual_seed(c + w)
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.rand(c, 1, 4, 4, generator=g)
+    skip = torch.randn(n, c, 2 * h, 2 * w, generator=g)
+    ref = F.conv_transpose2d(x.double(), wt.double(), None, stride=2, padding=1, groups=c) + skip.double()
+    xin = torch.full((n, h, w, c + 4), 3.0)
+    xin[..., :c] = x.permute(0, 2, 3, 1)
+    sk = torch.full((n, 2 * h, 2 * w, c + 8), 5.0)
+    sk[..., :c] = skip.permute(0, 2, 3, 1)
+    xin, sk = xin.to(dev), sk.to(dev)
+    wd = wt[:, 0].permute(1, 2, 0).contiguous().to(dev)
+    out = torch.full((n, 2 * h, 2 * w, c + 4), 9.0, device=dev)
+    _hip.check(L.m3d_upsample2x_add(xin.data_ptr(), c + 4, wd.data_ptr(), sk.data_ptr(), c + 8, out.data_ptr(), c + 4, n, h, w, c,
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    got = out[..., :c].permute(0, 3, 1, 2).cpu().double()
+    assert (out[..., c:] == 9.0).all()
+    assert ((got - ref).abs() <= 2e-6 * (1.0 + ref.abs())).all(), (got - ref).abs().max().item()
+    out2 = torch.zeros(n, 2 * h, 2 * w, c, device=dev)
+    _hip.check(L.m3d_upsample2x_add(xin.data_ptr(), c + 4, wd.data_ptr(), None, 0, out2.data_ptr(), c, n, h, w, c,
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    ref2 = F.conv_transpose2d(x.double(), wt.double(), None, stride=2, padding=1, groups=c)
+    assert ((out2.permute(0, 3, 1, 2).cpu().double() - ref2).abs() <= 2e-6 * (1.0 + ref2.abs())).all()
