@@ -34,7 +34,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming copy)
 CROP = (384, 1280)
 PER_GPU_BATCH = 8
-MFMA_FAMILIES = ("igemm", "wino", "head_mlp", "conv_wave", "bf16_conv", "bf16_halo", "bf16_wide", "bf16_anab", "bf16_dcn_patch",
+MFMA_FAMILIES = ("igemm", "wino", "head_mlp", "conv_wave", "anab_attend", "bf16_conv", "bf16_halo", "bf16_wide", "bf16_anab", "bf16_dcn_patch",
                  "bf16_head_mlp", "bf16_head2", "bf16_tail2", "bf16_qkvs", "bf16_tree_entry", "bf16_frontend")
 # SURVEY 8d, per image: 105.8 GFLOP; activations 1003.6 MB (fp32) + outputs 21 MB + input 5.9 MB; weights 82.6 MB (fp32) per batch
 ALG_GFLOP_PER_IMAGE = 105.8
@@ -152,7 +152,9 @@ def kernel_symbol(label):
     """engine label -> demangled kernel name as rocprofv3 prints it."""
     import re
     if label.startswith("bf16_anab"):
-        return "bf16_anab_attend_kernel(AnabArgs)"
+        return "void bf16_anab_attend_kernel<true>(AnabArgs)"
+    if label.startswith("anab_attend"):
+        return "void anab_attend_f32_kernel<168>(AnabF32Args)"
     if label.startswith("bf16_head2"):
         return "bf16_head2_kernel(Head2Args)"
     if label.startswith("bf16_tail2"):
@@ -202,7 +204,7 @@ def kernel_symbol(label):
 
 
 # engine family label prefix -> the kernel sources whose edit invalidates a PMC pass of that family (plus the shared headers)
-FAMILY_SOURCES = (("bf16_anab", ("bf16_anab.hip",)), ("bf16_head2", ("bf16_head_mlp2.hip",)), ("bf16_tail2", ("bf16_head_mlp2.hip",)), ("bf16_qkvs", ("bf16_head_mlp2.hip",)),
+FAMILY_SOURCES = (("bf16_anab", ("bf16_anab.hip",)), ("anab_attend", ("anab_attend.hip",)), ("bf16_head2", ("bf16_head_mlp2.hip",)), ("bf16_tail2", ("bf16_head_mlp2.hip",)), ("bf16_qkvs", ("bf16_head_mlp2.hip",)),
                   ("bf16_tree_entry", ("bf16_tree_entry.hip",)), ("bf16_head_mlp", ("bf16_head_mlp.hip",)),
                   ("bf16_frontend2", ("bf16_frontend2.hip",)), ("bf16_frontend", ("bf16_frontend.hip",)),
                   ("bf16_dcn_patch", ("bf16_dcn_patch.hip", "bf16_conv.hip")), ("bf16_wide", ("bf16_conv_wide.hip",)),

@@ -527,6 +527,15 @@ int m3d_anab_pool_nested_bf16(const void *kv, int kv_cs, const float *s, int s_c
 int m3d_anab_pool_nested_bf16_ex(const void *kv, int kv_cs, const float *s, int s_cs, int B, int H, int W, int Ck, int Cv,
                                  float *scratch, float *khat, int keys_pad, int ck_pad, float *vhatT, int frag,
                                  void *khat16, void *vhat16, m3d_stream_t stream);
+/* The attention of ANAB in ONE launch on fp32 MFMA (csrc/anab_attend.hip; attention.py:207-211 + the BatchNorm / activation behind the
+ * block): out[p] = act(softmax_k(q[p] . khat[k]) @ vhat (+ res[p], scale, shift)) per image, replacing the logits GEMM, the row softmax
+ * and the P.V GEMM (the logits never reach memory; one pass over the keys with a running maximum).  q [B*HW][q_cs] (first Ck
+ * channels), khat [B][keys_pad][k_cs] and vhatT [B][Cv][keys_pad] row-major as m3d_anab_pool_nested / _finish write them with
+ * frag = 0; Ck in {64, 128, 168}, Cv = 128, HW % 128 == 0, keys_pad % 32 == 0; res_mode as in m3d_conv_desc (0: + res behind the
+ * affine, 1: before it); scale / shift / res may be NULL. */
+int m3d_anab_attend_f32(const float *q, int q_cs, const float *khat, int k_cs, const float *vhatT, int B, int HW, int Ck,
+                        int keys, int keys_pad, int Cv, const float *res, int res_cs, int res_mode, const float *scale,
+                        const float *shift, int act, float *out, int out_cs, m3d_stream_t stream);
 /* In-place softmax over the first `valid` columns of each row; columns [valid, cs) are zeroed. */
 int m3d_softmax_rows(float *x, int rows, int valid, int cs, m3d_stream_t stream);
 

@@ -205,6 +205,7 @@ SIGNATURES = {
     "m3d_anab_pool_finish": (c_int, [P, P, P] + [c_int] * 4 + [P, c_int, c_int, P, c_int, c_int, P]),
     "m3d_anab_pool_nested_scratch_bytes": (c_ll, [c_int, c_int]),
     "m3d_anab_pool_nested": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P, c_int, P]),
+    "m3d_anab_attend_f32": (c_int, [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, P, P, c_int, P, c_int, P]),
     "m3d_anab_pool_nested_bf16": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P, c_int, P]),
     "m3d_anab_pool_nested_bf16_ex": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P, c_int, P, P, P]),
     "m3d_softmax_rows": (c_int, [P, c_int, c_int, c_int, P]),

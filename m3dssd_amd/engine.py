@@ -159,6 +159,7 @@ def pack_wino44_c16(weight, device):
 
 
 WINO_MIN_BLOCKS = int(os.environ.get("M3D_WINO_MIN_BLOCKS", "128"))
+FUSED_ANAB = os.environ.get("M3D_FUSED_ANAB", "1") != "0"       # logits + softmax + P.V of ANAB in one launch (csrc/anab_attend.hip)
 USE_ANAB_WAVE = os.environ.get("M3D_ANAB_WAVE", "1") != "0"
 USE_ANAB_NESTED = os.environ.get("M3D_ANAB_NESTED", "1") != "0"
 USE_DCN_WAVE = os.environ.get("M3D_DCN_WAVE", "1") != "0"
@@ -769,7 +770,8 @@ class Engine:
         n_bins, max_slots = len(bin_scale), int(bin_slots.max())
         # the two per-image GEMMs go to the wave-granular kernel when they yield enough waves; their weights (pooled keys /
         # values) are then written in MFMA-fragment order by the pooling finish and the key count is padded to 128
-        wave_ok = USE_ANAB_WAVE and USE_CONV_WAVE and HW % 32 == 0 and self.ck_pad % 32 == 0 and self.cv % 128 == 0
+        fused = FUSED_ANAB and self.cv == 128 and self.ck in (64, 128, 168) and HW % 128 == 0
+        wave_ok = (not fused) and USE_ANAB_WAVE and USE_CONV_WAVE and HW % 32 == 0 and self.ck_pad % 32 == 0 and self.cv % 128 == 0
         nw = B * HW // 32
         wave_logits = wave_ok and nw * (_rup(n_bins, 128) // 128) >= 900
         keys_pad = _rup(n_bins, 128) if wave_logits else _rup(n_bins, 32)
@@ -800,8 +802,18 @@ class Engine:
             self._op(plan, "anab.pool_finish", "anab_pool", lambda st: _hip.check(L.m3d_anab_pool_finish(
                 partial.data_ptr(), d_bslots.data_ptr(), d_binv.data_ptr(), n_bins, max_slots, self.ck, self.cv,
                 khat.data_ptr(), keys_pad, self.ck_pad, vhatT.data_ptr(), B, frag, st)))
-        logits = self._buf(plan, B, fh, fw, keys_pad)
         qv = qkvs.slice(off["q"], self.ck_pad)
+        if fused:
+            # logits + softmax + P.V in one launch: the fp32 logits (7680 x 352 per image) never reach HBM
+            rp, rcs = (x.ptr, x.cs) if x is not None else (None, 0)
+            sp = scale.data_ptr() if scale is not None else None
+            hp = shift.data_ptr() if shift is not None else None
+            self._op(plan, "anab.attend", "anab_attend", lambda st: _hip.check(L.m3d_anab_attend_f32(
+                qv.ptr, qv.cs, khat.data_ptr(), self.ck_pad, vhatT.data_ptr(), B, HW, self.ck, n_bins, keys_pad, self.cv, rp, rcs,
+                res_mode, sp, hp, 1 if act else 0, out.ptr, out.cs, st)), flops=2.0 * B * HW * n_bins * (self.ck + self.cv),
+                nbytes=B * HW * (self.ck + 3 * self.cv) * 4 + B * keys_pad * (self.ck + self.cv) * 4)
+            return
+        logits = self._buf(plan, B, fh, fw, keys_pad)
         self._conv(plan, "anab.logits", None, qv, logits, 1, 0, act=0, affine=False, wgt_ptr=khat.data_ptr(),
                    wgt_img_stride=keys_pad * self.ck_pad, cout=n_bins, cout_pad=keys_pad, kh=1, kw=1, cin_true=self.ck,
                    wgt_frag=wave_logits)

@@ -524,3 +524,46 @@ def test_upsample2x_add_matches_torch(c, n, h, w):
                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     ref2 = F.conv_transpose2d(x.double(), wt.double(), None, stride=2, padding=1, groups=c)
     assert ((out2.permute(0, 3, 1, 2).cpu().double() - ref2).abs() <= 2e-6 * (1.0 + ref2.abs())).all()
+
+
+@pytest.mark.parametrize("B,h,w,keys,ck,res_mode,affine", [(2, 8, 16, 337, 168, 1, True), (1, 16, 40, 337, 168, 0, False), (3, 8, 32, 85, 64, 1, True),
+                                                           (1, 48, 160, 337, 168, 1, True), (2, 8, 16, 21, 128, 0, True)])
+def test_anab_attend_f32_matches_torch(B, h, w, keys, ck, res_mode, affine):
+    """m3d_anab_attend_f32 (logits + softmax + P.V + residual + affine + LeakyReLU in one launch on fp32 MFMA, attention.py:207-211)
+    against torch in float64: 2e-5 (1 + |ref|) -- fp32 accumulation over 168 + 337 terms, one pass over the keys with a running
+    maximum.  Ragged last key tile, the padding rows / columns of khat / vhat ignored, both residual modes, no affine, slices of
+    wider buffers with untouched neighbours."""
+    from m3dssd_amd import _hip
+    L, dev = _hip.lib(), _dev()
+    g = torch.Generator().manual_seed(B * 100 + keys)
+    HW, cv = h * w, 128
+    kcs, kp, qcs = ck + 24, (keys + 31) // 32 * 32, ck + 8
+    q = torch.randn(B * HW, ck, generator=g) * 0.5
+    khat = torch.randn(B, keys, ck, generator=g) * 0.3
+    vhat = torch.randn(B, cv, keys, generator=g)
+    res = torch.randn(B * HW, cv, generator=g)
+    scale, shift = torch.rand(cv, generator=g) + 0.5, torch.randn(cv, generator=g) * 0.1
+    S = torch.einsum("bpc,bkc->bpk", q.view(B, HW, ck).double(), khat.double())
+    ref = torch.einsum("bpk,bck->bpc", torch.softmax(S, dim=-1), vhat.double()).reshape(B * HW, cv)
+    sc, sh = (scale.double(), shift.double()) if affine else (torch.ones(cv, dtype=torch.float64), torch.zeros(cv, dtype=torch.float64))
+    ref = (ref + res.double()) * sc + sh if res_mode else ref * sc + sh + res.double()
+    ref = F.leaky_relu(ref, 0.01)
+    dq = torch.full((B * HW, qcs), 3.0)
+    dq[:, :ck] = q
+    dk = torch.full((B, kp, kcs), 7.0)                        # rows past `keys` / columns past ck must be ignored
+    dk[:, :keys, :ck] = khat
+    dv = torch.full((B, cv, kp), 7.0)
+    dv[:, :, :keys] = vhat
+    dq, dk, dv, dr = (t.contiguous().to(dev) for t in (dq, dk, dv, res))
+    dsc, dsh = scale.to(dev), shift.to(dev)
+    out = torch.full((B * HW, cv + 4), 512.0, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _hip.check(L.m3d_anab_attend_f32(dq.data_ptr(), qcs, dk.data_ptr(), kcs, dv.data_ptr(), B, HW, ck, keys, kp, cv, dr.data_ptr(), cv,
+                                     res_mode, dsc.data_ptr() if affine else None, dsh.data_ptr() if affine else None, 1,
+                                     out.data_ptr(), cv + 4, st))
+    torch.cuda.synchronize()
+    assert (out[:, cv:] == 512.0).all()
+    got = out[:, :cv].cpu().double()
+    assert ((got - ref).abs() <= 2e-5 * (1.0 + ref.abs())).all(), (got - ref).abs().max().item()
+    assert L.m3d_anab_attend_f32(dq.data_ptr(), qcs, dk.data_ptr(), kcs, dv.data_ptr(), B, HW + 1, ck, keys, kp, cv, None, 0, 0, None, None, 0,
+                                 out.data_ptr(), cv + 4, st) != 0
