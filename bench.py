@@ -354,6 +354,130 @@ def rccl_proof(args, mdist, net, conf, B, rank, world, dev, last_gather):
             "shards_recomputed_on_rank0": checked, "shards_match": ok}
 
 
+LINE_LIMIT = 4096          # the driver keeps the tail of stdout: the one JSON line must fit (BENCH_r05.json: parsed = null at 24 KB)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _compact_roofline(r):
+    """The dominant symbol's roofline object, numbers only (notes / sources / family lists stay in the detail file)."""
+    if not isinstance(r, dict):
+        return None
+    c = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches_timed", "traffic",
+                  "algorithmic_bytes_per_launch", "traffic_stale", "share_of_gpu_time"))
+    c.setdefault("traffic", None)                        # the contract's key: null when no PMC pass covers the kernel
+    if r.get("traffic") and r.get("algorithmic_bytes_per_launch"):
+        c["traffic_ratio"] = round(r["traffic"] / r["algorithmic_bytes_per_launch"], 2)
+    return c
+
+
+def _compact_config(o):
+    """value / ms_per_step / whole-step fractions / dominant-kernel fraction of one measured configuration."""
+    if not isinstance(o, dict):
+        return None
+    if "error" in o and "value" not in o:
+        return {"value": None, "error": str(o["error"])[:160]}
+    c = _pick(o, ("value", "ms_per_step", "steps", "dtype", "mfma_time_weighted_frac", "sclk_under_step_ghz"))
+    sr = o.get("step_roofline") or {}
+    if sr:
+        c["step"] = _pick(sr, ("algorithmic_tflops", "mfma_frac", "hbm_frac"))
+    if isinstance(o.get("config"), dict) and "per_gpu_batch" in o["config"]:
+        c["per_gpu_batch"] = o["config"]["per_gpu_batch"]
+    rf = _compact_roofline(o.get("roofline"))
+    if rf:
+        c["roofline"] = rf
+    if "dropin" in o:
+        c["dropin"] = o["dropin"]
+    if "work_in_timed_region" in o:
+        c["work_in_timed_region"] = o["work_in_timed_region"]
+    return c
+
+
+def _clamp_strings(v, n=200):
+    if isinstance(v, dict):
+        return {k: (x if k == "workload" else _clamp_strings(x, n)) for k, x in v.items()}
+    if isinstance(v, list):
+        return [_clamp_strings(x, n) for x in v]
+    if isinstance(v, str) and len(v) > n:
+        return v[:n - 3] + "..."
+    return v
+
+
+def compact_line(out, detail_path=None):
+    """The ONE stdout line: headline keys of the bench contract, the dominant kernel's roofline, cpu_baseline and
+    compact summaries of the side legs.  Everything else lives in the detail file.  Guaranteed < LINE_LIMIT bytes: optional
+    blocks are dropped (least important first) until it fits."""
+    head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    line = {k: out.get(k) for k in head}
+    cfg = out.get("config") or {}
+    line["config"] = _pick(cfg, ("workload", "per_gpu_batch", "global_batch", "resolution", "parallelism"))
+    if len(line["config"].get("workload", "")) > 260:
+        line["config"]["workload"] = line["config"]["workload"][:257] + "..."
+    line["launch"] = str(out.get("launch", ""))[:120]
+    if "work_in_timed_region" in out:
+        line["work_in_timed_region"] = out["work_in_timed_region"]
+    line["roofline"] = _compact_roofline(out.get("roofline"))
+    sr = out.get("step_roofline") or {}
+    if sr:
+        line["step_roofline"] = _pick(sr, ("algorithmic_tflops", "mfma_frac", "hbm_frac", "mfma_time_weighted_frac"))
+    for k in ("mfma_time_weighted_frac", "sclk_under_step_ghz", "roofline_frac_at_held_clock", "dist_backend"):
+        if out.get(k) is not None:
+            line[k] = out[k]
+    if "dropin" in out:
+        line["dropin"] = out["dropin"]
+    if "configs2_bf16" in out:
+        line["configs2_bf16"] = _compact_config(out["configs2_bf16"])
+    c3 = out.get("configs3_shard32")
+    if isinstance(c3, dict):
+        line["configs3_shard32"] = {k: (_pick(v, ("value", "ms_per_step", "steps", "mfma_frac", "hbm_frac", "error")) if isinstance(v, dict) else v)
+                                    for k, v in c3.items() if k in ("f32", "bf16", "allgather_us_one_rank_rccl", "allgather_bytes_per_rank")}
+    if isinstance(out.get("feed_u8"), dict):
+        line["feed_u8"] = _pick(out["feed_u8"], ("value", "ms_per_step", "vs_resident", "h2d_bytes_per_step", "error"))
+    if isinstance(out.get("rccl"), dict):
+        line["rccl"] = _pick(out["rccl"], ("world_size", "backend", "distinct_devices", "allgather_us", "shards_match", "gathered_rows"))
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = _pick(cb, ("value", "unit", "cores", "kind", "cpu_model", "host_cores", "error"))
+        c.setdefault("value", None)
+        if cb.get("sample"):
+            c["sample"] = str(cb["sample"])[:200]
+        line["cpu_baseline"] = c
+    if detail_path:
+        line["detail"] = detail_path
+    line = _clamp_strings(line)
+    # never exceed the limit: drop optional blocks, least important first
+    for drop in (None, "feed_u8", "rccl", "configs3_shard32", "step_roofline", "launch", "dropin", "configs2_bf16"):
+        if drop is not None:
+            line.pop(drop, None)
+        text = json.dumps(line, separators=(",", ":"))
+        if len(text) < LINE_LIMIT:
+            return text
+    raise RuntimeError("bench.py: the headline line alone exceeds %d bytes" % LINE_LIMIT)
+
+
+def emit(out, detail_path, fd):
+    """Full record -> the detail file (and stderr); ONE compact line -> the real stdout."""
+    if detail_path is None:
+        detail_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_detail.json")
+    shown = None
+    try:
+        with open(detail_path, "w") as f:
+            json.dump(out, f, indent=1)
+            f.write("\n")
+        shown = os.path.relpath(detail_path, os.path.dirname(os.path.abspath(__file__)))
+        if shown.startswith(".."):
+            shown = detail_path
+    except OSError as e:                               # read-only checkout: the line still goes out
+        sys.stderr.write("bench.py: cannot write %s: %s\n" % (detail_path, e))
+    sys.stderr.write("bench.py detail record:\n" + json.dumps(out) + "\n")
+    sys.stderr.flush()
+    sys.stdout.flush()
+    os.write(fd, (compact_line(out, shown) + "\n").encode())
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -374,6 +498,12 @@ def parse_args():
     ap.add_argument("--dump-layers", default=None, help="write the per-launch table of one instrumented step here")
     ap.add_argument("--dump-launches", default=None,
                     help="write the ordered [family label, kernel base name] list of one step's MFMA launches (for tools/pmc_traffic.py)")
+    ap.add_argument("--detail", default=None,
+                    help="where the full record (kernel family tables, helper tables, per-kernel breakdowns, notes) is written; "
+                         "default: bench_detail.json next to this script.  stdout carries ONE compact line (< 4 KB)")
+    ap.add_argument("--no-dropin", action="store_true",
+                    help="skip the drop-in leg (the reference's own call sequence net(x) -> six tensors -> detect, eager and as one graph)")
+    ap.add_argument("--dropin-steps", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap decode/top-k/NMS of batch k with the forward of batch k+1")
@@ -438,7 +568,7 @@ def _main(args, real_stdout):
             except Exception as e:                 # noqa: BLE001  (side leg: the headline line survives)
                 c2 = {"error": "%s: %s" % (type(e).__name__, e)}
             out["configs2_bf16"] = {k: c2[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config",
-                                                        "launch", "roofline", "step_roofline", "gpu_ms_by_kernel_one_step",
+                                                        "launch", "roofline", "step_roofline", "gpu_ms_by_kernel_one_step", "dropin", "work_in_timed_region",
                                                         "mfma_kernel_families", "helper_kernels", "mfma_time_weighted_frac",
                                                         "sclk_under_step_ghz", "roofline_frac_at_held_clock", "error") if k in c2}
         if world == 1 and args.dtype == "f32" and args.batch is None and not args.no_configs3:
@@ -460,10 +590,50 @@ def _main(args, real_stdout):
                 out["cpu_baseline"] = cpu_baseline(sd)
             except Exception as e:                 # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "images/sec", "kind": "port", "error": "%s: %s" % (type(e).__name__, e)}
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        emit(out, args.detail, real_stdout)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def dropin_leg(net, x, conf, steps):
+    """The reference's OWN call sequence on the same frames: ``net(x)`` returning the six tensors of
+    M3d_inference_align.py:303-313 -- bundle_outputs runs, the four [B, N, C] outputs are fresh tensors -- then decode + top-3000 + NMS
+    + row selection on those tensors (lib/rpn_util.py:1439-1553, batched), launched eagerly (what a script calling the module gets)
+    and as ONE captured hipGraph.  Same bracket as the headline: synchronize, K steps, synchronize.  No overlap between batches."""
+    from m3dssd_amd.host.detect import detect_from_outputs, select_block
+    dev = x.device
+    B = x.shape[0]
+    eng = net.engine()
+    plan = eng.plan_for(B, x.shape[2], x.shape[3])
+
+    def seq():
+        with torch.no_grad():
+            cls, prob, b2, b3, feat_size, rois = net(x)
+            return select_block(*detect_from_outputs(eng, plan, prob, b2, b3, rois, conf), conf)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"value": round(B * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3)}
+
+    out = {"steps": steps, "eager": timed(seq)}
+    graph = torch.cuda.CUDAGraph()
+    cap = torch.cuda.Stream(dev)
+    cap.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(cap):
+        seq()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=cap):
+            g_block, g_counts = seq()
+    torch.cuda.current_stream(dev).wait_stream(cap)
+    out["graph"] = timed(graph.replay)
+    del graph
+    return out
 
 
 def feed_u8_leg(net, conf, B, dev, steps, resident_ms):
@@ -855,6 +1025,16 @@ def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=N
             "sclk_under_step_ghz": round(sclk, 3) if sclk else None,
             "roofline_frac_at_held_clock": round(achieved / wino_div / (peak_tf * sclk / 2.4), 4) if sclk else None,
         }
+        out["work_in_timed_region"] = (
+            "forward + decode + top-%d + NMS + select of K batches; bundle_outputs %s" %
+            (int(conf.nms_topN_pre), "NOT run (decode reads the planar head outputs; `dropin` is the bundled reference call sequence)"
+             if use_pipe else "run"))
+        if world == 1 and not args.no_dropin:
+            try:                                   # (side leg: never part of `value`)
+                out["dropin"] = dropin_leg(net, x, conf, args.dropin_steps or max(5, min(steps, 60 if not bf16 else 30)))
+                out["dropin"]["vs_headline_graph"] = round(out["dropin"]["graph"]["value"] / value, 4)
+            except Exception as e:                 # noqa: BLE001
+                out["dropin"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if feed:
             try:                                   # (side leg: never part of `value`)
                 out["feed_u8"] = feed_u8_leg(net, conf, B, dev, steps, 1e3 * dt / steps)

@@ -59,7 +59,15 @@ enum {
 
 /* Thread-local text of the last error returned on this thread. */
 const char *m3d_last_error(void);
-/* Library/ABI version (bumped when a signature changes). */
+/* Library/ABI version.  Policy: the number moves whenever a caller built against the previous header could misbehave --
+ * a signature or struct layout changes, the CONTRACT of an argument changes (a workspace size rule, a row limit, a
+ * precondition), or entry points are added that the Python binding resolves at load time.  A binding checks it once
+ * after dlopen and refuses a library of another version (m3dssd_amd/_hip.py).
+ *   4 -> 5 (round 6): m3d_conv_bf16_desc.dcn_ws sized by m3d_conv_bf16_dcn_ws_bytes(N, Ho, Wo) (was ">= 1024 bytes"),
+ *                     m3d_nms_sorted_dev / m3d_topk_decode accept up to 16 384 rows per image (was 4 096), 15 entry
+ *                     points added in round 5 (anab_attend_*, head_mlp2 / tail2 / qkvs bf16, tree_entry, frontend2, ...),
+ *                     the round-4 experimental forms (bf16_wino2, bf16_frontend, bf16_head_mlp) left the product library. */
+#define M3D_ABI_VERSION 5
 int m3d_abi_version(void);
 /* "file:sha256[:16];file:sha256[:16];..." of the sources (csrc .hip / .h files and this header) the loaded library was built from. */
 const char *m3d_source_hashes(void);
@@ -213,7 +221,10 @@ typedef struct m3d_conv_bf16_desc {
      * Wo) bytes of device scratch enable the LDS-patch kernel (csrc/bf16_dcn_patch.hip): every 16 x 16 (H % 16 == 0) or 8 x 16
      * (H % 8 == 0) pixel tile samples from an LDS-resident fp16 window sized to its own largest |offset| when that is <= 9 (<= 6)
      * and raises its word in dcn_ws otherwise; the implicit-GEMM kernel launched behind it recomputes the tiles that did
-     * (W % 16 == 0, Cin % 32 == 0, Cout_pad % 128 == 0) -- decided on the device per tile, no host synchronisation. */
+     * (W % 16 == 0, Cin % 32 == 0, Cout_pad % 128 == 0) -- decided on the device per tile, no host synchronisation.
+     * Mixed rounding: a recomputing workgroup rewrites its whole 128-pixel tile, so which of the two kernels' roundings (fp16
+     * window vs bf16 gather; both inside the bf16 tolerance) a pixel carries depends on the OFFSET DATA of its neighbourhood;
+     * for given inputs the output is deterministic.  `res` must not alias `out` on this path (checked: M3D_E_ARG). */
     const void *wgt_f16;
     void *dcn_ws;
     long long dcn_ws_bytes;
@@ -250,28 +261,6 @@ typedef struct m3d_tree_entry_bf16_desc {
 } m3d_tree_entry_bf16_desc;
 int m3d_tree_entry_bf16_applicable(const m3d_tree_entry_bf16_desc *d);
 int m3d_tree_entry_bf16_forward(const m3d_tree_entry_bf16_desc *d, m3d_stream_t stream);
-
-/* 3x3 stride-1 pad-1 convolution of the bf16 path by Winograd F(2x2, 3x3) on fp16 MFMA (csrc/bf16_wino2.hip; replaces nn.Conv2d +
- * BatchNorm2d (+ residual) + activation of model/pose_dla_dcn.py:107-121 and model/M3d_inference_align.py:66-75 where it applies:
- * Cin % 32 == 0 (>= 64), Cout % 128 == 0, H % 8 == 0, W % 16 == 0):  out = act(conv3x3(in) * scale + shift (+ res)), 2.25x fewer
- * MFMA passes than the direct kernels -- and operand-bound: measured slower than m3d_conv_bf16_forward's wave-tile kernel, NOT used
- * by the engine (see the source header).  bf16 -> fp16 input conversion is exact, the transforms run in fp16 (input) / fp32 (weights,
- * output), products accumulate in fp32.  wfrag = G g G^T * scale[cout] in fp16, fragment order [Cout/32][Cin/32][16 positions]
- * [2 K steps][64 lanes][8]: lane l, element e of (slice ws, chunk c, position p = 4 i + j, step s) is U[i][j] of output channel
- * 32 ws + 16 ((r % 8) / 4) + 4 (r / 8) + r % 4 (r = l % 32) and input channel 32 c + 16 s + 8 (l / 32) + e
- * (m3dssd_amd/engine_bf16.py: pack_wino2); shift fp32 [Cout]; views bf16 NHWC, pixel strides in elements (% 8 == 0); act 0 none,
- * 1 LeakyReLU(0.01). */
-typedef struct m3d_wino2_bf16_desc {
-    const void *in;
-    int in_cs, N, H, W, Cin, Cout;
-    const void *wfrag;
-    const float *shift;
-    const void *res; int res_cs;     /* optional residual (added before the activation) */
-    void *out; int out_cs;
-    int act;
-} m3d_wino2_bf16_desc;
-int m3d_wino2_bf16_applicable(const m3d_wino2_bf16_desc *d);
-int m3d_wino2_bf16_forward(const m3d_wino2_bf16_desc *d, m3d_stream_t stream);
 
 /* Fused 3-layer RPN head of the bf16 path (model/M3d_inference_align.py:77-210): [1x1 128 -> 256, affine, LeakyReLU] ->
  * [1x1 256 -> 256, affine, LeakyReLU] -> [1x1 256 -> Cout, affine] per 128-pixel tile in ONE launch, hidden activations in LDS.
@@ -350,16 +339,9 @@ int m3d_anab_qkvs_bf16_forward(const m3d_qkvs_bf16_desc *d, m3d_stream_t stream)
 int m3d_stem_conv7x7_bf16(const void *img, int is_u8, int img_h, int img_w, const float *mean3, const float *stds3,
                           const float *wgt, const float *scale, const float *shift, void *out, int out_cs, int N, int H, int W,
                           m3d_stream_t stream);
-/* Fused front end of the bf16 path: base_layer 7x7 3->16 -> level0 3x3 16->16 -> level1 3x3/2 16->32, each + folded BN +
- * LeakyReLU (pose_dla_dcn.py:336-345,391-397), image read once, only the level1 map [N][H/2][W/2][out_cs >= 32] bf16 written.
- * img / is_u8 / img_h / img_w / mean3 / stds3 as in m3d_stem_conv7x7_bf16.  Weights bf16: w_stem [16][7*32] with
- * k = i*32 + j*4 + c (tap row i, tap column j < 7, channel c < 3, other slots 0); w_l0 [16][160], w_l1 [32][160] with
- * k = (i*3 + j)*16 + c, zero padded from 144. */
-int m3d_frontend_bf16_forward(const void *img, int is_u8, int img_h, int img_w, const float *mean3, const float *stds3,
-                              const void *w_stem, const float *s_stem, const float *t_stem, const void *w_l0, const float *s_l0,
-                              const float *t_l0, const void *w_l1, const float *s_l1, const float *t_l1, void *out, int out_cs,
-                              int N, int H, int W, m3d_stream_t stream);
-/* Round-5 form of the fused front end (csrc/bf16_frontend2.hip): fp16 inside the kernel (the tiles never leave LDS), the
+/* Fused front end of the bf16 path (csrc/bf16_frontend2.hip): base_layer 7x7 3->16 -> level0 3x3 16->16 -> level1 3x3/2 16->32,
+ * each + folded BN + LeakyReLU (pose_dla_dcn.py:336-345,391-397) in ONE launch: the image is read once, only the level1 map
+ * [N][H/2][W/2][out_cs >= 32] bf16 is written.  img / is_u8 / img_h / img_w / mean3 / stds3 as in m3d_stem_conv7x7_bf16.  fp16 inside the kernel (the tiles never leave LDS), the
  * BatchNorm scales folded into fp16 weights by the caller, the shifts added as the C operand of the MFMA chains; stem on
  * v_mfma_f32_32x32x16_f16 with two adjacent output pixels per column.  Operands (m3dssd_amd/engine_bf16.py: pack_frontend_f16):
  *   w_stem_frag fp16 [7 tap rows][2 K-steps][64 lanes][8]: lane l, element e = weight * scale of channel 4 * ((l % 32) / 8) +
@@ -367,7 +349,7 @@ int m3d_frontend_bf16_forward(const void *img, int is_u8, int img_h, int img_w, 
  *               + e / 4 - shift (outside [0, 7): zero); colour slot 3 of tap (0, 0) = the channel's BatchNorm shift (the kernel
  *               writes 1.0 into that slot of every image pixel; t_stem itself is not read);
  *   w_l0 / w_l1 fp16 [16 | 32][160], k = tap * 16 + c (k >= 144 zero), scale folded; t_* fp32 shifts [16], [16], [32].
- * Same image arguments and output as m3d_frontend_bf16_forward. */
+ */
 int m3d_frontend2_bf16_forward(const void *img, int is_u8, int img_h, int img_w, const float *mean3, const float *stds3,
                                const void *w_stem_frag, const float *t_stem, const void *w_l0, const float *t_l0,
                                const void *w_l1, const float *t_l1, void *out, int out_cs, int N, int H, int W,
@@ -376,7 +358,10 @@ int m3d_frontend2_bf16_forward(const void *img, int is_u8, int img_h, int img_w,
  * out[p] = act((softmax_k(q[p] . khat[k]) @ vhat + res[p]) * scale + shift) per image, replacing the logits GEMM / row softmax /
  * P.V GEMM sequence (m3d_conv_bf16_forward with per-image weights, m3d_softmax_rows_bf16).  q bf16 [B*HW][q_cs] (channels
  * [Ck, Ck_pad) zero), khat bf16 [B][keys_pad][Ck_pad], vhatT bf16 [B][Cv][keys_pad] (rows >= keys ignored), res bf16 [B*HW][res_cs]
- * or NULL, scale / shift fp32 [Cv] or NULL, out bf16 [B*HW][out_cs].  Built for Ck_pad = 192, Cv = 128; HW % 128 == 0. */
+ * or NULL, scale / shift fp32 [Cv] or NULL, out bf16 [B*HW][out_cs].  Built for Ck_pad = 192, Cv = 128; HW % 128 == 0.
+ * PRECONDITION (not checked): the padding -- khat rows [keys, keys_pad) and vhatT columns [keys, keys_pad) -- must hold FINITE
+ * values (zeros; m3d_anab_pool_nested* leave what the caller allocated, the engine allocates with zeros): the padded keys get
+ * probability 0, and 0 * (Inf | NaN) in the P.V product would be NaN. */
 int m3d_anab_attend_bf16(const void *q, int q_cs, const void *khat, const void *vhatT, int B, int HW, int Ck_pad, int keys,
                          int keys_pad, int Cv, const void *res, int res_cs, const float *scale, const float *shift, int act,
                          void *out, int out_cs, m3d_stream_t stream);
@@ -532,7 +517,9 @@ int m3d_anab_pool_nested_bf16_ex(const void *kv, int kv_cs, const float *s, int 
  * and the P.V GEMM (the logits never reach memory; one pass over the keys with a running maximum).  q [B*HW][q_cs] (first Ck
  * channels), khat [B][keys_pad][k_cs] and vhatT [B][Cv][keys_pad] row-major as m3d_anab_pool_nested / _finish write them with
  * frag = 0; Ck in {64, 128, 168}, Cv = 128, HW % 128 == 0, keys_pad % 32 == 0; res_mode as in m3d_conv_desc (0: + res behind the
- * affine, 1: before it); scale / shift / res may be NULL. */
+ * affine, 1: before it); scale / shift / res may be NULL.
+ * PRECONDITION (not checked): khat rows [keys, keys_pad) and vhatT columns [keys, keys_pad) hold finite values (zeros), as for
+ * m3d_anab_attend_bf16. */
 int m3d_anab_attend_f32(const float *q, int q_cs, const float *khat, int k_cs, const float *vhatT, int B, int HW, int Ck,
                         int keys, int keys_pad, int Cv, const float *res, int res_cs, int res_mode, const float *scale,
                         const float *shift, int act, float *out, int out_cs, m3d_stream_t stream);

@@ -113,15 +113,6 @@ class TreeEntryBf16Desc(ctypes.Structure):
     ]
 
 
-class Wino2Bf16Desc(ctypes.Structure):
-    """Mirror of ``m3d_wino2_bf16_desc``."""
-    _fields_ = [
-        ("inp", c_void_p), ("in_cs", c_int), ("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("Cout", c_int),
-        ("wfrag", c_void_p), ("shift", c_void_p), ("res", c_void_p), ("res_cs", c_int), ("out", c_void_p), ("out_cs", c_int),
-        ("act", c_int),
-    ]
-
-
 class QkvsBf16Desc(ctypes.Structure):
     """Mirror of ``m3d_qkvs_bf16_desc``."""
     _fields_ = [
@@ -144,16 +135,12 @@ SIGNATURES = {
     "m3d_conv_bf16_variant": (c_int, [ctypes.POINTER(ConvBf16Desc)]),
     "m3d_head_mlp_bf16_forward": (c_int, [ctypes.POINTER(HeadBf16Desc), P]),
     "m3d_head_mlp2_bf16_forward": (c_int, [ctypes.POINTER(Head2Bf16Desc), P]),
-    "m3d_wino2_bf16_applicable": (c_int, [ctypes.POINTER(Wino2Bf16Desc)]),
-    "m3d_wino2_bf16_forward": (c_int, [ctypes.POINTER(Wino2Bf16Desc), P]),
     "m3d_tree_entry_bf16_applicable": (c_int, [ctypes.POINTER(TreeEntryBf16Desc)]),
     "m3d_tree_entry_bf16_forward": (c_int, [ctypes.POINTER(TreeEntryBf16Desc), P]),
     "m3d_anab_qkvs_bf16_forward": (c_int, [ctypes.POINTER(QkvsBf16Desc), P]),
     "m3d_head_tail2_bf16_forward": (c_int, [ctypes.POINTER(Tail2Bf16Desc), P]),
     "m3d_stem_conv7x7_bf16": (c_int, [P, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                       P, P, P, P, c_int, c_int, c_int, c_int, P]),
-    "m3d_frontend_bf16_forward": (c_int, [P, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
-                                  + [P] * 10 + [c_int] * 4 + [P]),
     "m3d_frontend2_bf16_forward": (c_int, [P, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
                                    + [P] * 7 + [c_int] * 4 + [P]),
     "m3d_anab_attend_bf16": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, c_int, P, c_int, P]),

@@ -14,7 +14,7 @@ void m3d_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *m3d_last_error(void) { return g_err; }
-extern "C" int m3d_abi_version(void) { return 4; }
+extern "C" int m3d_abi_version(void) { return M3D_ABI_VERSION; }
 // "name:sha256[:16];..." of every source this library was built from (build/src_hash.h, written by the Makefile): lets a
 // measurement taken with one build (profiles/*_hbm_traffic.json) be told apart from the build that is loaded now.
 #include "build/src_hash.h"

@@ -707,6 +707,10 @@ extern "C" int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t s
     const int pvar = deform ? dcn_patch_variant(d) : 0;
     if (pvar) {
         int rc;
+        // a fallback workgroup recomputes its WHOLE 128-pixel tile when any patch tile it touches carries the flag: pixels the patch
+        // kernel already wrote are written a second time (with this kernel's rounding), which is idempotent only while the
+        // residual does not alias the output -- an in-place residual would be added twice
+        M3D_REQUIRE(d->res == nullptr || d->res != d->out, "m3d_conv_bf16_forward: the LDS-patch DCNv2 path needs res != out");
         if ((rc = launch_dcn_patch(a, d, pvar, st))) return rc;
         a.gate = (const unsigned *)d->dcn_ws; a.gate_th = pvar; a.gate_tpx = d->Wo / 16; a.gate_tpy = d->Ho / pvar;
     }

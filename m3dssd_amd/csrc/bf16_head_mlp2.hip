@@ -60,10 +60,27 @@ struct Head2Args {
 // byte offset of 16-byte chunk c of row r (rb = bytes per row, 256 or 512): chunks XOR-swizzled by the row inside each 256-byte half
 __device__ __forceinline__ int h2_off(int r, int c, int rb) { return r * rb + ((((c & 15) ^ (r & 15)) | (c & 16)) << 4); }
 
+// The hidden activations are fp16: a value past +-65504 would convert to +-inf and turn into NaN in the next layer's MFMA
+// (inf * 0 weight padding, inf - inf) without any signal.  M3D_F16_SATURATE (default on) clamps the packed pair to the
+// finite range -- two packed-fp16 instructions per pair -- so that an out-of-range activation degrades like a saturating
+// quantiser instead of poisoning the planar outputs; -DM3D_F16_SATURATE=0 builds the unclamped form.
+#ifndef M3D_F16_SATURATE
+#define M3D_F16_SATURATE 1
+#endif
+__device__ __forceinline__ f16x2 f16_sat(f16x2 y)
+{
+#if M3D_F16_SATURATE
+    const f16x2 hi = {(_Float16)65504.0f, (_Float16)65504.0f};
+    return __builtin_elementwise_max(__builtin_elementwise_min(y, hi), -hi);
+#else
+    return y;
+#endif
+}
+
 __device__ __forceinline__ unsigned h2_leaky_pack(float lo, float hi)
 {
     const f32x2 v = {lo, hi};
-    const f16x2 y = __builtin_convertvector(v, f16x2);
+    const f16x2 y = f16_sat(__builtin_convertvector(v, f16x2));
     const f16x2 sl = {(_Float16)M3D_LEAKY_SLOPE, (_Float16)M3D_LEAKY_SLOPE};
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(y, y * sl));
 }
@@ -308,7 +325,7 @@ struct Tail2Args {
 __device__ __forceinline__ unsigned t2_shift_leaky_pack(float lo, float hi, unsigned shift_pair)
 {
     const f32x2 v = {lo, hi};
-    const f16x2 y = __builtin_convertvector(v, f16x2) + __builtin_bit_cast(f16x2, shift_pair);
+    const f16x2 y = f16_sat(__builtin_convertvector(v, f16x2) + __builtin_bit_cast(f16x2, shift_pair));
     const f16x2 sl = {(_Float16)M3D_LEAKY_SLOPE, (_Float16)M3D_LEAKY_SLOPE};
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(y, y * sl));
 }

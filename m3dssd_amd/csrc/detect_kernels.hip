@@ -11,6 +11,8 @@
 //    exactly the rows still needed.  No float atomics, no data-dependent launch count: graph-capturable.
 //  * select_post_kernel: keep lists of the NMS -> [B][post + 1][14] blocks (zero padded; row `post` carries the count), the
 //    wire format of the multi-GPU all-gather.
+#include <atomic>
+
 #include "common.h"
 
 #define TOPK_NT 1024
@@ -290,13 +292,23 @@ static int topk_launch(const TopkArgs &a, int B, hipStream_t stream)
     int P = 1;
     while (P < a.k) P <<= 1;
     const int lds = P * (int)sizeof(unsigned long long);             // <= 128 KB (+ 8 KB of static LDS)
-    static const int big_ok = []() {
-        const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            TOPK_MAXK * (int)sizeof(unsigned long long)) == hipSuccess;
-        if (!ok) (void)hipGetLastError();
-        return ok ? 1 : 0;
-    }();
-    M3D_REQUIRE(big_ok || lds <= 32768, "topk_decode: cannot reserve %d bytes of LDS for k = %d", lds, a.k);
+    if (lds > 32768) {
+        // The raised dynamic-LDS limit is a PER-DEVICE attribute of the kernel: a process that drives several GPUs (nn.DataParallel
+        // replica engines, one engine per device) needs it on each of them -- set it on the current device, once per device ordinal.
+        static std::atomic<int> state[64];                             // 0 unknown, 1 raised, 2 refused
+        int dev = 0;
+        M3D_HIP(hipGetDevice(&dev));
+        int st = (dev >= 0 && dev < 64) ? state[dev].load(std::memory_order_acquire) : 0;
+        if (st == 0) {
+            const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_decode_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                TOPK_MAXK * (int)sizeof(unsigned long long)) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+            st = ok ? 1 : 2;
+            if (dev >= 0 && dev < 64) state[dev].store(st, std::memory_order_release);
+        }
+        M3D_REQUIRE(st == 1, "topk_decode: device %d cannot reserve %d bytes of LDS for k = %d", dev, lds, a.k);
+    }
     hipLaunchKernelGGL(topk_decode_kernel, dim3(B), dim3(TOPK_NT), lds, stream, a);
     M3D_LAUNCH_CHECK();
     return M3D_OK;

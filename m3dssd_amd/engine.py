@@ -692,6 +692,7 @@ class Engine:
         if NC == 4 and A >= 4 and SELECT_KEYS:
             # + the detection stage's sort keys (plan.named["score_bits"], created below) while the logits are in registers
             plan.named["keys_by_select"] = True
+            plan.named["score_bits_first_write_op"] = len(plan.ops)     # a detect(k-1) beside forward(k) must be done before it
             self._op(plan, "anchor_select", "select", lambda st: _hip.check(L.m3d_anchor_select_keys(
                 cls_pl.data_ptr(), B, A, HW, sel_idx.data_ptr(), sel_prob.data_ptr(), plan.named["score_bits"].data_ptr(), st)),
                 nbytes=B * HW * (A * NC + 2 + A) * 4)

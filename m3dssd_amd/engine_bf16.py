@@ -34,7 +34,6 @@ BRANCH = os.environ.get("M3D_BF16_BRANCH", "1") != "0"         # ANAB + z3d head
 TREE_ENTRY = os.environ.get("M3D_BF16_TREE_ENTRY", "1") != "0"   # max-pool + project + stride-2 conv1 of a tree in one launch (csrc/bf16_tree_entry.hip)
 HEADS2 = os.environ.get("M3D_BF16_HEADS2", "1") != "0"         # round-5 form of the fused heads (csrc/bf16_head_mlp2.hip)
 SHAPE_PATCH = os.environ.get("M3D_BF16_SHAPE_PATCH", "0") != "0"   # shape_align through the LDS-patch DCNv2 kernel (per-tile decision)
-FRONT2 = os.environ.get("M3D_BF16_FRONT2", "1") != "0"         # round-5 form of the fused front end (csrc/bf16_frontend2.hip)
 
 
 
@@ -45,20 +44,6 @@ def _f16_checked(t, what):
     if not bool(torch.isfinite(t).all()) or float(t.abs().max()) > 65504.0:
         raise RuntimeError("bf16 engine: %s with the BatchNorm scale folded in leaves the fp16 range (|w| max %g)" % (what, float(t.abs().max())))
     return t.to(torch.float16)
-
-
-def pack_frontend_bf16(w_stem, w_l0, w_l1, device):
-    """Weights of m3d_frontend_bf16_forward: stem [16,3,7,7] -> [16][7*32] (k = i*32 + j*4 + c), level0 / level1
-    [Co,16,3,3] -> [Co][160] (k = (i*3 + j)*16 + c)."""
-    ws = torch.zeros(16, 7, 8, 4)
-    ws[:, :, :7, :3] = w_stem.detach().float().cpu().permute(0, 2, 3, 1)
-    out = [ws.reshape(16, 224)]
-    for w in (w_l0, w_l1):
-        co = w.shape[0]
-        t = torch.zeros(co, 160)
-        t[:, :144] = w.detach().float().cpu().permute(0, 2, 3, 1).reshape(co, 144)
-        out.append(t)
-    return [t.to(device, BF16).contiguous() for t in out]
 
 
 def pack_frontend_f16(w_stem, bn_stem, w_l0, bn_l0, w_l1, bn_l1, device):
@@ -157,25 +142,6 @@ def pack_tree_entry(w1, s1, wp, sp, device):
     return _f16_checked(out, "tree entry weights").contiguous().to(device)
 
 
-def pack_wino2(w, scale, device):
-    """Weights of m3d_wino2_bf16_forward (csrc/bf16_wino2.hip): w [Cout, Cin, 3, 3] fp32, scale [Cout] (folded BatchNorm) ->
-    U = G g G^T * scale in fp32, rounded once to fp16, in the A-fragment order [Cout/32][Cin/32][16 positions p = 4 i + j][2 K steps]
-    [64 lanes][8]: lane l, element e holds output channel 32 ws + 16 ((r % 8) / 4) + 4 (r / 8) + r % 4 (r = l % 32) and input channel
-    32 c + 16 s + 8 (l / 32) + e."""
-    co, ci = w.shape[0], w.shape[1]
-    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
-    g = w.detach().double().cpu() * scale.detach().double().cpu()[:, None, None, None]
-    U = torch.einsum("ik,ockl,jl->ocij", G, g, G).reshape(co, ci, 16).float()                # [Co, Ci, p]
-    lane = torch.arange(64)
-    r = lane % 32
-    ch = 32 * torch.arange(co // 32)[:, None] + (16 * ((r % 8) // 4) + 4 * (r // 8) + r % 4)[None, :]                  # [WS, 64]
-    cin = (32 * torch.arange(ci // 32)[:, None, None, None] + 16 * torch.arange(2)[None, :, None, None]
-           + 8 * (lane // 32)[None, None, :, None] + torch.arange(8)[None, None, None, :])                               # [C, 2, 64, 8]
-    # out[ws, c, p, s, l, e] = U[ch[ws, l], cin[c, s, l, e], p]
-    out = U[ch[:, None, None, None, :, None], cin[None, :, None, :, :, :], torch.arange(16)[None, None, :, None, None, None]]
-    return _f16_checked(out, "Winograd-transformed 3x3 weights").contiguous().to(device)
-
-
 class View16:
     """NHWC bf16 view (possibly a channel slice) of a device buffer; strides in elements."""
     __slots__ = ("t", "ptr", "n", "h", "w", "c", "cs", "esize")
@@ -270,7 +236,6 @@ class EngineBF16(Engine):
         P["stem.scale"], P["stem.shift"] = s.contiguous(), (be - m * s).contiguous()
         P["level0"] = self._pc(b + ".level0.0", b + ".level0.1")
         P["level1"] = self._pc(b + ".level1.0", b + ".level1.1")
-        P["front.w"] = pack_frontend_bf16(sd[b + ".base_layer.0.weight"], sd[b + ".level0.0.weight"], sd[b + ".level1.0.weight"], dev)
         P["front2"] = pack_frontend_f16(sd[b + ".base_layer.0.weight"], (P["stem.scale"], P["stem.shift"]),
                                         sd[b + ".level0.0.weight"], (P["level0"].scale, P["level0"].shift),
                                         sd[b + ".level1.0.weight"], (P["level1"].scale, P["level1"].shift), dev)
@@ -437,25 +402,16 @@ class EngineBF16(Engine):
         l1 = self._buf16(plan, B, H // 2, W // 2, 32, name="level1")
         if FUSED_FRONT:
             # stem -> level0 -> level1 in one launch: the 16-channel full-resolution maps never reach HBM
-            fwts, p0, p1 = P["front.w"], P["level0"], P["level1"]
+            f2 = P["front2"]
 
             def front(st):
                 u8 = 1 if in_u8[0] else 0
-                _hip.check(L.m3d_frontend_bf16_forward(
-                    in_u8[0] if u8 else in_ptr[0], u8, in_u8[1], in_u8[2], mean3, stds3, fwts[0].data_ptr(),
-                    P["stem.scale"].data_ptr(), P["stem.shift"].data_ptr(), fwts[1].data_ptr(), p0.scale.data_ptr(),
-                    p0.shift.data_ptr(), fwts[2].data_ptr(), p1.scale.data_ptr(), p1.shift.data_ptr(), l1.ptr, l1.cs, B, H, W, st))
-            if FRONT2:
-                f2 = P["front2"]
-
-                def front(st):         # noqa: F811
-                    u8 = 1 if in_u8[0] else 0
-                    _hip.check(L.m3d_frontend2_bf16_forward(
-                        in_u8[0] if u8 else in_ptr[0], u8, in_u8[1], in_u8[2], mean3, stds3, f2[0].data_ptr(), f2[1].data_ptr(),
-                        f2[2].data_ptr(), f2[3].data_ptr(), f2[4].data_ptr(), f2[5].data_ptr(), l1.ptr, l1.cs, B, H, W, st))
+                _hip.check(L.m3d_frontend2_bf16_forward(
+                    in_u8[0] if u8 else in_ptr[0], u8, in_u8[1], in_u8[2], mean3, stds3, f2[0].data_ptr(), f2[1].data_ptr(),
+                    f2[2].data_ptr(), f2[3].data_ptr(), f2[4].data_ptr(), f2[5].data_ptr(), l1.ptr, l1.cs, B, H, W, st))
             flops = 2.0 * B * H * W * (147 * 16 + 144 * 16) + 2.0 * B * (H // 2) * (W // 2) * 144 * 32
             # (bytes: the fp32 NCHW image in, the 32-channel half-resolution bf16 map out)
-            plan.ops.append(("stem+level0+level1", "bf16_frontend2" if FRONT2 else "bf16_frontend", flops, front,
+            plan.ops.append(("stem+level0+level1", "bf16_frontend2", flops, front,
                              OpCost(B * H * W * 3 * 4 + B * (H // 2) * (W // 2) * 32 * 2)))
         else:
             s0 = self._buf16(plan, B, H, W, 16)
@@ -701,6 +657,7 @@ class EngineBF16(Engine):
         if NC == 4 and A >= 4 and SELECT_KEYS:
             # + the detection stage's sort keys (plan.named["score_bits"], created below) while the logits are in registers
             plan.named["keys_by_select"] = True
+            plan.named["score_bits_first_write_op"] = len(plan.ops)     # a detect(k-1) beside forward(k) must be done before it
             self._op(plan, "anchor_select", "select", lambda st: _hip.check(L.m3d_anchor_select_keys(
                 cls_pl.data_ptr(), B, A, HW, sel_idx.data_ptr(), sel_prob.data_ptr(), plan.named["score_bits"].data_ptr(), st)),
                 nbytes=B * HW * (A * NC + 2 + A) * 4)

@@ -120,7 +120,8 @@ def detect_device(net, im, conf, top_post=None, scale=None):
     im = im.to(dev) if u8 else im.to(dev, torch.float32)
     with torch.no_grad():
         net.eval()
-        cls, prob, bbox_2d, bbox_3d, feat_size, rois = net(im)
+        # plan-owned views, consumed right here (net(im) itself returns fresh tensors: host/rpn.py)
+        cls, prob, bbox_2d, bbox_3d, feat_size, rois = net._forward_views(im)
         eng = net.engine()
         H, W = (int(v) for v in conf.crop_size) if u8 else (im.shape[2], im.shape[3])
         plan = eng.plan_for(prob.shape[0], H, W)

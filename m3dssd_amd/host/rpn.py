@@ -75,6 +75,7 @@ class RPN(nn.Module):
         # a parent's load_state_dict reaches sub-modules through _load_from_state_dict only: invalidate from there
         self.register_load_state_dict_post_hook(_invalidate_after_load)
         self.compute_dtype = str(conf.compute_dtype) if "compute_dtype" in conf else "f32"
+        self.reuse_outputs = bool(conf.reuse_outputs) if "reuse_outputs" in conf else False
 
     # -- engine management: parameters are folded / packed once and re-packed when they change --------------------------------
     # Everything that replaces or moves parameters through the nn.Module API marks the packed engine stale:
@@ -193,6 +194,17 @@ class RPN(nn.Module):
         return self._engine
 
     def forward(self, x):
+        """Eval-mode forward of the reference (M3d_inference_align.py:303-313).  The four big outputs are FRESH tensors, as the
+        reference's are: a caller may keep them across iterations.  ``conf.reuse_outputs = True`` (or ``net.reuse_outputs = True``)
+        returns views of the engine's plan-owned buffers instead, which the next forward of the same shape overwrites -- the form
+        the device detection stage (lib.rpn_util.detect_batch / im_detect_3d, PipelinedDetector) uses internally: it consumes the
+        outputs before the next forward and saves the 4 x [B, N, C] copies (0.17 GB at bs 8)."""
+        out = self._forward_views(x)
+        if self.reuse_outputs:
+            return out
+        return tuple(t.clone() for t in out[:4]) + out[4:]
+
+    def _forward_views(self, x):
         if self.training:
             raise NotImplementedError("m3dssd_amd accelerates inference (eval mode); call .eval() or build(conf, 'test')")
         u8 = x.dtype == torch.uint8 and x.dim() == 4 and x.shape[3] == 3      # raw BGR frames [B, h, w, 3]: the test-time

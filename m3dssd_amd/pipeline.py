@@ -80,7 +80,11 @@ class PipelinedDetector:
         assert self.plan.ops[-1][0] == "bundle_outputs"
         n = self.plan.named
         # planar form: the side branch must be done before the first launch that overwrites the planar staging
-        self.n_join = int(n["planar_first_op"]) if self.planar else self.n_fwd
+        # bundled form: detect(k-1) reads prob / bbox_* / score_bits; bundle_outputs (the last op) writes the first three, but with
+        # SELECT_KEYS anchor_select of batch k already writes score_bits in the middle of the forward (that write ran
+        # unordered against the side branch's top-k): join in front of the FIRST op that writes anything the side branch reads
+        self.n_join = int(n["planar_first_op"]) if self.planar else min(self.n_fwd, int(n.get("score_bits_first_write_op", self.n_fwd)))
+        self._check_no_write_beside_detect()
         # where the side branch forks off (experiment switch M3D_PIPE_FORK = op index; default: at the first launch).  In the bf16 graph
         # the persistent front end is stretched from 0.83 to 1.09 ms by detect(k-1) beside it (tools/graph_timeline.py), but forking
         # behind it moves the cost, it does not remove it: 10.48 / 10.58 / 10.61 / 10.52 ms for forks at op 0 / 1 / 2 / 3 on one lease
@@ -101,6 +105,18 @@ class PipelinedDetector:
             self._clip = torch.zeros(batch, 2, device=dev, dtype=torch.float32)
             self._meta_next = None
         self._build()
+
+    def _check_no_write_beside_detect(self):
+        """No op of forward(k) in [0, n_join) may write a buffer that detect(k-1) reads: the ops that do are known by name
+        (the heads and anchor_select write the planar staging / the sort keys, bundle_outputs the bundled tensors)."""
+        n = self.plan.named
+        first_writer = {"planar": int(n["planar_first_op"]), "keys": int(n.get("score_bits_first_write_op", self.n_fwd)),
+                        "bundled": self.n_fwd}
+        reads = ("planar", "keys") if self.planar else ("keys", "bundled")
+        limit = min(first_writer[r] for r in reads)
+        if self.n_join > limit:
+            raise AssertionError("PipelinedDetector: join at op %d, but op %d of the next forward writes what detect reads (%s)"
+                                 % (self.n_join, limit, first_writer))
 
     def _detect(self):
         prob, b2, b3 = self._outs

@@ -9,9 +9,16 @@
  *   sequential greedy reduce on the host ... lib/nms/nms_kernel.cu:124-141
  *   caller-side descending score sort ...... lib/nms/gpu_nms.pyx:24-31
  *
- * All IoU arithmetic is IEEE fp32 with no FMA contraction (the expression has no
- * mul feeding an add: width*height, (a2-a0+1)*(a3-a1+1), Sa+Sb-interS) -- built
- * with -ffp-contract=off so the CPU matches the device bit for bit.
+ * All IoU arithmetic is IEEE fp32 with NO FMA contraction.  The expression DOES hold
+ * products that feed an add/subtract -- interS = width*height goes into Sa + Sb - interS,
+ * and Sa, Sb are themselves products (a2-a0+1)*(a3-a1+1) (nms_kernel.cu:27-31) -- so a
+ * compiler free to contract would fuse them (fma(-width, height, Sa+Sb), ...) and change
+ * the last bit.  This file, the device kernel (csrc/nms.hip) and the pinned target
+ * (lib/nms/py_cpu_nms.py: numpy, one rounding per operation) all evaluate it unfused:
+ * this file is built with -ffp-contract=off, csrc/nms.hip carries `#pragma clang fp contract(off)` around
+ * the expression -- both are load-bearing.  (An nvcc build of
+ * the reference may contract it -- nvcc's default is --fmad=true; there is no such build
+ * to compare with here, so parity is pinned on the unfused numpy form.)
  */
 #include <stdint.h>
 #include <stdlib.h>

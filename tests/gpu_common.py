@@ -116,7 +116,7 @@ def _parity_log(name, payload):
     import json
     d = os.path.join(os.path.dirname(GOLDEN.rstrip("/")), "..", "gpurun_out")
     if os.path.isdir(d):
-        with open(os.path.join(d, "parity_r04.jsonl"), "a") as f:
+        with open(os.path.join(d, "parity_r06.jsonl"), "a") as f:
             f.write(json.dumps({"test": name, **payload}) + "\n")
 
 
@@ -179,10 +179,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _log(name, payload):
-    """Measured margins of the parity tests, merged back from the GPU box (gpurun_out/parity_r04.jsonl)."""
+    """Measured margins of the parity tests, merged back from the GPU box (gpurun_out/parity_r06.jsonl)."""
     d = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(d):
-        with open(os.path.join(d, "parity_r04.jsonl"), "a") as f:
+        with open(os.path.join(d, "parity_r06.jsonl"), "a") as f:
             f.write(json.dumps({"test": name, **payload}) + "\n")
 
 

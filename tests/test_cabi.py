@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), n
     assert names == set(_hip.SIGNATURES), (names ^ set(_hip.SIGNATURES))
-    assert L.m3d_abi_version() == 4
+    assert L.m3d_abi_version() == 5
 
 
 def test_conv_desc_layout_matches_header():

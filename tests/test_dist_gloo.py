@@ -55,3 +55,42 @@ def test_shard_range_and_single_process_passthrough():
     d, c = torch.zeros(2, 40, 14), torch.zeros(2, dtype=torch.int32)
     d2, c2 = mdist.gather_detections(d, c)
     assert d2 is d and c2 is c
+
+
+def _worker8(rank, world, port, out_dir):
+    """BASELINE.json configs[3]: bs 256 = 8 ranks x 32 images; every rank contributes its [32, 41, 14] block (40 kept rows + the
+    count row, as m3d_select_post writes it) to ONE all_gather_into_tensor and reads [256, 40, 14] + [256] back."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    torch.set_num_threads(1)
+    r, w, _ = mdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    g = torch.Generator().manual_seed(7)
+    B, P = 256, 40
+    counts = torch.randint(0, P + 1, (B,), generator=g, dtype=torch.int32)
+    counts[::37] = 0
+    counts[5::41] = P
+    full = torch.zeros(B, P + 1, 14)
+    full[:, :P] = torch.randn(B, P, 14, generator=g)
+    for i in range(B):
+        full[i, int(counts[i]):P] = 0
+    full[:, P, 0] = counts.float()
+    lo, hi = mdist.shard_range(B, rank, world)
+    assert (lo, hi) == (32 * rank, 32 * rank + 32)
+    block = full[lo:hi].contiguous()
+    assert tuple(block.shape) == (32, 41, 14) and block.numel() * 4 == 73472
+    ok = True
+    for _ in range(2):                           # second call: the cached receive buffer
+        dets, cnt = mdist.gather_block(block)
+        ok = ok and tuple(dets.shape) == (256, 40, 14) and tuple(cnt.shape) == (256,) and cnt.dtype == torch.int32
+        ok = ok and torch.equal(dets, full[:, :P]) and torch.equal(cnt, counts)
+    np.save(os.path.join(out_dir, "ok8_%d.npy" % rank), np.array([int(ok)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_block_world8_configs3_block_gloo(tmp_path):
+    world, port = 8, _free_port()
+    mp.spawn(_worker8, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert np.load(os.path.join(str(tmp_path), "ok8_%d.npy" % r))[0] == 1

@@ -14,8 +14,6 @@ for cfg in "bf16 64" "f32 8"; do set -- $cfg
 done
 timeout 200 python tools/front2_trace.py > $O/${TAG}_front2_trace.txt 2>&1
 timeout 200 python tools/bf16_head2_trace.py > $O/${TAG}_head2_trace.txt 2>&1
-timeout 200 python tools/wino2_trace.py > $O/${TAG}_wino2_trace.txt 2>&1
-timeout 200 python tools/wino2_bench.py > $O/${TAG}_wino2_bench.txt 2>&1
 timeout 100 python tools/nms_bench.py 64 3000 > $O/${TAG}_nms.txt 2>&1; M3D_NMS_DIV=1 timeout 100 python tools/nms_bench.py 64 3000 >> $O/${TAG}_nms.txt 2>&1
 tail -3 $O/${TAG}_tests.log; python -c "
 import json; d=json.load(open('$O/${TAG}_bench_default.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic_stale'], d['configs2_bf16']['ms_per_step'])"

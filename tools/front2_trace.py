@@ -1,4 +1,4 @@
-"""Fused bf16 front end (stem -> level0 -> level1): launch times of both forms back to back, and -- with the diagnostic build
+"""Fused bf16 front end (stem -> level0 -> level1): launch time, and -- with the diagnostic build
 `make -C m3dssd_amd/csrc trace` -- the in-kernel timeline of bf16_frontend2_kernel (thread 0 of every workgroup: start | image
 patch staged | stem done | level0 done | level1 stored; the SECOND tile of every persistent workgroup).
     python tools/front2_trace.py [B]"""
@@ -11,7 +11,7 @@ import torch
 
 sys.path.insert(0, ".")
 from m3dssd_amd import _hip                               # noqa: E402
-from m3dssd_amd.engine_bf16 import pack_frontend_bf16, pack_frontend_f16   # noqa: E402
+from m3dssd_amd.engine_bf16 import pack_frontend_f16   # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 H, W = 384, 1280
@@ -21,17 +21,9 @@ ws, w0, w1 = (torch.randn(16, 3, 7, 7, generator=g) / 12, torch.randn(16, 16, 3,
 aff = [(torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1) for c in (16, 16, 32)]
 img = torch.randn(B, 3, H, W, generator=g).to(dev)
 out = torch.empty(B, H // 2, W // 2, 32, device=dev, dtype=torch.bfloat16)
-p1 = pack_frontend_bf16(ws, w0, w1, dev)
-dv = [t.to(dev).contiguous() for pair in aff for t in pair]
 f2 = pack_frontend_f16(ws, aff[0], w0, aff[1], w1, aff[2], dev)
 mean3, stds3 = (ctypes.c_float * 3)(0.5, 0.5, 0.5), (ctypes.c_float * 3)(0.2, 0.2, 0.2)
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-
-def form1(L):
-    assert L.m3d_frontend_bf16_forward(img.data_ptr(), 0, 0, 0, mean3, stds3, p1[0].data_ptr(), dv[0].data_ptr(), dv[1].data_ptr(),
-                                       p1[1].data_ptr(), dv[2].data_ptr(), dv[3].data_ptr(), p1[2].data_ptr(), dv[4].data_ptr(),
-                                       dv[5].data_ptr(), out.data_ptr(), 32, B, H, W, st) == 0
 
 
 def form2(L):
@@ -53,8 +45,7 @@ def timeit(fn, L, reps=20):
 
 
 L = _hip.lib()
-print("B = %d, back to back: form 1 %.4f ms" % (B, timeit(form1, L)))
-print("  form 2 (persistent, 2 workgroups per CU): %.4f ms" % timeit(form2, L))
+print("B = %d, back to back (persistent, 2 workgroups per CU): %.4f ms" % (B, timeit(form2, L)))
 tp = "m3dssd_amd/csrc/build/libm3dssd_hip_trace.so"
 if os.path.exists(tp):
     T = ctypes.CDLL(tp)
