@@ -462,7 +462,7 @@ def test_fused_head2_saturates_fp16_hidden_activations_instead_of_going_nan():
     n, h, w, cout, G = 1, 8, 16, 36, 2
     M, HW = n * h * w, h * w
     x = _r(torch.randn(n, 128, h, w, generator=g))
-    x[:, :, :4] *= 3000.0                                       # upper half of the map: far out of the fp16 range after layer 1
+    x[:, :, :4] *= 30000.0                                      # upper half of the map: far out of the fp16 range after layer 1
     x = _r(x)
     xin = _nhwc16(x, 136)
     w1 = _r(torch.randn(G, 256, 128, generator=g) / 128 ** 0.5 * 4)

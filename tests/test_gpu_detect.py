@@ -557,7 +557,9 @@ def test_pipelined_detector_planar_and_bundled_forms_equal_detect_batch(planar, 
         d, c = detect_batch(net, x, conf)
         ref.append((d.clone(), c.clone()))
     pipe = PipelinedDetector(net, conf, 2, 128, 320, planar=planar)
-    assert pipe.planar is planar and (pipe.n_join < pipe.n_fwd) == planar
+    # planar: join in front of the first head; bundled: in front of anchor_select, which writes the sort keys detect(k-1) reads
+    first_key_write = pipe.plan.named["score_bits_first_write_op"]
+    assert pipe.planar is planar and pipe.n_join == (pipe.plan.named["planar_first_op"] if planar else first_key_write) < pipe.n_fwd
     got = []
     for x in xs:
         r = pipe.step(x)

@@ -5,8 +5,8 @@ timeout 1500 python -m pytest tests -m gpu -q -x > $O/${TAG}_tests.log 2>&1; ech
 timeout 1500 bash tools/gpu_profile.sh $TAG both all > $O/${TAG}_profile.log 2>&1
 timeout 600 python bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
 timeout 600 bash tools/pmc_counters.sh $TAG bf16 > $O/${TAG}_pmc_counters.log 2>&1
-timeout 300 python bench.py --dtype bf16 --steps 5 --no-cpu-baseline --no-configs2 --no-configs3 --no-feed --dump-layers $O/${TAG}_layers_bf16.csv > /dev/null 2>&1
-timeout 300 python bench.py --dtype f32 --steps 5 --no-cpu-baseline --no-configs2 --no-configs3 --no-feed --dump-layers $O/${TAG}_layers_f32.csv > /dev/null 2>&1
+timeout 300 python bench.py --dtype bf16 --steps 5 --no-cpu-baseline --no-configs2 --no-configs3 --no-feed --no-dropin --dump-layers $O/${TAG}_layers_bf16.csv > /dev/null 2>&1
+timeout 300 python bench.py --dtype f32 --steps 5 --no-cpu-baseline --no-configs2 --no-configs3 --no-feed --no-dropin --dump-layers $O/${TAG}_layers_f32.csv > /dev/null 2>&1
 for cfg in "bf16 64" "f32 8"; do set -- $cfg
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_trace_$1 -o t -- python $R/tools/graph_replay.py $1 $2 20 > /dev/null 2>&1)
   f=$(find $O/${TAG}_trace_$1 -name 't_kernel_trace.csv' | head -1)
