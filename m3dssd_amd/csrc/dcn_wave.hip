@@ -31,7 +31,6 @@ struct ConvWaveArgs {
     int kh, kw, stride, pad, dil;
     int M, KG, tiles_n;
     int act, res_mode, sigmoid_from;
-    int chunk_major;               // DEFORM: K loop order (1 = 32-channel chunks outer, taps inner; 0 = taps outer: A/B runs)
     int vec_out;                   // out / res / scale / shift views allow 16-byte accesses: epilogue through the LDS transpose
     long long w_img_stride;        // floats between the per-image weight sets (0: shared weights)
     unsigned in_bytes, out_bytes, res_bytes, w_bytes;
@@ -49,6 +48,8 @@ struct ConvWaveArgs {
 #ifdef CONV_TRACE
 static long long *g_conv_trace = nullptr;
 extern "C" void m3d_conv_wave_set_trace(void *buf) { g_conv_trace = (long long *)buf; }
+static int g_conv_variant = 0;
+extern "C" void m3d_conv_wave_set_variant(int v) { g_conv_variant = v; }
 #define TRACE_INIT() long long *trp = a.trace ? a.trace + (size_t)blockIdx.x * 128 : nullptr; int tri = 0
 #define TRACE() do { if (trp && lane == 0 && tri < 128) trp[tri++] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -57,8 +58,10 @@ extern "C" void m3d_conv_wave_set_trace(void *buf) { g_conv_trace = (long long *
 #endif
 
 // NT = column tiles of 32 output channels per wave: 4 (128 channels) or, for 64-channel layers, 2
-template <bool DEFORM, int NT>      // register bound: 3 waves per SIMD for the plain kernel, 2 for the deformable one (as its K loop needs)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFORM ? 2 : 3))) void conv_wave_kernel(const ConvWaveArgs a)
+// NCQ / WPE: experiment knobs (diagnostic library only, m3d_conv_wave_experiment): corners gathered per (pixel, tap) and the
+// register bound in waves per SIMD.  The product instantiates the defaults.
+template <bool DEFORM, int NT, int NCQ = 4, int WPE = (DEFORM ? 2 : 3)>      // register bound: 3 waves per SIMD for the plain kernel, 2 for the deformable one (as its K loop needs)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void conv_wave_kernel(const ConvWaveArgs a)
 {
     __shared__ __attribute__((aligned(16))) float tileA[32 * 32];     // [pixel][8 slots of 4 channels], swizzled
     // [tap][pixel][4 corner offsets (as bits), 4 weights]: DEFORM keeps the sampling state of all (<= 9) taps here, built once in
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFORM ? 2 :
         }
     };
 
-    constexpr int NC = DEFORM ? 4 : 1;
+    constexpr int NC = DEFORM ? NCQ : 1;
     f32x4 cr[4][NC];                           // gathered chunks of the step in flight: [pixel group][corner]
     f32x4 bfA[NT], bfB[NT];
     auto issue_gather = [&](int c32) {
@@ -212,8 +215,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFORM ? 2 :
     // step s of the K loop: plain = tap-major (s = tap * C32 + c32), DEFORM = chunk-major (s = c32 * KK + tap); the weights are
     // packed tap-major either way: k-group of a step = (tap * C32 + c32) * 4
     int tap, c32;
-    const bool cmaj = DEFORM && a.chunk_major;
-    if (cmaj) { c32 = ss0 / KK; tap = ss0 - c32 * KK; }
+    // K order of the deformable kernel: chunk-major, at COMPILE time.  As a runtime flag (round 3: an A/B switch) the two loop tails
+    // defined the 32 sampling registers (doff / bw) on different paths and the compiler shuttled them through a second register
+    // set at the join: 64 v_mov per step next to 64 MFMAs, each VALU instruction ~11 cycles of matrix-pipe delay
+    // (tools/ubench/mfma_side_cost) -- a sixth of the K loop (round 6, found in the ISA; profiles/r6c_dcn_wave_isa.txt).
+    constexpr bool cmaj = DEFORM;
+    if constexpr (cmaj) { c32 = ss0 / KK; tap = ss0 - c32 * KK; }
     else { tap = ss0 / C32; c32 = ss0 - tap * C32; }
     setup_tap(tap);
     issue_gather(c32);
@@ -237,14 +244,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEFORM ? 2 :
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 v;
-            if constexpr (DEFORM)
+            if constexpr (DEFORM && NCQ == 4)
                 v = pk_fma_s(bw[g][0], cr[g][0], pk_fma_s(bw[g][1], cr[g][1], pk_fma_s(bw[g][2], cr[g][2], pk_mul_s(bw[g][3], cr[g][3]))));
+            else if constexpr (DEFORM && NCQ == 2)      // (experiment: wrong results, timing only)
+                v = pk_fma_s(bw[g][0], cr[g][0], pk_mul_s(bw[g][1], cr[g][1]));
+            else if constexpr (DEFORM)
+                v = pk_mul_s(bw[g][0], cr[g][0]);
             else
                 v = cr[g][0];
             *reinterpret_cast<f32x4 *>(&tileA[wr_off[g]]) = v;
         }
         // ---- next step ----------------------------------------------------------------------------------------------------
-        if (cmaj) {
+        if constexpr (cmaj) {
             if (++tap == KK) { tap = 0; ++c32; }        // wave-uniform; past the last step: clamped, a redundant in-range reload
             setup_tap(tap);                              // 8 x ds_read_b128: the state of every tap was built in the prologue
             issue_gather(min(c32, C32 - 1));
@@ -495,8 +506,6 @@ extern "C" int m3d_conv_wave_forward(const m3d_conv_desc *d, m3d_stream_t stream
     const int cw = d->Cout_pad % 128 == 0 ? 128 : 64;
     a.M = (int)M; a.KG = d->kh * d->kw * d->Cin / 8; a.tiles_n = d->Cout_pad / cw;
     a.act = d->act; a.res_mode = d->res_mode; a.sigmoid_from = d->sigmoid_from; a.w_img_stride = d->wgt_img_stride;
-    static const int cmaj = []() { const char *e = getenv("M3D_DCN_CHUNK_MAJOR"); return e ? atoi(e) : 1; }();
-    a.chunk_major = cmaj;
     static int vec_epi = -1;       // M3D_WAVE_VEC_EPILOGUE=0: 4-byte stores straight from the accumulators (A/B)
     if (vec_epi < 0) { const char *e = getenv("M3D_WAVE_VEC_EPILOGUE"); vec_epi = e ? atoi(e) : 1; }
     a.vec_out = vec_epi && d->out_cs % 4 == 0 && ((uintptr_t)d->out & 15) == 0 &&
@@ -517,6 +526,22 @@ extern "C" int m3d_conv_wave_forward(const m3d_conv_desc *d, m3d_stream_t stream
                     d->splitk_ws_bytes);
         a.ws = d->splitk_ws; a.splits = splits; a.base_waves = waves / splits; a.ws_bytes = (unsigned)need;
     }
+#ifdef CONV_TRACE
+    // diagnostic library only (tools/conv_wave_third_wave.py): would a third wave per SIMD pay if the gathered
+    // corners (64 of the kernel's registers) lived elsewhere?  Variants gather fewer corners (WRONG results, timing only) at a
+    // register bound of two or three waves per SIMD.
+    if (g_conv_variant && d->dcn_offmask && cw == 128) {
+        switch (g_conv_variant) {
+        case 1: hipLaunchKernelGGL((conv_wave_kernel<true, 4, 1, 2>), dim3(waves), dim3(64), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((conv_wave_kernel<true, 4, 1, 3>), dim3(waves), dim3(64), 0, stream, a); break;
+        case 3: hipLaunchKernelGGL((conv_wave_kernel<true, 4, 2, 2>), dim3(waves), dim3(64), 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((conv_wave_kernel<true, 4, 2, 3>), dim3(waves), dim3(64), 0, stream, a); break;
+        default: hipLaunchKernelGGL((conv_wave_kernel<true, 4, 4, 3>), dim3(waves), dim3(64), 0, stream, a); break;   // 5: as built but bound to 3 waves (spills)
+        }
+        M3D_LAUNCH_CHECK();
+        return M3D_OK;
+    }
+#endif
     if (cw == 128) {
         if (d->dcn_offmask) hipLaunchKernelGGL((conv_wave_kernel<true, 4>), dim3(waves), dim3(64), 0, stream, a);
         else hipLaunchKernelGGL((conv_wave_kernel<false, 4>), dim3(waves), dim3(64), 0, stream, a);
