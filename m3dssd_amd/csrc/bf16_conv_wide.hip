@@ -154,30 +154,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
 
     const int NCH = a.Cin >> 5, NPOS = NCH * 18;
-    // Residual (HAS_RES): [buffer][pixel block][register group], 8 bytes each.  Channel block 0 (16 loads per lane) is fetched under
-    // the LAST chunk of the K loop -- the 48 patch registers are free there (no next chunk) -- so that the epilogue does not open
-    // with an exposed HBM round trip (~3 000 cycles of a wave that nothing covers: one wave per SIMD); blocks 1..3 follow in the
-    // epilogue, one ahead of the arithmetic, as before.  (Compiler-visible loads: its own wait in front of the first use in the
-    // epilogue counts only the loads it knows, which makes that wait conservative, never short.)
-    u32x2 rr[2][4][4];
-    const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res ? a.res : a.out, a.res ? a.res_bytes : 0u);
-    auto load_res = [&](int j, u32x2 (&r)[4][4]) __attribute__((always_inline)) {
-        // (the lane id is recomputed: derived from the kernel's `lane`, the index arithmetic was computed -- and spilled -- before
-        // the K loop) -- in asm, so that the copy made under the last chunk is not merged with the epilogue's (the shared value
-        // was kept alive across the loop tail and spilled: a scratch store inside the hand-counted vmcnt region)
-        int le;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(le));
-        const int l31r = le & 31, lhr = le >> 5;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned rp = (unsigned)((img * a.H + y0 + 2 * i + (l31r >> 4)) * a.W + x0 + (l31r & 15)) * (unsigned)a.res_cs * 2u;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c0 = n0 + j * 32 + 4 * lhr + 8 * g;
-                r[i][g] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rres, c0 < a.Cout ? rp + (unsigned)c0 * 2u : M3D_BUF_OOB, 0, 0));
-            }
-        }
-    };
     f32x16 acc[4][4];                                       // [channel block][pixel block]; the first position multiplies onto a zero
                                                             // operand (256 v_accvgpr_write cost 2 400 cycles in front of the first MFMA)
 
@@ -220,9 +196,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         cw_static_for<0, 18>([&](auto ptag) __attribute__((always_inline)) {
             constexpr int P = decltype(ptag)::value;
             constexpr int ahead = LAST ? (17 - P < 5 ? 17 - P : 5) : 5;
-            // behind position 0 go out: the 12 patch loads of the next chunk, or -- last chunk, residual -- the 16 residual loads of
-            // channel block 0; both are younger than the weights of positions 1..6
-            constexpr int young = 4 * ahead + ((P >= 1 && P <= 6) ? (!LAST ? 12 : (HAS_RES ? 16 : 0)) : 0);
+            constexpr int young = 4 * ahead + ((!LAST && P >= 1 && P <= 6) ? 12 : 0);
             cw_wait<young>(wf[P % CW_LA]);
             bf16x8 (&cur)[4] = (P & 1) ? pfb : pfa;
             bf16x8 (&nxt)[4] = (P & 1) ? pfa : pfb;
@@ -261,7 +235,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_sched_barrier(0);
             group(std::integral_constant<int, 3>{});
             if constexpr (!LAST && P == 0) load_patch(c + 1);
-            if constexpr (LAST && HAS_RES && P == 0) load_res(0, rr[0]);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (P == 0 || P == 6 || P == 7 || P == 12 || P == 17) CW_TRACE();
         });
@@ -285,7 +258,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int l31e = lane_e & 31, lhe = lane_e >> 5;
     {
         const float slope = a.act ? M3D_LEAKY_SLOPE : 1.f;
+        const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res ? a.res : a.out, a.res ? a.res_bytes : 0u);
         const bool rm1 = a.res_mode == 1;
+        unsigned rpix[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            rpix[i] = (unsigned)((img * a.H + y0 + 2 * i + (l31e >> 4)) * a.W + x0 + (l31e & 15)) * (unsigned)a.res_cs * 2u;
+        u32x2 rr[2][4][4];                                  // [buffer][pixel block][register group]
+        auto load_res = [&](int j, u32x2 (&r)[4][4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = n0 + j * 32 + 4 * lhe + 8 * g;
+                    r[i][g] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rres, c0 < a.Cout ? rpix[i] + (unsigned)c0 * 2u : M3D_BUF_OOB, 0, 0));
+                }
+        };
+        if constexpr (HAS_RES) load_res(0, rr[0]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if constexpr (HAS_RES) { if (j + 1 < 4) load_res(j + 1, rr[(j + 1) & 1]); }

@@ -349,22 +349,39 @@ __global__ void anab_pool_nested_finish_kernel(const float *__restrict__ fine, i
     const int bi = local / sz, bj = local - bi * sz, f = 16 / sz;      // f x f finest bins per bin of this scale
     const float inv = 1.f / (float)((H / sz) * (W / sz));
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        // f*f terms (256 for the whole-map bin): 8 independent partial sums keep 8 loads in flight instead of one dependent
-        // chain, then a fixed-order combine (deterministic)
-        float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // f*f terms (256 for the whole-map bin, 64 for the scale-4 bins): 32 independent partial sums = 32 loads in flight per thread
+        // (round 6; before: 8 -- the whole-map workgroup of every image walked 32 dependent round trips, ~50 us of a 74 us launch
+        // that moves 78 MB), then a fixed-order tree combine (deterministic)
+        float acc;
         const float *fp = fine + (((size_t)b * 256) * 4 + si) * C + c;
-        if (f >= 8) {                           // f = 8 or 16: rows of the fine grid in chunks of 8 independent loads
-            for (int di = 0; di < f; ++di)
-                for (int dj = 0; dj < f; dj += 8) {
-                    const float *q = fp + (size_t)((bi * f + di) * 16 + bj * f + dj) * 4 * C;
+        if (f == 16) {                          // the whole-map bin (f is 16, 4, 2 or 1): 8 rounds of 32 independent loads = 2 rows of the fine grid
+            float part[32];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) part[u] += q[(size_t)u * 4 * C];
-                }
-        } else {                                // f = 1, 2 or 4: at most 16 terms
-            for (int di = 0; di < f; ++di)
-                for (int dj = 0; dj < f; ++dj) part[dj] += fp[(size_t)((bi * f + di) * 16 + bj * f + dj) * 4 * C];
+            for (int u = 0; u < 32; ++u) part[u] = 0.f;
+            for (int di = 0; di < 16; di += 2) {
+#pragma unroll
+                for (int u = 0; u < 32; ++u) part[u] += fp[(size_t)((di + (u >> 4)) * 16 + (u & 15)) * 4 * C];
+            }
+#pragma unroll
+            for (int w = 16; w >= 1; w >>= 1)
+#pragma unroll
+                for (int u = 0; u < w; ++u) part[u] += part[u + w];
+            acc = part[0];
+        } else {                                // f = 1, 2 or 4: at most 16 terms, all in flight at once
+            float part[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) part[u] = 0.f;
+#pragma unroll
+            for (int di = 0; di < 4; ++di)
+#pragma unroll
+                for (int dj = 0; dj < 4; ++dj)
+                    if (di < f && dj < f) part[di * 4 + dj] = fp[(size_t)((bi * f + di) * 16 + bj * f + dj) * 4 * C];
+#pragma unroll
+            for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+                for (int u = 0; u < w; ++u) part[u] += part[u + w];
+            acc = part[0];
         }
-        float acc = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
         acc *= inv;
         if (c < Ck) {
             const size_t o = (frag & 1) ? (size_t)b * keys_pad * ck_pad + frag_index(bin, c, ck_pad) : ((size_t)b * keys_pad + bin) * ck_pad + c;
@@ -395,6 +412,9 @@ static int anab_pool_nested_launch(const T *kv, int kv_cs, const float *s, int s
     // (tried, round 5: 8 channels per thread + pixel lanes combined through LDS -- 16-byte loads instead of 2-byte ones -- measured
     // 0.1 ms SLOWER per bs-64 step: 37 channel groups x 6 pixel lanes leave a thread 5 dependent loads and the 33 KB of LDS four
     // workgroups per CU; this form keeps 256 x 5 independent loads in flight per workgroup)
+    // (tried, round 6: a compile-time 3 x 10 bin with all 30 loads of a thread issued up front -- 0.198 ms against 0.164 for pool +
+    // finish at bs 64: the pool kernel already moves 4.2 TB/s (88 us by rocprofv3); the finish kernel's dependent round trips were
+    // the slow half)
     hipLaunchKernelGGL(anab_pool_nested_kernel<T>, dim3(256, B), dim3(threads), 0, (hipStream_t)stream, kv, kv_cs, s, s_cs, scratch,
                        H, W, C);
     M3D_LAUNCH_CHECK();

@@ -370,6 +370,8 @@ class EngineBF16(Engine):
         variant = L.m3d_conv_bf16_variant(ref)          # which kernel the library runs for this descriptor
         if variant == 5:
             kind = "bf16_wide<128,128>"                           # 3x3 with 128-pixel x 128-channel wave tiles
+        elif variant == 6:
+            kind = "bf16_dcn1x1"                                  # 1x1 DCNv2 128 -> 128 (center_align; csrc/bf16_dcn1x1.hip)
         elif variant >= 3:
             kind = "bf16_dcn_patch<%d>" % (8 * (variant - 2))     # LDS-patch DCNv2 (+ the gated implicit-GEMM fallback behind it)
         elif variant:
@@ -527,7 +529,7 @@ class EngineBF16(Engine):
 
         # ---- DLAUp / IDAUp: offsets / masks stay fp32 (they address memory) ---------------------------
         def deform(p, x, out):
-            om = self._buf16(plan, B, x.h, x.w, 27, 32, dtype=torch.float32)
+            om = self._buf16(plan, B, x.h, x.w, 27, 32, name=p + ".om", dtype=torch.float32)
             self._pconv(plan, p + ".offset_mask", P[p + ".om"], x, om, 1, 1, act=0, sigmoid_from=18, out_mode=1)
             self._pconv(plan, p + ".dcn", P[p + ".dcn"], x, out, 1, 1, act=1, om=om)
             plan.named[p + ".out"] = out

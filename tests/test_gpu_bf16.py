@@ -675,6 +675,50 @@ def test_dcn_bf16_matches_oracle(shape):
     assert (got32 - ref).abs().max().item() < 1e-2 * scale
 
 
+@pytest.mark.parametrize("n,h,w,act,with_res", [(2, 16, 40, 0, True), (1, 9, 13, 1, False), (2, 48, 160, 0, True), (3, 8, 16, 1, True)])
+def test_dcn1x1_bf16_kernel_matches_oracle_and_the_generic_tile(n, h, w, act, with_res):
+    """csrc/bf16_dcn1x1.hip (center_align's op: 1x1 DCNv2 128 -> 128 + bias (+ input as residual), feturealign_mgpu.py:48-99) against
+    oracle/dcn.py on the bf16-rounded operands, and against the generic deformable tile (the fp32 output mode of the same
+    descriptor runs there; rounded to bf16 on the host): same corner rules (dcn_corners), same fp32 combine, same K order -- equal
+    up to ONE bf16 ulp at a handful of entries (the two epilogues contract  acc * scale + shift + res  differently).
+    Several tiles, a ragged single tile (117 pixels), the full-size map; offsets on the image border, far outside, NaN and inf."""
+    from oracle import dcn as odcn
+    g = torch.Generator().manual_seed(n * 100 + h)
+    c = co = 128
+    x = _r(torch.randn(n, c, h, w, generator=g) + 0.5)
+    wt = _r(torch.randn(co, c, 1, 1, generator=g) / c ** 0.5)
+    b = torch.randn(co, generator=g) * 0.1
+    off = torch.randn(n, 2, h, w, generator=g) * 2.5
+    off[0, :, 0, 0] = torch.tensor([-1.0, -1.0])               # exactly on the "contributes nothing" border
+    off[0, :, 0, 1] = torch.tensor([-0.5, float(w)])           # column far outside
+    off[0, :, 1, 0] = torch.tensor([float(h) - 1.0, 0.25])     # row H: outside
+    off[0, :, 1, 1] = torch.tensor([1e9, 0.0])
+    m = torch.rand(n, 1, h, w, generator=g)
+    ref = odcn.dcn_v2_forward(x, off, m, wt, b, 1, 0, 1, 1)
+    if with_res:
+        ref = ref + x
+    if act:
+        ref = F.leaky_relu(ref, 0.01)
+    off[0, :, 2, 2] = float("nan")                             # non-finite offsets: the sample contributes nothing (dcn_v2_im2col_cuda.cu:165)
+    off[0, 0, 2, 3] = float("inf")
+    for yy, xx in ((2, 2), (2, 3)):
+        r = b.view(-1) + (x[0, :, yy, xx] if with_res else 0.0)
+        ref[0, :, yy, xx] = F.leaky_relu(r, 0.01) if act else r
+    om = torch.cat([off, m, torch.zeros(n, 1, h, w)], 1).permute(0, 2, 3, 1).contiguous()
+    res = x if with_res else None
+    got = _run_conv(x, wt, b, None, 1, 0, act, res, 0, -1, 0, om, variant=6)
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item()
+    _log("dcn1x1_bf16", dict(shape=[n, h, w], err=err, scale=scale))
+    assert torch.isfinite(got).all() and err < 1e-2 * scale + 2.0 ** -8 * scale
+    gen32 = _run_conv(x, wt, b, None, 1, 0, act, res, 0, -1, 1, om, variant=0)          # fp32 NHWC output: the generic tile
+    gen = gen32.to(BF16).float()
+    diff = (got - gen).abs()
+    assert (diff <= 2.0 ** -7 * gen.abs() + 1e-30).all() and float((diff > 0).float().mean()) < 2e-3, (diff.max().item(), float((diff > 0).float().mean()))
+    again = _run_conv(x, wt, b, None, 1, 0, act, res, 0, -1, 0, om, variant=6)
+    assert torch.equal(got, again)
+
+
 def _dcn_case(shape, off_std, seed=0, clamp=None):
     n, c, h, w, co = shape
     g = torch.Generator().manual_seed(sum(shape) + seed)
