@@ -714,7 +714,7 @@ def test_dcn1x1_bf16_kernel_matches_oracle_and_the_generic_tile(n, h, w, act, wi
     gen32 = _run_conv(x, wt, b, None, 1, 0, act, res, 0, -1, 1, om, variant=0)          # fp32 NHWC output: the generic tile
     gen = gen32.to(BF16).float()
     diff = (got - gen).abs()
-    assert (diff <= 2.0 ** -7 * gen.abs() + 1e-30).all() and float((diff > 0).float().mean()) < 2e-3, (diff.max().item(), float((diff > 0).float().mean()))
+    assert (diff <= 2.0 ** -6 * gen.abs() + 1e-30).all() and float((diff > 0).float().mean()) < 2e-3, (diff.max().item(), float((diff > 0).float().mean()))
     again = _run_conv(x, wt, b, None, 1, 0, act, res, 0, -1, 0, om, variant=6)
     assert torch.equal(got, again)
 
@@ -1245,6 +1245,34 @@ def test_bf16_engine_alternative_paths_agree(monkeypatch):
             # decision -- top-1 anchor, hard mask -- moves a few entries by more than the rounding noise)
             assert float((d ** 2).mean().sqrt()) <= BF16_BBOX_RMS_TOL and float(torch.quantile(d.flatten()[:2000000], 0.999)) <= 2 * BF16_BBOX_P999_TOL \
                 and float(d.max()) <= BF16_BBOX_MAX_TOL, (fused, kv16, heads, front, heads2, front2, name, float(d.max()))
+
+
+def test_bf16_detections_scored_in_kitti_ap_units_against_the_fp32_detector():
+    """a statement about the bf16 path in the units BASELINE.json configs[4] is quoted in, without KITTI.  64 synthetic
+    1280x384 frames run through forward -> decode -> NMS -> 3-D refinement -> KITTI result text in fp32 and in bf16
+    (tools/bf16_ap_agreement.py); the fp32 rows (shifted by 1 mm: the reference's rotated IoU is 0 for many boxes against a
+    bit-identical copy, tests/test_kitti_eval.py) are the pseudo ground truth, `get_official_eval_result` (lib/eval/eval.py:638-747)
+    scores both.  fp32 against itself reads ~100 by construction.  Measured for bf16 (round 6, gpurun_out/parity_r06.jsonl
+    "bf16_ap_agreement"; moderate, AP_R40): Car image 85.8 / BEV 65.1 / 3-D 58.2, Pedestrian 77.1 / 57.7 / 48.9, Cyclist 84.6 / 81.9 /
+    58.5 at IoU 0.7 / 0.5 / 0.5 with 943 fp32 and 946 bf16 rows -- random-init weights, where 1.3-1.9 % of the pixels pick another
+    top-1 anchor in bf16 and every such flip moves a box by more than the IoU margin.  NOT AP3D parity (no dataset, no trained
+    weights); floors at ~0.75 x measured."""
+    from tools import bf16_ap_agreement as T
+    r = T.run(64, 8)
+    f, b = r["f32"], r["bf16"]
+    _log("bf16_ap_agreement", {"rows_f32": r["rows_f32"], "rows_bf16": r["rows_bf16"], "gt_per_class": r["gt_per_class"],
+                               "f32": {k: v for k, v in f.items() if "moderate_R40" in k},
+                               "bf16": {k: v for k, v in b.items() if "moderate_R40" in k}})
+    assert r["rows_f32"] > 500 and abs(r["rows_bf16"] - r["rows_f32"]) <= 0.03 * r["rows_f32"]
+    assert min(r["gt_per_class"].values()) >= 40
+    for k, v in f.items():                                   # the detector against its own (1 mm shifted) output
+        assert v >= 99.0, (k, v)
+    floors = {"Car_image_moderate_R40": 64.0, "Car_bev_moderate_R40": 48.0, "Car_3d_moderate_R40": 43.0,
+              "Pedestrian_image_moderate_R40": 57.0, "Pedestrian_bev_moderate_R40": 43.0, "Pedestrian_3d_moderate_R40": 36.0,
+              "Cyclist_image_moderate_R40": 63.0, "Cyclist_bev_moderate_R40": 61.0, "Cyclist_3d_moderate_R40": 43.0}
+    for k, lo in floors.items():
+        assert b[k] >= lo, (k, b[k], lo)
+        assert b[k] <= f[k] + 1e-6
 
 
 def test_bf16_batch64_full_size_properties():
