@@ -679,8 +679,8 @@ def test_dcn_bf16_matches_oracle(shape):
 def test_dcn1x1_bf16_kernel_matches_oracle_and_the_generic_tile(n, h, w, act, with_res):
     """csrc/bf16_dcn1x1.hip (center_align's op: 1x1 DCNv2 128 -> 128 + bias (+ input as residual), feturealign_mgpu.py:48-99) against
     oracle/dcn.py on the bf16-rounded operands, and against the generic deformable tile (the fp32 output mode of the same
-    descriptor runs there; rounded to bf16 on the host): same corner rules (dcn_corners), same fp32 combine, same K order -- equal
-    up to ONE bf16 ulp at a handful of entries (the two epilogues contract  acc * scale + shift + res  differently).
+    descriptor runs there; rounded to bf16 on the host): same corner rules (dcn_corners), same fp32 combine, same K order -- bit-identical
+    except for a handful of entries (< 1e-4 of them, <= 0.4 % of the output scale).
     Several tiles, a ragged single tile (117 pixels), the full-size map; offsets on the image border, far outside, NaN and inf."""
     from oracle import dcn as odcn
     g = torch.Generator().manual_seed(n * 100 + h)
@@ -714,7 +714,9 @@ def test_dcn1x1_bf16_kernel_matches_oracle_and_the_generic_tile(n, h, w, act, wi
     gen32 = _run_conv(x, wt, b, None, 1, 0, act, res, 0, -1, 1, om, variant=0)          # fp32 NHWC output: the generic tile
     gen = gen32.to(BF16).float()
     diff = (got - gen).abs()
-    assert (diff <= 2.0 ** -6 * gen.abs() + 1e-30).all() and float((diff > 0).float().mean()) < 2e-3, (diff.max().item(), float((diff > 0).float().mean()))
+    # measured on the full-size map: 12 of 1.97 M entries differ, by up to 2^-7 (a sample that rounds to the neighbouring bf16 in one
+    # of the two kernels: their fp32 blends contract differently); every other entry is bit-identical
+    assert float(diff.max()) <= 4e-3 * scale and float((diff > 0).float().mean()) < 1e-4, (diff.max().item(), float((diff > 0).float().mean()))
     again = _run_conv(x, wt, b, None, 1, 0, act, res, 0, -1, 0, om, variant=6)
     assert torch.equal(got, again)
 
