@@ -194,7 +194,8 @@ def kernel_symbol(label):
     if label.startswith("wino"):
         return "wino_kernel(WinoArgs)"
     if label.startswith("conv_wave"):
-        return "void conv_wave_kernel<%s, 4>(ConvWaveArgs)" % ("true" if "deform" in label else "false")   # (+ split-K reduce)
+        # (+ split-K reduce; template tail = corners gathered per tap, register bound in waves per SIMD: csrc/dcn_wave.hip)
+        return "void conv_wave_kernel<%s, 4, 4, %d>(ConvWaveArgs)" % (("true", 2) if "deform" in label else ("false", 3))
     if label.startswith("head_mlp"):
         layers, n3 = re.findall(r"\d+", label)[:2]
         return "void head_mlp_kernel<%s, %s>(MlpBatch)" % ("true" if layers == "3" else "false", n3)

@@ -42,8 +42,8 @@ def test_families_of_one_symbol_are_grouped_for_the_headline_roofline():
     sym = {}
     for k in labels:
         sym.setdefault(bench.kernel_symbol(k), []).append(k)
-    assert sym["void conv_wave_kernel<true, 4>(ConvWaveArgs)"] == labels[:3]
-    assert sym["void conv_wave_kernel<false, 4>(ConvWaveArgs)"] == [labels[3]]
+    assert sym["void conv_wave_kernel<true, 4, 4, 2>(ConvWaveArgs)"] == labels[:3]
+    assert sym["void conv_wave_kernel<false, 4, 4, 3>(ConvWaveArgs)"] == [labels[3]]
     assert len(sym["void head_mlp_kernel<true, 64>(MlpBatch)"]) == 1
     assert bench.kernel_symbol("wino44<16,16,kpair>") != bench.kernel_symbol("wino44<16,16>")
     for k in labels:                                         # every family maps to sources that exist in the library's record

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Would a third wave per SIMD pay for the fp32 deformable kernel?
 
-`conv_wave_kernel<true, 4>` (csrc/dcn_wave.hip) needs 246 registers: two waves per SIMD.  64 of them hold the 16 gathered corner
+`conv_wave_kernel<true, 4>` (csrc/dcn_wave.hip) needs 216 registers (246 before the K order became a compile-time constant): two waves per SIMD.  64 of them hold the 16 gathered corner
 chunks of the step in flight.  The review's proposal: move those to LDS so that three waves fit (<= 168 registers).  LDS cannot
 take them (16 KB per wave and step, 12 waves per CU), so before any redesign this experiment asks the question the proposal rests
 on: WITH the registers freed, is the kernel faster at three waves per SIMD than at two?
@@ -9,7 +9,7 @@ on: WITH the registers freed, is the kernel faster at three waves per SIMD than 
 The diagnostic library (`make -C m3dssd_amd/csrc trace`) carries variants of the kernel that gather 1 or 2 of the 4 corners per
 (pixel, tap) -- WRONG results, same prologue / K loop / MFMA stream / epilogue, 48 / 32 fewer registers -- each built with a
 register bound of two and of three waves per SIMD (`m3d_conv_wave_set_variant`):
-    0  as built (4 corners, 2 waves, 246 VGPRs)        5  as built, bound to 3 waves (168 VGPRs, 177 spilled)
+    0  as built (4 corners, 2 waves, 216 VGPRs)        5  as built, bound to 3 waves (168 VGPRs, 177 spilled)
     1  1 corner, 2 waves (172)                          2  1 corner, 3 waves (168, no spill)
     3  2 corners, 2 waves (186)                         4  2 corners, 3 waves (168, 18 spilled)
 Reading: (1 - 2) is what the third wave buys when registers are free; (0 - 1) is what the gather itself costs at two waves.
@@ -35,7 +35,7 @@ T.m3d_conv_wave_forward.argtypes = [ctypes.POINTER(_hip.ConvDesc), ctypes.c_void
 T.m3d_conv_wave_set_variant.argtypes = [ctypes.c_int]
 dev = torch.device("cuda:0")
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-NAMES = {0: "as built: 4 corners, 2 waves/SIMD (246 VGPR)", 1: "1 corner, 2 waves (172)", 2: "1 corner, 3 waves (168)",
+NAMES = {0: "as built: 4 corners, 2 waves/SIMD (216 VGPR)", 1: "1 corner, 2 waves (172)", 2: "1 corner, 3 waves (168)",
          3: "2 corners, 2 waves (186)", 4: "2 corners, 3 waves (168, 18 spilled)", 5: "4 corners, 3 waves (168, 177 spilled)"}
 
 
