@@ -171,8 +171,6 @@ def kernel_symbol(label):
         return "bf16_frontend_kernel(FrontArgs)"
     if label.startswith("bf16_dcn1x1"):
         return "bf16_dcn1x1_kernel(Bf16Args)"
-    if label.startswith("bf16_dcn_patchw"):
-        return "void bf16_dcn_patchw_kernel<8, 7, 3>(Bf16Args, void const*, unsigned int, unsigned int*)"
     if label.startswith("bf16_dcn_patch"):
         th = re.findall(r"\d+", label.split("<", 1)[1])[0]
         return "void bf16_dcn_patch_kernel<%s, %s>(Bf16Args, void const*, unsigned int const*)" % (th, "9, 3" if th == "16" else "6, 1")
@@ -791,7 +789,7 @@ def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=N
         for name, kind, flops, ms in eng.profile:
             if kind.startswith(MFMA_FAMILIES):
                 seq.append([kind, kernel_symbol(kind).split("(", 1)[0].split("<", 1)[0].replace("void ", "").strip()])
-                if kind.startswith("bf16_dcn_patch"):        # (incl. bf16_dcn_patchw) the gated implicit-GEMM fallback is launched right behind it
+                if kind.startswith("bf16_dcn_patch"):        # the gated implicit-GEMM fallback is launched right behind it
                     seq.append([kind + "/fallback", "bf16_conv_kernel"])
         json.dump(seq, open(args.dump_launches, "w"))
     per_kind = {}

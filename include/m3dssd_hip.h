@@ -233,11 +233,6 @@ typedef struct m3d_conv_bf16_desc {
      * [64 lanes][8] with lane = 32 * (k / 8) + (channel % 32) (m3dssd_amd/engine_bf16.py:PackedBf16.wave3x3) -- enable the
      * 128 x 128 wave-tile kernel on maps with H % 8 == 0, W % 16 == 0, Cin % 32 == 0, Cout_pad % 128 == 0, bf16 NHWC output. */
     const void *wgt_wave;
-    /* Deformable 3x3 / stride 1 / pad 1, optional (round 6): the fp16 weights in the SAME fragment order as wgt_wave (exact copy of
-     * the bf16 values).  With dcn_ws this selects the 8 x 16 LDS-patch kernel whose waves fetch their weight fragments straight from
-     * global memory (bf16_dcn_patchw_kernel: no weight staging, no per-tap barriers, window radius <= 7); H % 8 == 0, W % 16 == 0,
-     * Cin % 32 == 0, Cout_pad % 128 == 0.  Takes precedence over wgt_f16 (which may then be NULL). */
-    const void *wgt_f16_frag;
 } m3d_conv_bf16_desc;
 int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t stream);
 /* Which kernel m3d_conv_bf16_forward launches for `d` (profiling labels; no launch): 0 = implicit-GEMM tile
@@ -245,9 +240,8 @@ int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t stream);
  * 3 / 4 = deformable 3x3 with the sampling window in LDS, 8 x 16 / 16 x 16 pixel patches (bf16_dcn_patch_kernel; the
  * implicit-GEMM kernel is launched behind it and recomputes, on the device, the tiles whose offsets do not fit),
  * 5 = 3x3 with 128 x 128 wave tiles (bf16_conv3x3_wide_kernel; needs wgt_wave),
- * 6 = deformable 1x1, 128 -> 128 channels, bf16 NHWC output (bf16_dcn1x1_kernel: center_align, feturealign_mgpu.py:48-99),
- * 7 = deformable 3x3 on 8 x 16 patches with the weights fetched in fragment order (bf16_dcn_patchw_kernel; needs wgt_f16_frag). */
-/* Bytes of dcn_ws the LDS-patch DCNv2 kernels need for N x Ho x Wo output pixels (one flag word per 8 x 16 pixel tile; 0 = the map does not tile). */
+ * 6 = deformable 1x1, 128 -> 128 channels, bf16 NHWC output (bf16_dcn1x1_kernel: center_align, feturealign_mgpu.py:48-99). */
+/* Bytes of dcn_ws the LDS-patch DCNv2 kernel needs for N x Ho x Wo output pixels (one flag word per pixel tile; 0 = the map does not tile). */
 long long m3d_conv_bf16_dcn_ws_bytes(int N, int Ho, int Wo);
 int m3d_conv_bf16_variant(const m3d_conv_bf16_desc *d);
 

@@ -66,7 +66,6 @@ class ConvBf16Desc(ctypes.Structure):
         ("ss_group_off", c_int),
         ("wgt_f16", c_void_p), ("dcn_ws", c_void_p), ("dcn_ws_bytes", c_ll),
         ("wgt_wave", c_void_p),
-        ("wgt_f16_frag", c_void_p),
     ]
 
 

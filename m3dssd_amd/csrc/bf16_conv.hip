@@ -635,7 +635,7 @@ extern "C" int m3d_conv_bf16_variant(const m3d_conv_bf16_desc *d)
     if (d->dcn_offmask) {
         if (dcn1x1_applicable(d)) return 6;
         const int pv = dcn_patch_variant(d);
-        return pv == 7 ? 7 : (pv == 16 ? 4 : (pv == 8 ? 3 : 0));
+        return pv == 16 ? 4 : (pv == 8 ? 3 : 0);
     }
     if (conv_wide_applicable(d)) return 5;
     return conv_bf16_variant(d, nullptr);
@@ -715,8 +715,7 @@ extern "C" int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t s
         // residual does not alias the output -- an in-place residual would be added twice
         M3D_REQUIRE(d->res == nullptr || d->res != d->out, "m3d_conv_bf16_forward: the LDS-patch DCNv2 path needs res != out");
         if ((rc = launch_dcn_patch(a, d, pvar, st))) return rc;
-        const int gth = pvar == 7 ? 8 : pvar;                  // rows of a patch tile (7 = the 8-row kernel with the weights out of LDS)
-        a.gate = (const unsigned *)d->dcn_ws; a.gate_th = gth; a.gate_tpx = d->Wo / 16; a.gate_tpy = d->Ho / gth;
+        a.gate = (const unsigned *)d->dcn_ws; a.gate_th = pvar; a.gate_tpx = d->Wo / 16; a.gate_tpy = d->Ho / pvar;
     }
 #define LAUNCH(BN_, DF_) hipLaunchKernelGGL((bf16_conv_kernel<BN_, DF_>), grid, block, 0, st, a)
     if (bn == 128) { if (deform) LAUNCH(128, true); else LAUNCH(128, false); }

@@ -32,9 +32,6 @@
 
 #include "bf16_tile.h"
 
-#ifndef DPW_ABL
-#define DPW_ABL 0                        // diagnostic builds of bf16_dcn_patchw_kernel (see its compute_pos)
-#endif
 #ifndef DP_ABL
 #define DP_ABL 0                         // diagnostic builds: operand ablations of the K loop (timing only)
 #endif
@@ -369,261 +366,21 @@ void bf16_dcn_patch_kernel(const Bf16Args a, const void *__restrict__ wgt16, uns
     PTRACE();
 }
 
-// ------------------------------------------------------------------------------------------------------------------------------------
-// Round 6: the same tile with the WEIGHTS OUT OF LDS ("patchw").  What the ablations of round 5 said about the kernel above: the
-// sampling is a fifth of it, the rest is the workgroup-tile structure -- every tap's 128 x 32 weight tile staged global -> register
-// -> LDS -> register behind a barrier per tap (or per three taps).  Here a wave fetches its four A fragments of a (tap, K-step)
-// position straight from global memory in FRAGMENT order (the fp16 twin of PackedBf16.wave3x3(): 4 x 16 bytes per lane and
-// position, coalesced, the four waves of the workgroup and its neighbour on the CU hit the same lines in L1), LA positions ahead in
-// a ring of register sets.  No weight staging, no per-tap barriers: the waves of a workgroup meet only where the window of the
-// next 32-channel chunk replaces the current one (two barriers per chunk = per 18 positions).  The 16 KB of weight staging go to
-// the window: radius 7 instead of 6 at two workgroups per CU, which is what the 48x160 layers of the synthetic network need
-// (tools/dcn_radius_hist.py: 4-7 on every tile) -- one kernel for every 3x3 DCN layer whose map tiles 8 x 16.
-template <int I, int N, typename F>
-__device__ __forceinline__ void dp_static_for(F &&f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        dp_static_for<I + 1, N>(f);
-    }
-}
-
-template <int TH, int RMAX, int LA>
-__global__ __launch_bounds__(TH * 32) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void bf16_dcn_patchw_kernel(const Bf16Args a, const void *__restrict__ wfrag16, unsigned group_bytes, unsigned *__restrict__ flags)
-{
-    constexpr int TW = 16, BM = TH * TW, BN = 128, NT = TH * 32;
-    constexpr int PHMAX = TH + 3 + 2 * RMAX, PWMAX = TW + 3 + 2 * RMAX;
-    constexpr int HBYTES = PHMAX * PWMAX * DP_PS;
-    constexpr int HP = (PHMAX * PWMAX * 4 + NT - 1) / NT;        // 16-byte patch pieces per thread and chunk, at most
-    static_assert(BM * BN * 2 + 2 * BN * 4 <= HBYTES && 18 % LA == 0, "tile shape");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[HBYTES];
-    unsigned char *Hs = lds;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, lh = lane >> 5;
-
-    const int ntiles = a.tiles_m * a.tiles_n;
-    int tile = blockIdx.x;
-    {
-        const int q = ntiles >> 3, r = ntiles & 7, xcd = tile & 7, idx = tile >> 3;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tile_m = tile / a.tiles_n, tile_n = tile - tile_m * a.tiles_n;
-    const int n0 = tile_n * BN;
-    const int tpx = a.Wo / TW, tpy = (a.Ho + TH - 1) / TH;
-    const int img = tile_m / (tpx * tpy), trem = tile_m - img * tpx * tpy;
-    const int y0 = (trem / tpx) * TH, x0 = (trem % tpx) * TW;
-
-    int lpos;                                                   // lane -> pixel of the wave's 2 x 16 pixels (see the kernel above)
-    if (l31 < 4) lpos = l31;
-    else if (l31 < 12) lpos = 16 + (l31 - 4);
-    else if (l31 < 16) lpos = 4 + (l31 - 12);
-    else if (l31 < 20) lpos = 24 + (l31 - 16);
-    else if (l31 < 28) lpos = 8 + (l31 - 20);
-    else lpos = 28 + (l31 - 28);
-    const int p = wave * 32 + lpos, ty = p / TW, tx = p - ty * TW;
-    const int oy = y0 + ty, ox = x0 + tx;
-    const bool pvalid = oy < a.Ho && ox < a.Wo;
-    const int mpx = pvalid ? (img * a.Ho + oy) * a.Wo + ox : -1;
-    f32x4 omv[7];
-    {
-        const f32x4 *omp = reinterpret_cast<const f32x4 *>(a.om + (size_t)(pvalid ? mpx : 0) * a.om_cs);
-#pragma unroll
-        for (int q = 0; q < 7; ++q) omv[q] = omp[q];
-    }
-    float ssc = 1.f, ssh = 0.f;
-    if (tid < BN && n0 + tid < a.Cout) {
-        if (a.scale) ssc = a.scale[n0 + tid];
-        if (a.shift) ssh = a.shift[n0 + tid];
-    }
-    unsigned omx = 0u;
-    if (pvalid) {
-#pragma unroll
-        for (int q = 0; q < 18; ++q) omx = max(omx, __float_as_uint(omv[q >> 2][q & 3]) & 0x7fffffffu);
-    }
-    const int R = dcn_tile_radius(omx, reinterpret_cast<unsigned *>(lds), tid, NT);
-    if (tid == 0) flags[tile_m] = R > RMAX ? 1u : 0u;
-    if (R > RMAX) return;
-    __syncthreads();
-    const int PH = TH + 3 + 2 * R, PW = TW + 3 + 2 * R, PWB = PW * DP_PS;
-    const int py0 = y0 - 1 - R, px0 = x0 - 1 - R;
-
-    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
-    const __amdgpu_buffer_rsrc_t rwf = make_rsrc((const char *)wfrag16 + (size_t)tile_n * group_bytes, group_bytes);
-
-    int soff[9];
-    unsigned swa[9], swb[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const float dh = omv[(2 * t) >> 2][(2 * t) & 3], dw = omv[(2 * t + 1) >> 2][(2 * t + 1) & 3];
-        const float mk = pvalid ? omv[(18 + t) >> 2][(18 + t) & 3] : 0.f;
-        const float h_im = (float)(oy - 1 + t / 3) + dh, w_im = (float)(ox - 1 + t % 3) + dw;
-        const float hf = floorf(h_im), wf = floorf(w_im);
-        const float lhh = h_im - hf, lww = w_im - wf, uh = 1.f - lhh, uw = 1.f - lww;
-        const int r = min(max((int)hf - py0, 0), PH - 2), cc = min(max((int)wf - px0, 0), PW - 2);
-        soff[t] = (r * PW + cc) * DP_PS + lh * 16;
-        const f32x2 wa = {uh * uw * mk, uh * lww * mk}, wb = {lhh * uw * mk, lhh * lww * mk};
-        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-        swa[t] = __builtin_bit_cast(unsigned, __builtin_convertvector(wa, f16x2));
-        swb[t] = __builtin_bit_cast(unsigned, __builtin_convertvector(wb, f16x2));
-    }
-
-    const int npieces = PH * PW * 4;
-    const int piece = tid & 3, pix0 = tid >> 2;
-    const int hy0 = pix0 / PW, hx0 = pix0 - hy0 * PW;
-    const int dq = (NT / 4) / PW, dr = (NT / 4) - dq * PW;
-    const int hdst0 = pix0 * DP_PS + piece * 16;
-    u32x4 rh[HP];
-    const int NC = a.Cin >> 5, NPOS = NC * 18;
-
-    auto load_patch = [&](int c) __attribute__((always_inline)) {
-        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(c) * 64u;
-        int hy = hy0, hx = hx0;
-#pragma unroll
-        for (int i = 0; i < HP; ++i) {
-            const int y = py0 + hy, x = px0 + hx;
-            const bool ok = tid + NT * i < npieces && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-            const unsigned off = ok ? ((unsigned)((img * a.H + y) * a.W + x) * (unsigned)a.in_cs + (unsigned)piece * 8u) * 2u : M3D_BUF_OOB;
-            rh[i] = buf_load_u32x4(rin, off, so);
-            hx += dr; hy += dq;
-            if (hx >= PW) { hx -= PW; ++hy; }
-        }
-    };
-    auto store_patch = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < HP; ++i)
-            if (tid + NT * i < npieces) {
-                u32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned d = rh[i][e];
-                    v[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(d << 16), __uint_as_float(d & 0xffff0000u)));
-                }
-                *reinterpret_cast<u32x4 *>(Hs + hdst0 + i * (NT / 4) * DP_PS) = v;
-            }
-    };
-    // weight fragments: [group][chunk][tap][K-step][channel block][lane][8 fp16] = 4 KB per position; a position past the last is
-    // clamped (a redundant in-range load: the number of loads in flight does not depend on the position)
-    const unsigned wlane = (unsigned)lane * 16u;
-    u32x4 wf[LA][4];
-    auto load_w = [&](int pos, auto slot_tag) __attribute__((always_inline)) {
-        constexpr int SL = decltype(slot_tag)::value;
-        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(min(pos, NPOS - 1)) * 4096u;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wf[SL][j] = buf_load_u32x4(rwf, wlane + (unsigned)j * 1024u, so);
-    };
-
-    f32x16 acc[4][1];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][0][r] = 0.f;
-
-    // one position = (tap u, K-step s): 4 corner reads, 16 packed fp16 multiply-adds, 4 MFMAs
-    auto compute_pos = [&](auto ptag) __attribute__((always_inline)) {
-        constexpr int P = decltype(ptag)::value, u = P >> 1, s = P & 1, SL = P % LA;
-        const unsigned char *P0 = Hs + soff[u] + s * 32, *P1 = P0 + PWB;
-        // DPW_ABL (diagnostic builds, timing only, wrong results; tools/bf16_dcn_patchw_ablate.sh): 1 = weights fetched once, 2 = no
-        // sampling at all (one corner read is the fragment), 4 = the window is never replaced, 8 = one corner read feeds the whole
-        // combine, 16 = one combine per TAP (the second K-step re-uses the first one's fragment)
-        const u32x4 c00 = *reinterpret_cast<const u32x4 *>(P0);
-#if DPW_ABL & (2 | 8)
-        const u32x4 c01 = c00, c10 = c00, c11 = c00;
-        (void)P1;
-#else
-        const u32x4 c01 = *reinterpret_cast<const u32x4 *>(P0 + DP_PS);
-        const u32x4 c10 = *reinterpret_cast<const u32x4 *>(P1), c11 = *reinterpret_cast<const u32x4 *>(P1 + DP_PS);
-#endif
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        const h2 w2a = __builtin_bit_cast(h2, swa[u]), w2b = __builtin_bit_cast(h2, swb[u]);
-        const h2 w00 = __builtin_shufflevector(w2a, w2a, 0, 0), w01 = __builtin_shufflevector(w2a, w2a, 1, 1);
-        const h2 w10 = __builtin_shufflevector(w2b, w2b, 0, 0), w11 = __builtin_shufflevector(w2b, w2b, 1, 1);
-        u32x4 fb;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            // (named temporaries: __builtin_bit_cast applied to a vector-element EXPRESSION reads element 0 with this compiler)
-            const unsigned d00 = c00[e], d01 = c01[e], d10 = c10[e], d11 = c11[e];
-            h2 r = __builtin_bit_cast(h2, d00) * w00;
-            r = __builtin_elementwise_fma(__builtin_bit_cast(h2, d01), w01, r);
-            r = __builtin_elementwise_fma(__builtin_bit_cast(h2, d10), w10, r);
-            r = __builtin_elementwise_fma(__builtin_bit_cast(h2, d11), w11, r);
-            fb[e] = __builtin_bit_cast(unsigned, r);
-#if DPW_ABL & 2
-            fb[e] = d00;
-#endif
-        }
-        const f16x8 fp = __builtin_bit_cast(f16x8, fb);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[SL][j]), fp, acc[j][0], 0, 0, 0);
-    };
-
-    load_patch(0);
-    dp_static_for<0, LA>([&](auto st) __attribute__((always_inline)) { load_w(decltype(st)::value, st); });
-    __syncthreads();                                            // (the radius reduction used the start of the LDS)
-    store_patch();
-    __syncthreads();
-    for (int c = 0; c < NC; ++c) {
-        const int pos0 = c * 18;
-        dp_static_for<0, 18>([&](auto ptag) __attribute__((always_inline)) {
-            constexpr int P = decltype(ptag)::value;
-#if !(DPW_ABL & 4)
-            if constexpr (P == 8) { if (c + 1 < NC) load_patch(c + 1); }      // the next chunk's window travels under the second half of this one
-#endif
-            compute_pos(ptag);
-#if !(DPW_ABL & 1)
-            load_w(pos0 + P + LA, std::integral_constant<int, P % LA>{});
-#endif
-        });
-#if DPW_ABL & 4
-        if (false) {
-#else
-        if (c + 1 < NC) {
-#endif
-            __syncthreads();                                    // every wave is done reading the window
-            store_patch();
-            __syncthreads();
-        }
-    }
-    __syncthreads();                                            // the window becomes the output tile
-
-    int mpix[1] = {mpx}, lrow[1] = {p};
-    float *ssl = reinterpret_cast<float *>(lds + sizeof(lds) - 2 * BN * 4);
-    if (tid < BN) { ssl[tid] = ssc; ssl[BN + tid] = ssh; }
-    __syncthreads();
-    if (a.out_mode == 0) {
-        if (a.sigmoid_from < 0) conv_epilogue_fast<4, 1>(a, acc, mpix, lrow, n0, 0, lh, ssl, BN, lds);
-        else conv_epilogue<4, 1>(a, acc, mpix, n0, 0, lh, 0, ssl, BN, lds, lrow);
-        __syncthreads();
-        store_otile<BN, BM, NT>(a, lds, n0, 0, tid, [&](int row) {
-            const int y = y0 + row / TW, x = x0 + row % TW;
-            return (y < a.Ho && x < a.Wo) ? (img * a.Ho + y) * a.Wo + x : -1;
-        });
-    } else {
-        conv_epilogue<4, 1>(a, acc, mpix, n0, 0, lh, 0, ssl, BN);
-    }
-}
-
 // Which patch kernel serves a descriptor: 0 = none (the implicit-GEMM kernel only), 16 / 8 = rows of the pixel patch.
 int dcn_patch_variant(const m3d_conv_bf16_desc *d)
 {
-    static int on = -1, onw = -1;         // M3D_BF16_DCN_PATCH=0: implicit-GEMM kernel everywhere (A/B); M3D_BF16_DCN_PATCHW=0: round 5's patch kernels
+    static int on = -1;                   // M3D_BF16_DCN_PATCH=0: implicit-GEMM kernel everywhere (A/B)
     if (on < 0) { const char *e = getenv("M3D_BF16_DCN_PATCH"); on = e ? atoi(e) : 1; }
-    if (onw < 0) { const char *e = getenv("M3D_BF16_DCN_PATCHW"); onw = e ? atoi(e) : 1; }
-    if (!on || !d->dcn_offmask || !d->dcn_ws) return 0;
+    if (!on || !d->dcn_offmask || !d->wgt_f16 || !d->dcn_ws) return 0;
     if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->groups != 1 || d->wgt_img_stride != 0) return 0;
     if (d->Cin % 32 != 0 || d->Cout_pad % 128 != 0 || d->W % 16 != 0 || d->dcn_om_cs < 28 || d->dcn_om_cs % 4 != 0) return 0;
-    if (onw && d->wgt_f16_frag && d->H % 8 == 0 && d->dcn_ws_bytes >= dcn_patch_ws_bytes(d, 8)) return 7;     // weights out of LDS (round 6)
-    if (!d->wgt_f16) return 0;
     const int v = d->H % 16 == 0 ? 16 : d->H % 8 == 0 ? 8 : 0;
     return (v && d->dcn_ws_bytes >= dcn_patch_ws_bytes(d, v)) ? v : 0;      // (one flag word per pixel tile: m3d_conv_bf16_dcn_ws_bytes)
 }
 
 long long dcn_patch_ws_bytes(const m3d_conv_bf16_desc *d, int variant)
 {
-    const int th = variant == 7 ? 8 : variant;
-    return th ? 4ll * d->N * (d->Ho / th) * (d->Wo / 16) : 0;
+    return variant ? 4ll * d->N * (d->Ho / variant) * (d->Wo / 16) : 0;
 }
 
 int launch_dcn_patch(const Bf16Args &a0, const m3d_conv_bf16_desc *d, int variant, hipStream_t st)
@@ -631,12 +388,7 @@ int launch_dcn_patch(const Bf16Args &a0, const m3d_conv_bf16_desc *d, int varian
     Bf16Args a = a0;
     a.tiles_n = d->Cout_pad / 128;
     unsigned *bound = (unsigned *)d->dcn_ws;                      // one flag per pixel tile
-    if (variant == 7) {
-        a.tiles_m = d->N * (d->Ho / 8) * (d->Wo / 16);
-        const long long gb = (long long)(d->Cin / 32) * 18 * 4096;
-        M3D_REQUIRE(gb < (1ll << 31), "conv_bf16 (dcn patchw): weight group too large");
-        hipLaunchKernelGGL((bf16_dcn_patchw_kernel<8, 7, 3>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, st, a, d->wgt_f16_frag, (unsigned)gb, bound);
-    } else if (variant == 16) {
+    if (variant == 16) {
         a.tiles_m = d->N * (d->Ho / 16) * (d->Wo / 16);
         hipLaunchKernelGGL((bf16_dcn_patch_kernel<16, 9, 3>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, st, a, d->wgt_f16, bound);
     } else {
@@ -649,7 +401,6 @@ int launch_dcn_patch(const Bf16Args &a0, const m3d_conv_bf16_desc *d, int varian
 
 extern "C" long long m3d_conv_bf16_dcn_ws_bytes(int N, int Ho, int Wo)
 {
-    // sized for the finest tiling any patch kernel uses (8 x 16 pixels): the 16-row kernel needs half of it
-    const int v = Ho % 8 == 0 ? 8 : 0;
+    const int v = Ho % 16 == 0 ? 16 : Ho % 8 == 0 ? 8 : 0;
     return (v && Wo % 16 == 0) ? 4ll * N * (Ho / v) * (Wo / 16) : 0;
 }

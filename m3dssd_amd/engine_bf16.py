@@ -189,14 +189,6 @@ class PackedBf16:
                 self._wp16 = w.to(torch.float16).contiguous()
         return self._wp16 if self._wp16 is not False else None
 
-    def wave3x3_f16(self):
-        """wave3x3() as fp16 (exact copy of the bf16 values inside the fp16 range; None outside it or where wave3x3() does not apply):
-        the weight operand of bf16_dcn_patchw_kernel (csrc/bf16_dcn_patch.hip)."""
-        if getattr(self, "_wave16", None) is None:
-            w = self.wave3x3() if self.f16() is not None else None
-            self._wave16 = False if w is None else w.to(torch.float16).contiguous()
-        return self._wave16 if self._wave16 is not False else None
-
     def wave3x3(self):
         """The 3x3 weights in the fragment order of csrc/bf16_conv_wide.hip: [Cout_pad/128][Cin/32][9 taps][2 K-steps of 16][4 blocks of
         32 channels][64 lanes][8], lane = 32 * ((c % 16) / 8) + (channel % 32); None where the kernel does not apply."""
@@ -334,7 +326,7 @@ class EngineBF16(Engine):
 
     def _conv16(self, plan, name, x, out=None, wgt=None, kpad=None, cout=None, cout_pad=None, kh=1, kw=1, stride=1, pad=0,
                 scale=None, shift=None, act=0, res=None, res_mode=0, sigmoid_from=-1, om=None, out_mode=0, planar=None,
-                wgt_img_stride=0, groups=1, in_goff=0, wgt_goff=0, out_goff=0, ss_goff=0, cin=None, flops_cin=None, wgt_f16=None, wgt_wave=None, wgt_f16_frag=None):
+                wgt_img_stride=0, groups=1, in_goff=0, wgt_goff=0, out_goff=0, ss_goff=0, cin=None, flops_cin=None, wgt_f16=None, wgt_wave=None):
         """One m3d_conv_bf16_forward launch appended to the plan.  x: View16 (bf16); out: View16 (bf16 or fp32 NHWC) or
         planar = (tensor, img_stride, channel offset) for the fp32 planar staging of the head outputs."""
         d = ConvBf16Desc()
@@ -367,9 +359,6 @@ class EngineBF16(Engine):
                 ws = torch.zeros(max(256, self.L.m3d_conv_bf16_dcn_ws_bytes(x.n, out.h, out.w) // 4), device=self.device, dtype=torch.int32)
                 plan.keep += [wgt_f16, ws]
                 d.wgt_f16, d.dcn_ws, d.dcn_ws_bytes = wgt_f16.data_ptr(), ws.data_ptr(), ws.numel() * 4
-                if wgt_f16_frag is not None:        # round 6: the same weights in fragment order -> the patch kernel that keeps them out of LDS
-                    plan.keep.append(wgt_f16_frag)
-                    d.wgt_f16_frag = wgt_f16_frag.data_ptr()
         elif wgt_wave is not None:
             plan.keep.append(wgt_wave)       # 128 x 128 wave-tile kernel (csrc/bf16_conv_wide.hip) where the library finds it applicable
             d.wgt_wave = wgt_wave.data_ptr()
@@ -383,8 +372,6 @@ class EngineBF16(Engine):
             kind = "bf16_wide<128,128>"                           # 3x3 with 128-pixel x 128-channel wave tiles
         elif variant == 6:
             kind = "bf16_dcn1x1"                                  # 1x1 DCNv2 128 -> 128 (center_align; csrc/bf16_dcn1x1.hip)
-        elif variant == 7:
-            kind = "bf16_dcn_patchw<8>"                           # LDS-patch DCNv2, weights out of LDS (+ the gated fallback behind it)
         elif variant >= 3:
             kind = "bf16_dcn_patch<%d>" % (8 * (variant - 2))     # LDS-patch DCNv2 (+ the gated implicit-GEMM fallback behind it)
         elif variant:
@@ -400,7 +387,6 @@ class EngineBF16(Engine):
                      shift=pc.shift if (affine and pc.has_affine) else None, act=act, res=res, res_mode=res_mode,
                      sigmoid_from=sigmoid_from, om=om, out_mode=out_mode, cin=pc.cin,
                      wgt_f16=pc.f16() if (om is not None and patch) else None,
-                     wgt_f16_frag=pc.wave3x3_f16() if (om is not None and patch and stride == 1 and pad == 1) else None,
                      wgt_wave=pc.wave3x3() if (USE_WIDE and om is None and stride == 1 and pad == 1 and out_mode == 0
                                                and sigmoid_from < 0 and x.c == pc.cin) else None)
 

@@ -81,7 +81,7 @@ def _nhwc16(x, cs=None):
 
 
 def _run_conv(x, wt, bias=None, bn=None, stride=1, pad=0, act=0, res=None, res_mode=0, sigmoid_from=-1, out_mode=0, om=None,
-              in_cs=None, variant=None, patch=False, wide=False, alias_res_out=False, patchw=False):
+              in_cs=None, variant=None, patch=False, wide=False, alias_res_out=False):
     """Through the C ABI.  Returns [N, Cout, Ho, Wo] fp32 (bf16 outputs widened).  alias_res_out: res = out (in-place residual);
     returns the call's status code and error text instead."""
     from m3dssd_amd import _hip
@@ -128,11 +128,6 @@ def _run_conv(x, wt, bias=None, bn=None, stride=1, pad=0, act=0, res=None, res_m
             w16, ws = wp.float().to(torch.float16).contiguous(), torch.full((nws,), 7, device=dev, dtype=torch.int32)
             d.wgt_f16, d.dcn_ws, d.dcn_ws_bytes = w16.data_ptr(), ws.data_ptr(), 4 * nws
             keep += [w16, ws]
-            if patchw:      # the same weights as fp16 in the wave-tile fragment order: the patch kernel that keeps them out of LDS
-                cop = wp.shape[0]
-                wfr = wp[:, :9 * c].reshape(cop // 128, 4, 32, 9, c // 32, 2, 2, 8).permute(0, 4, 3, 5, 1, 6, 2, 7).float().to(torch.float16).contiguous()
-                d.wgt_f16_frag = wfr.data_ptr()
-                keep.append(wfr)
     if out_mode == 0:
         ocs = (co + 7) // 8 * 8 + 8
         out = torch.full((n, ho, wo, ocs), 512.0, device=dev, dtype=BF16)
@@ -821,89 +816,6 @@ def test_dcn_bf16_patch_kernel_hands_over_when_the_window_does_not_fit():
     base3 = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 1, om3, variant=0)
     assert not torch.equal(got3, base3)
     assert (got3 - ref3).abs().max().item() < 1e-2 * ref3.abs().max().item()
-
-
-@pytest.mark.parametrize("shape,off_std,clamp", [
-    ((2, 128, 16, 32, 128), 1.5, None),           # offsets up to ~6: radius 7 windows
-    ((1, 128, 48, 160, 128), 2.0, 6.9),           # the full-size backbone map at the largest radius the kernel takes (7)
-    ((2, 256, 24, 80, 256), 1.2, 5.9),            # 24x80, two channel tiles, 8 chunks
-    ((3, 64, 8, 16, 128), 0.3, None),             # one patch per image: every window crosses all four image borders
-    ((1, 32, 16, 16, 100), 1.0, None),            # ragged Cout (pad 128), ONE chunk (no window swap)
-])
-def test_dcn_bf16_patchw_kernel_matches_oracle(shape, off_std, clamp):
-    """Round 6's form of the LDS-patch DCNv2 kernel (bf16_dcn_patchw_kernel: weight fragments global -> register in fragment order,
-    no weight staging, no per-tap barriers, radius <= 7) against oracle/dcn.py on the bf16-rounded operands, against the kernel it
-    replaces (same fp16 window arithmetic: bit-identical where both run the tile) and run to run."""
-    from oracle import dcn as odcn
-    x, wt, b, off, m, om = _dcn_case(shape, off_std, 1, clamp)
-    ref = odcn.dcn_v2_forward(x, off, m, wt, b, 1, 1, 1, 1)
-    scale = ref.abs().max().item()
-    got32 = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 1, om, variant=7, patch=True, patchw=True)
-    err = (got32 - ref).abs().max().item()
-    _log("dcn_bf16_patchw", dict(shape=list(shape), err=err, scale=scale))
-    assert err < 1e-2 * scale
-    again = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 1, om, variant=7, patch=True, patchw=True)
-    assert torch.equal(got32, again)
-    if shape[2] % 16 == 0 or float(off.abs().max()) <= 6.0:      # the round-5 kernel takes the same tiles: same arithmetic, same K order
-        old32 = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 1, om, patch=True)
-        assert torch.equal(got32, old32)
-    # bf16 output with BatchNorm + LeakyReLU + residual epilogue
-    g = torch.Generator().manual_seed(3)
-    co = shape[4]
-    bn = (torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.1, torch.randn(co, generator=g) * 0.1, torch.rand(co, generator=g) + 0.5)
-    res = _r(torch.randn(shape[0], co, shape[2], shape[3], generator=g))
-    sc = bn[0] / torch.sqrt(bn[3] + 1e-5)
-    ref2 = F.leaky_relu((ref - bn[2].view(1, -1, 1, 1)) * sc.view(1, -1, 1, 1) + bn[1].view(1, -1, 1, 1) + res, 0.01)
-    got2 = _run_conv(x, wt, b, bn, 1, 1, 1, res, 0, -1, 0, om, variant=7, patch=True, patchw=True)
-    s2 = ref2.abs().max().item()
-    assert (got2 - ref2).abs().max().item() < 1e-2 * s2 + 2.0 ** -8 * s2
-
-
-def test_dcn_bf16_patchw_kernel_hands_over_and_border_positions():
-    """Per-tile decision of the round-6 kernel: a tile whose largest |offset| needs a radius beyond 7 (or holds a NaN) raises its flag
-    and the implicit-GEMM kernel behind it recomputes the 128-pixel tiles that touch it -- bit-identical to a launch without the patch
-    kernel there, the patch kernel's bits elsewhere; exactly at the radius it still fits.  Then the border grid of
-    test_dcn_bf16_patch_kernel_border_positions through this kernel's zero-padded window."""
-    from oracle import dcn as odcn
-    shape = (2, 64, 16, 32, 128)
-    x, wt, b, off, m, om = _dcn_case(shape, 1.0, 2, 4.0)
-    base = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 0, om, variant=0)
-    fit = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 0, om, variant=7, patch=True, patchw=True)
-    assert not torch.equal(fit, base)
-    for bad in (7.25, -37.0, float("nan")):
-        om2 = om.clone()
-        om2[1, 7, 9, 5] = bad                                   # image 1, patch tile (rows 0-7, columns 0-15)
-        base2 = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 0, om2, variant=0)
-        got2 = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 0, om2, variant=7, patch=True, patchw=True)
-        # 128-pixel tiles of the fallback = 4 rows of 32: rows 0-7 of image 1 touch the flagged patch tile
-        assert torch.equal(got2[1, :, 0:8], base2[1, :, 0:8]), bad
-        assert torch.equal(got2[1, :, 8:16], fit[1, :, 8:16]) and torch.equal(got2[0], fit[0]), bad
-    om3 = om.clone()
-    om3[0, 3, 4, 0] = 7.0                                       # exactly at the radius
-    off3 = om3[..., :18].permute(0, 3, 1, 2).contiguous()
-    ref3 = odcn.dcn_v2_forward(x, off3, m, wt, b, 1, 1, 1, 1)
-    got3 = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 1, om3, variant=7, patch=True, patchw=True)
-    base3 = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 1, om3, variant=0)
-    assert not torch.equal(got3[0, :, 0:8, 0:16], base3[0, :, 0:8, 0:16])
-    assert (got3 - ref3).abs().max().item() < 1e-2 * ref3.abs().max().item()
-    # border grid
-    h, w, c, co = 16, 32, 32, 128
-    g = torch.Generator().manual_seed(9)
-    x = _r(torch.randn(1, c, h, w, generator=g) + 3.0)
-    wt = _r(torch.randn(co, c, 3, 3, generator=g) / (9 * c) ** 0.5)
-    b = torch.zeros(co)
-    off = torch.zeros(1, 18, h, w)
-    m = torch.zeros(1, 9, h, w)
-    off[:, 8:10] = _border_grid_offsets(h, w)
-    m[:, 4] = 1.0
-    keep = (off.abs() <= 6.9).all(1, keepdim=True)
-    off, m = off * keep, m * keep
-    ref = odcn.dcn_v2_forward(x, off, m, wt, b, 1, 1, 1, 1)
-    om = torch.cat([off, m, torch.zeros(1, 5, h, w)], 1).permute(0, 2, 3, 1).contiguous()
-    got = _run_conv(x, wt, b, None, 1, 1, 0, None, 0, -1, 1, om, variant=7, patch=True, patchw=True)
-    assert (got - ref).abs().max().item() < 1e-2 * ref.abs().max().item()
-    zero_rows = ref.abs().amax(dim=(0, 1, 3)) == 0
-    assert zero_rows.any() and torch.equal(got[0, :, zero_rows, :], torch.zeros_like(got[0, :, zero_rows, :]))
 
 
 def test_dcn_bf16_patch_kernel_border_positions():

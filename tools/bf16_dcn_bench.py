@@ -1,6 +1,6 @@
 """Single-layer timing of the bf16 DCNv2 3x3 kernels at bs 64: the LDS-patch kernel (csrc/bf16_dcn_patch.hip, incl. its |offset|
 pre-pass and the gated fallback launch) against the implicit-GEMM kernel, for several offset magnitudes.
-    python tools/bf16_dcn_bench.py [--patchw] [offset_std ...]      (--patchw: round 6's kernel with the weights out of LDS)
+    python tools/bf16_dcn_bench.py [offset_std ...]
 Offsets are N(0, std) clamped to +-clamp (the window radius of the launch = ceil(max |offset|))."""
 import ctypes
 import sys
@@ -14,16 +14,14 @@ from m3dssd_amd.engine_bf16 import pack_conv_bf16          # noqa: E402
 dev = torch.device("cuda:0")
 L = _hip.lib()
 SHAPES = [(128, 128, 48, 160, 64), (256, 128, 24, 80, 64), (256, 256, 24, 80, 64)]
-PATCHW = "--patchw" in sys.argv
-ARGS = [a for a in sys.argv[1:] if a != "--patchw"]
-CASES = [(0.25, 0.9), (1.0, 2.9), (1.5, 4.9), (2.0, 6.9), (3.0, 8.9)] if not ARGS else [(float(s), float(s) * 3.3) for s in ARGS]
+CASES = [(0.25, 0.9), (1.0, 2.9), (1.5, 4.9), (2.0, 6.9), (3.0, 8.9)] if len(sys.argv) < 2 else \
+    [(float(s), float(s) * 3.3) for s in sys.argv[1:]]
 st = torch.cuda.current_stream().cuda_stream
 for cin, cout, H, W, B in SHAPES:
     g = torch.Generator().manual_seed(cin + H)
     x = torch.randn(B * H * W, cin, generator=g).to(torch.bfloat16).to(dev)
     wp, kpad = pack_conv_bf16(torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5, None, None, dev)
     w16 = wp.float().to(torch.float16).contiguous()
-    wfr = wp[:, :9 * cin].reshape(wp.shape[0] // 128, 4, 32, 9, cin // 32, 2, 2, 8).permute(0, 4, 3, 5, 1, 6, 2, 7).float().to(torch.float16).contiguous()
     ws = torch.zeros(max(256, L.m3d_conv_bf16_dcn_ws_bytes(B, H, W) // 4), device=dev, dtype=torch.int32)   # one flag word per pixel tile
     fl = 2.0 * B * H * W * cout * 9 * cin
     for std, clamp in CASES:
@@ -41,8 +39,6 @@ for cin, cout, H, W, B in SHAPES:
             d.dcn_offmask, d.dcn_om_cs = om.data_ptr(), 32
             if patch:
                 d.wgt_f16, d.dcn_ws, d.dcn_ws_bytes = w16.data_ptr(), ws.data_ptr(), ws.numel() * 4
-                if PATCHW:
-                    d.wgt_f16_frag = wfr.data_ptr()
             var = L.m3d_conv_bf16_variant(ctypes.byref(d))
             for _ in range(3):
                 _hip.check(L.m3d_conv_bf16_forward(ctypes.byref(d), st))
