@@ -19,6 +19,20 @@ from .. import _hip
 NMS_MAX_PRE = 16384       # m3d_nms_sorted_dev / m3d_topk_decode: "removed" words and the k sort keys live in LDS
 
 
+def unwrap(net):
+    """The RPN module behind the wrappers the reference's scripts put around it: `nn.DataParallel(net)`
+    (scripts/test_rpn_3d.py:50-51, lib/core.py:73-74) or DistributedDataParallel hand `.module`.  The device detection stage needs
+    the module itself (its packed engine and plan buffers); with one process per GPU (m3dssd_amd.dist) that is also the whole of
+    what the wrapper would have done."""
+    seen = 0
+    while not hasattr(net, "engine") and hasattr(net, "module") and seen < 4:
+        net, seen = net.module, seen + 1
+    if not hasattr(net, "engine"):
+        raise TypeError("expected the RPN module of model.M3d_inference_align.build() (or a DataParallel / DDP wrapper of it), got %s"
+                        % type(net).__name__)
+    return net
+
+
 def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
@@ -113,6 +127,7 @@ def score_keys_planar(eng, plan):
 def detect_device(net, im, conf, top_post=None, scale=None):
     """-> (aboxes [B, n_pre, 14] score-sorted, keep [B, n_pre] int32 positions, num_keep [B] int32), device tensors.
     scale: test-time scale factor(s) of the frames (float, [B] floats or tensor): applied before the NMS."""
+    net = unwrap(net)
     if im.dim() == 3:
         im = im[None]
     dev = next(net.parameters()).device

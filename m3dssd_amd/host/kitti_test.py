@@ -16,7 +16,7 @@ import torch
 
 from ..eval import get_label_annos, get_official_eval_result
 from . import refine as R
-from .detect import detect_batch
+from .detect import detect_batch, unwrap
 
 
 def _unpack(batch, rpn_conf):
@@ -103,6 +103,7 @@ def test_kitti_3d(dataset_test, net, rpn_conf, results_path, test_path, use_log=
     (lib/rpn_util.py:1868-1876) -- a wrong test_path / phase must not look like a successful run without AP;
     require_labels=False writes the result files only and returns (None, None)."""
     os.makedirs(results_path, exist_ok=True)
+    net = unwrap(net)                                      # scripts/test_rpn_3d.py:50-59 passes the nn.DataParallel wrapper
     dev = next(net.parameters()).device
     net.eval()
     bs = max(1, int(getattr(rpn_conf, "batch_size", 1)))

@@ -38,13 +38,14 @@ import numpy as np
 import torch
 
 from . import _hip
-from .host.detect import detect_from_outputs, detect_from_planar, score_keys_planar, select_block
+from .host.detect import detect_from_outputs, detect_from_planar, score_keys_planar, select_block, unwrap
 from .host.refine import p2_arrays
 
 
 class PipelinedDetector:
     def __init__(self, net, conf, batch, height, width, refine=False, score_thresh=0.75, step_r_init=0.3 * math.pi, r_lim=0.01,
                  u8_frame=None, planar=None):
+        net = unwrap(net)                               # (a DataParallel / DDP wrapper of the module, as the reference's scripts pass it)
         self.net, self.conf = net, conf
         self.planar = (os.environ.get("M3D_PIPE_PLANAR", "1") != "0") if planar is None else bool(planar)
         self.u8_frame = None if u8_frame is None else (int(u8_frame[0]), int(u8_frame[1]))

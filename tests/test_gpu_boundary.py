@@ -324,6 +324,43 @@ def test_pipelined_detector_joins_before_the_first_write_of_what_detect_reads():
         pipe._check_no_write_beside_detect()
 
 
+def test_detection_stage_takes_the_data_parallel_wrapper_like_the_reference_script(tmp_path):
+    """scripts/test_rpn_3d.py:50-59 wraps the network in nn.DataParallel and hands THE WRAPPER to test_kitti_3d -> im_detect_3d
+    (lib/rpn_util.py:1439: `net(im)`).  The device detection stage needs the module behind it (engine, plan buffers):
+    im_detect_3d / detect_batch / test_kitti_3d / PipelinedDetector unwrap `.module` and return what the bare module returns."""
+    from model.M3d_inference_align import build
+    from lib.rpn_util import detect_batch, im_detect_3d, test_kitti_3d
+    from m3dssd_amd.config import Conf
+    from m3dssd_amd.pipeline import PipelinedDetector
+    dev = _dev()
+    crop, B = (128, 320), 2
+    conf = synth.synth_conf(crop, 0, batch_size=B, device="cuda:0")
+    net = build(conf, "test")
+    net.load_state_dict(synth.synth_state_dict(0), strict=True)
+    net = net.to(dev)
+    wrapped = nn.DataParallel(net, device_ids=[0])
+    x = synth.synth_frames(B, crop, 5).to(dev)
+    d0, c0 = (t.clone() for t in detect_batch(net, x, conf))
+    d1, c1 = detect_batch(wrapped, x, conf)
+    assert torch.equal(d0, d1) and torch.equal(c0, c1)
+    a = im_detect_3d(x[:1], net, conf)
+    b = im_detect_3d(x[:1], wrapped, conf)
+    assert a.shape[1] == 14 and np.array_equal(a, b)
+    pipe = PipelinedDetector(wrapped, conf, B, crop[0], crop[1])
+    assert pipe.step(x) is None
+    r = pipe.flush()
+    assert torch.equal(r[0], d0) and torch.equal(r[1], c0)
+    p2 = np.array([[721.5377, 0.0, 609.5593, 44.85728], [0.0, 721.5377, 172.854, 0.2163791], [0.0, 0.0, 1.0, 0.002745884],
+                   [0.0, 0.0, 0.0, 1.0]])
+    data = [(x[i:i + 1].cpu(), Conf(id="%06d" % i, p2=p2, scale_factor=1.0)) for i in range(B)]
+    for tag, n in (("bare", net), ("wrapped", wrapped)):
+        test_kitti_3d(data, n, conf, str(tmp_path / tag), str(tmp_path), use_log=False, require_labels=False)
+    for i in range(B):
+        assert open(tmp_path / "bare" / ("%06d.txt" % i)).read() == open(tmp_path / "wrapped" / ("%06d.txt" % i)).read()
+    with pytest.raises(TypeError):
+        detect_batch(nn.Linear(2, 2), x, conf)
+
+
 def test_bench_nccl_refuses_more_ranks_than_devices():
     if torch.cuda.device_count() >= 2:
         pytest.skip("needs a single-device lease")
