@@ -241,6 +241,11 @@ def lib():
             raise RuntimeError(
                 "libm3dssd_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
                 "there is no non-HIP fallback for the M3DSSD hot path" % SO_PATH)
+        # torch first: PyTorch-ROCm ships its own libamdhip64; a library dlopen()ed BEFORE torch binds the system's /opt/rocm copy and
+        # the process ends up with two HIP runtimes -- kernels registered in one, the device initialised in the other ("no
+        # ROCm-capable device is detected" at the first launch; seen with `python __graft_entry__.py smoke` = build() then smoke()
+        # in one process, round 6).  With torch loaded the library's libamdhip64 dependency resolves to the copy torch already mapped.
+        import torch  # noqa: F401
         L = ctypes.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)            # AttributeError if a declared symbol is not exported
