@@ -34,7 +34,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming copy)
 CROP = (384, 1280)
 PER_GPU_BATCH = 8
-MFMA_FAMILIES = ("igemm", "wino", "head_mlp", "conv_wave", "anab_attend", "bf16_conv", "bf16_halo", "bf16_wide", "bf16_anab", "bf16_dcn_patch", "bf16_dcn1x1",
+MFMA_FAMILIES = ("igemm", "wino", "head_mlp", "conv_wave", "anab_attend", "bf16_conv", "bf16_halo", "bf16_wide", "bf16_anab", "bf16_dcn_patch", "bf16_dcn1x1", "bf16_c64",
                  "bf16_head_mlp", "bf16_head2", "bf16_tail2", "bf16_qkvs", "bf16_tree_entry", "bf16_frontend")
 # SURVEY 8d, per image: 105.8 GFLOP; activations 1003.6 MB (fp32) + outputs 21 MB + input 5.9 MB; weights 82.6 MB (fp32) per batch
 ALG_GFLOP_PER_IMAGE = 105.8
@@ -169,6 +169,8 @@ def kernel_symbol(label):
         return "void bf16_frontend2_kernel<2, %s>(Front2Args)" % ("true" if "u8" in label else "false")
     if label.startswith("bf16_frontend"):
         return "bf16_frontend_kernel(FrontArgs)"
+    if label.startswith("bf16_c64"):               # (two instantiations, with / without a residual)
+        return "void bf16_conv3x3_c64_kernel<true>(Bf16Args)"
     if label.startswith("bf16_dcn1x1"):
         return "bf16_dcn1x1_kernel(Bf16Args)"
     if label.startswith("bf16_dcn_patch"):
@@ -210,7 +212,7 @@ def kernel_symbol(label):
 FAMILY_SOURCES = (("bf16_anab", ("bf16_anab.hip",)), ("anab_attend", ("anab_attend.hip",)), ("bf16_head2", ("bf16_head_mlp2.hip",)), ("bf16_tail2", ("bf16_head_mlp2.hip",)), ("bf16_qkvs", ("bf16_head_mlp2.hip",)),
                   ("bf16_tree_entry", ("bf16_tree_entry.hip",)), ("bf16_head_mlp", ("bf16_head_mlp.hip",)),
                   ("bf16_frontend2", ("bf16_frontend2.hip",)), ("bf16_frontend", ("bf16_frontend.hip",)),
-                  ("bf16_dcn1x1", ("bf16_dcn1x1.hip",)), ("bf16_dcn_patch", ("bf16_dcn_patch.hip", "bf16_conv.hip")), ("bf16_wide", ("bf16_conv_wide.hip",)),
+                  ("bf16_dcn1x1", ("bf16_dcn1x1.hip",)), ("bf16_c64", ("bf16_conv_c64.hip",)), ("bf16_dcn_patch", ("bf16_dcn_patch.hip", "bf16_conv.hip")), ("bf16_wide", ("bf16_conv_wide.hip",)),
                   ("bf16_halo", ("bf16_conv.hip",)), ("bf16_conv", ("bf16_conv.hip",)), ("wino44", ("wino44_conv.hip",)),
                   ("wino", ("wino_conv.hip",)), ("conv_wave", ("dcn_wave.hip", "igemm_conv.hip")), ("head_mlp", ("head_mlp.hip",)),
                   ("igemm", ("igemm_conv.hip",)))

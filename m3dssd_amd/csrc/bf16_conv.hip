@@ -597,7 +597,7 @@ static int ilog2_exact(int v)
 }
 
 // Which kernel m3d_conv_bf16_forward runs for a descriptor (m3d_conv_bf16_variant: 3 / 4 = LDS-patch DCNv2 8 / 16 rows, 5 = wave tile,
-// 6 = the 1x1 DCNv2 kernel): 0 = generic implicit-GEMM tile, 1 = halo tile 8 x 16 pixels / 4
+// 6 = the 1x1 DCNv2 kernel, 8 = the persistent 64 -> 64 kernel): 0 = generic implicit-GEMM tile, 1 = halo tile 8 x 16 pixels / 4
 // waves, 2 = halo tile 8 x 32 pixels / 8 waves.  3x3 / stride 1 / pad 1 on a 64-multiple of channels goes to the halo-tile
 // kernel when its patches tile the map well.
 // M3D_BF16_HALO: 0 = generic kernel everywhere, 1 = default choice, 2 = 128-pixel patches only, +16 = identity lane map
@@ -638,6 +638,7 @@ extern "C" int m3d_conv_bf16_variant(const m3d_conv_bf16_desc *d)
         return pv == 16 ? 4 : (pv == 8 ? 3 : 0);
     }
     if (conv_wide_applicable(d)) return 5;
+    if (conv_c64_applicable(d)) return 8;
     return conv_bf16_variant(d, nullptr);
 }
 
@@ -688,6 +689,7 @@ extern "C" int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t s
     const bool deform = d->dcn_offmask != nullptr;
     if (conv_wide_applicable(d)) return launch_conv_wide(a, d, st);      // 128 x 128 wave tiles (bf16_conv_wide.hip)
     if (deform && dcn1x1_applicable(d)) return launch_dcn1x1(a, d, st);  // 1x1 DCNv2 128 -> 128 (center_align; bf16_dcn1x1.hip)
+    if (conv_c64_applicable(d)) return launch_conv_c64(a, d, st);        // 3x3 64 -> 64, persistent workgroups (level2; bf16_conv_c64.hip)
     long long htiles = 0;
     const int variant = conv_bf16_variant(d, &htiles);
     a.lane_perm = (halo_env() & 16) ? 0 : 1;

@@ -57,6 +57,8 @@ struct Bf16Args;
 int launch_dcn_patch(const Bf16Args &a0, const m3d_conv_bf16_desc *d, int variant, hipStream_t st);
 int conv_wide_applicable(const m3d_conv_bf16_desc *d);                                  // bf16_conv_wide.hip
 int launch_conv_wide(const Bf16Args &a, const m3d_conv_bf16_desc *d, hipStream_t st);
+int conv_c64_applicable(const m3d_conv_bf16_desc *d);                                   // bf16_conv_c64.hip
+int launch_conv_c64(const Bf16Args &a, const m3d_conv_bf16_desc *d, hipStream_t st);
 int dcn1x1_applicable(const m3d_conv_bf16_desc *d);                                     // bf16_dcn1x1.hip
 int launch_dcn1x1(const Bf16Args &a, const m3d_conv_bf16_desc *d, hipStream_t st);
 

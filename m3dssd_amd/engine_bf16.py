@@ -370,6 +370,8 @@ class EngineBF16(Engine):
         variant = L.m3d_conv_bf16_variant(ref)          # which kernel the library runs for this descriptor
         if variant == 5:
             kind = "bf16_wide<128,128>"                           # 3x3 with 128-pixel x 128-channel wave tiles
+        elif variant == 8:
+            kind = "bf16_c64"                                     # 3x3 64 -> 64, persistent workgroups, weights resident in LDS (level2)
         elif variant == 6:
             kind = "bf16_dcn1x1"                                  # 1x1 DCNv2 128 -> 128 (center_align; csrc/bf16_dcn1x1.hip)
         elif variant >= 3:

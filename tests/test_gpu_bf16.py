@@ -290,6 +290,34 @@ def test_conv_bf16_wide_tile_matches_torch(case):
         _check(got1, ref1, 0)
 
 
+@pytest.mark.parametrize("n,h,w,act,use_res,res_mode", [(8, 128, 256, 1, True, 0), (9, 96, 320, 1, False, 0), (17, 64, 256, 0, True, 1)])
+def test_conv_bf16_c64_persistent_kernel_matches_torch_and_the_halo_tile(n, h, w, act, use_res, res_mode):
+    """csrc/bf16_conv_c64.hip (3x3 64 -> 64 on persistent workgroups, all weights resident in LDS, next tile's halo in flight; DLA
+    level2) against torch on the bf16-rounded operands, bit for bit against the halo-tile kernel it replaces (a sub-batch with fewer
+    than 1024 tiles runs there: same arithmetic, same K order) and run to run.  Tile counts that do not divide by the workgroups
+    (1 080 = 9 x 12 x 10; 1 088 = 17 x 8 x 8) and exactly four tiles per workgroup (1 024)."""
+    c = co = 64
+    g = torch.Generator().manual_seed(n + h)
+    x = _r(torch.randn(n, c, h, w, generator=g))
+    wt = _r(torch.randn(co, c, 3, 3, generator=g) / (c * 9) ** 0.5)
+    bias = torch.randn(co, generator=g) * 0.1
+    bn = (torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.1, torch.randn(co, generator=g) * 0.1, torch.rand(co, generator=g) + 0.5)
+    res = _r(torch.randn(n, co, h, w, generator=g)) if use_res else None
+    sc = bn[0] / torch.sqrt(bn[3] + 1e-5)
+    conv = F.conv2d(x, wt, None, padding=1)
+    aff = lambda t: t * sc.view(1, -1, 1, 1) + ((bias - bn[2]) * sc + bn[1]).view(1, -1, 1, 1)     # noqa: E731
+    ref = aff(conv + res) if (use_res and res_mode == 1) else (aff(conv) + (res if use_res else 0.0))
+    if act:
+        ref = F.leaky_relu(ref, 0.01)
+    got = _run_conv(x, wt, bias, bn, 1, 1, act, res, res_mode, -1, 0, in_cs=c + 8, variant=8)
+    _check(got, ref, 0)
+    again = _run_conv(x, wt, bias, bn, 1, 1, act, res, res_mode, -1, 0, in_cs=c + 8, variant=8)
+    assert torch.equal(got, again)
+    k = 3                                                        # a sub-batch: < 1024 tiles -> a halo-tile kernel (8 x 16 patches at this size)
+    halo = _run_conv(x[:k], wt, bias, bn, 1, 1, act, None if res is None else res[:k], res_mode, -1, 0, in_cs=c + 8, variant=1)
+    assert torch.equal(got[:k], halo)
+
+
 def test_dcn_bf16_run_to_run_identical():
     """Deformable mode at full-size grids (3840 workgroups, two waves per SIMD): 24 launches on the same operands must agree bit
     for bit.  Sampling code written with compares (v_cmp -> s_and_b64 -> v_cndmask on SGPR lane masks) dropped one corner in
