@@ -241,8 +241,8 @@ int m3d_conv_bf16_forward(const m3d_conv_bf16_desc *d, m3d_stream_t stream);
  * implicit-GEMM kernel is launched behind it and recomputes, on the device, the tiles whose offsets do not fit),
  * 5 = 3x3 with 128 x 128 wave tiles (bf16_conv3x3_wide_kernel; needs wgt_wave),
  * 6 = deformable 1x1, 128 -> 128 channels, bf16 NHWC output (bf16_dcn1x1_kernel: center_align, feturealign_mgpu.py:48-99),
- * 8 = 3x3 64 -> 64 channels on maps of >= 1024 tiles of 8 x 32 pixels, persistent workgroups with the weights resident in LDS
- *     (bf16_conv3x3_c64_kernel: DLA level2; same bits as variant 2). */
+ * 8 = 3x3 64 -> 64 channels on maps that tile 8 x 32 pixels, persistent workgroups with the weights resident in LDS
+ *     (bf16_conv3x3_c64_kernel: DLA level2). */
 /* Bytes of dcn_ws the LDS-patch DCNv2 kernel needs for N x Ho x Wo output pixels (one flag word per pixel tile; 0 = the map does not tile). */
 long long m3d_conv_bf16_dcn_ws_bytes(int N, int Ho, int Wo);
 int m3d_conv_bf16_variant(const m3d_conv_bf16_desc *d);

@@ -11,7 +11,8 @@
 //   * the halo of tile t + 1 is in flight (6 x 16 bytes per thread) while tile t computes, the residual of tile t + 1 while tile t's
 //     output leaves; two barriers per tile (patch free / output tile ready), none per tap;
 //   * tiles are walked in an XCD-contiguous order (the 8 x 32 tiles of one image region share their halo rows in one L2).
-// Same arithmetic and K order as the halo-tile kernel ((chunk, tap, K-step), fp32 accumulation): bit-identical outputs.
+// Every 64 -> 64 3x3 layer whose map tiles 8 x 32 runs here whatever the batch size (batch invariance: one kernel, one fp32
+// summation order -- (tap column, K-step, tap row), not the halo-tile kernel's (tap, K-step)).
 #include "bf16_tile.h"
 
 #define C6_PS 144                         // bytes per halo pixel (128 + 16 pad), as the halo-tile kernel
@@ -150,17 +151,23 @@ __global__ __launch_bounds__(C6_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        // K order (tap column dx, K-step s, tap row dy): the wave's two pixel blocks are two consecutive tile rows, so block 1 at tap
+        // row dy reads the fragment block 0 reads at dy + 1 -- FOUR patch rows per (dx, s) serve the six (block, dy) pairs: 48 pixel
+        // fragment reads per tile and wave instead of 72 (the compute phase is LDS-bound: 1.5 KB of ds_read_b128 per MFMA before).
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int toff = ((tap / 3) * C6_HW + (tap % 3)) * C6_PS;
+        for (int dx = 0; dx < 3; ++dx) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int co = ((2 * s + lh) ^ swk) << 4;
-                const bf16x8 fw = *reinterpret_cast<const bf16x8 *>(Wb + tap * 8192 + co);
-                const bf16x8 f0 = *reinterpret_cast<const bf16x8 *>(Hs + pbase[0] + toff + s * 32);
-                const bf16x8 f1 = *reinterpret_cast<const bf16x8 *>(Hs + pbase[1] + toff + s * 32);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, f0, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, f1, acc[1], 0, 0, 0);
+                bf16x8 fr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fr[r] = *reinterpret_cast<const bf16x8 *>(Hs + pbase[0] + (r * C6_HW + dx) * C6_PS + s * 32);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const bf16x8 fw = *reinterpret_cast<const bf16x8 *>(Wb + (dy * 3 + dx) * 8192 + co);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, fr[dy], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, fr[dy + 1], acc[1], 0, 0, 0);
+                }
             }
         }
         __syncthreads();                                           // A: every wave is done with the patch (and with the previous output tile)
@@ -226,8 +233,7 @@ int conv_c64_applicable(const m3d_conv_bf16_desc *d)
     if (on < 0) { const char *e = getenv("M3D_BF16_C64"); on = e ? atoi(e) : 1; }
     if (!on || d->dcn_offmask || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->groups != 1 || d->wgt_img_stride) return 0;
     if (d->Cin != 64 || d->Cout_pad != 64 || d->Kpad != 576 || d->out_mode != 0 || d->sigmoid_from >= 0) return 0;
-    if (d->W % 32 != 0 || d->H % 8 != 0) return 0;
-    return (long long)d->N * (d->H / 8) * (d->W / 32) >= 1024;    // fewer tiles than four per CU: the halo-tile kernel's grid fills better
+    return d->W % 32 == 0 && d->H % 8 == 0;
 }
 
 int launch_conv_c64(const Bf16Args &a0, const m3d_conv_bf16_desc *d, hipStream_t st)

@@ -293,8 +293,8 @@ def test_conv_bf16_wide_tile_matches_torch(case):
 @pytest.mark.parametrize("n,h,w,act,use_res,res_mode", [(8, 128, 256, 1, True, 0), (9, 96, 320, 1, False, 0), (17, 64, 256, 0, True, 1)])
 def test_conv_bf16_c64_persistent_kernel_matches_torch_and_the_halo_tile(n, h, w, act, use_res, res_mode):
     """csrc/bf16_conv_c64.hip (3x3 64 -> 64 on persistent workgroups, all weights resident in LDS, next tile's halo in flight; DLA
-    level2) against torch on the bf16-rounded operands, bit for bit against the halo-tile kernel it replaces (a sub-batch with fewer
-    than 1024 tiles runs there: same arithmetic, same K order) and run to run.  Tile counts that do not divide by the workgroups
+    level2) against torch on the bf16-rounded operands, run to run, and batch-invariant (a sub-batch = the same bits per image: one
+    kernel for every batch size).  Tile counts that do not divide by the workgroups
     (1 080 = 9 x 12 x 10; 1 088 = 17 x 8 x 8) and exactly four tiles per workgroup (1 024)."""
     c = co = 64
     g = torch.Generator().manual_seed(n + h)
@@ -313,9 +313,11 @@ def test_conv_bf16_c64_persistent_kernel_matches_torch_and_the_halo_tile(n, h, w
     _check(got, ref, 0)
     again = _run_conv(x, wt, bias, bn, 1, 1, act, res, res_mode, -1, 0, in_cs=c + 8, variant=8)
     assert torch.equal(got, again)
-    k = 3                                                        # a sub-batch: < 1024 tiles -> a halo-tile kernel (8 x 16 patches at this size)
-    halo = _run_conv(x[:k], wt, bias, bn, 1, 1, act, None if res is None else res[:k], res_mode, -1, 0, in_cs=c + 8, variant=1)
-    assert torch.equal(got[:k], halo)
+    k = 3                                                        # batch invariance: a sub-batch runs the same kernel, same bits per image
+    sub = _run_conv(x[:k], wt, bias, bn, 1, 1, act, None if res is None else res[:k], res_mode, -1, 0, in_cs=c + 8, variant=8)
+    assert torch.equal(got[:k], sub)
+    # the halo-tile kernel it replaces (M3D_BF16_C64=0) sums the taps in another order: equal to fp32 summation noise, i.e. one bf16 ulp
+    # of the result at a few entries -- checked against torch above, like every other conv kernel
 
 
 def test_dcn_bf16_run_to_run_identical():
