@@ -751,8 +751,11 @@ class Engine:
         key = torch.empty(B, R, device=self.device, dtype=torch.int32)   # monotone score bits (u32)
         plan.named.update(cls=cls, prob=prob, bbox_2d=b2, bbox_3d=b3, score_bits=key)
         assert NC == 4, "bundle kernel is written for 4 classes (bg + 3)"
+        # destination of the four bundled outputs: the plan's own buffers, or -- for one forward -- fresh tensors handed in by
+        # Engine.forward(fresh=True) (RPN.forward returns fresh tensors like the reference: written in place, no copies)
+        dst = plan.named["out_dst"] = [cls, prob, b2, b3]
         self._op(plan, "bundle_outputs", "bundle", lambda st: _hip.check(L.m3d_bundle_outputs(
-            cls_pl.data_ptr(), box_pl.data_ptr(), cls.data_ptr(), prob.data_ptr(), b2.data_ptr(), b3.data_ptr(),
+            cls_pl.data_ptr(), box_pl.data_ptr(), dst[0].data_ptr(), dst[1].data_ptr(), dst[2].data_ptr(), dst[3].data_ptr(),
             key.data_ptr(), B, A, HW, st)), nbytes=B * R * (NC + 11 + 2 * NC + 4 + 7 + 1) * 4)
         plan.feat = (fh, fw)
         return plan
@@ -873,9 +876,26 @@ class Engine:
                 self.plans[key] = self._build_plan(B, H, W)
         return self.plans[key]
 
-    def forward(self, x):
-        """x: float32 [B,3,H,W] on the engine's device -> (cls, prob, bbox_2d, bbox_3d) device tensors
-        (views of plan-owned buffers, overwritten by the next call with the same shape)."""
+    def _run_to(self, plan, fresh):
+        """Run the plan; fresh=True: the four bundled outputs are written into newly allocated tensors (returned), the plan's own
+        output buffers are left as they are; else into the plan-owned buffers (returned as views)."""
+        n = plan.named
+        owned = (n["cls"], n["prob"], n["bbox_2d"], n["bbox_3d"])
+        if not fresh:
+            self.run_plan(plan)
+            return owned
+        dst = n["out_dst"]
+        outs = [torch.empty_like(t) for t in owned]
+        dst[:] = outs
+        try:
+            self.run_plan(plan)
+        finally:
+            dst[:] = owned
+        return tuple(outs)
+
+    def forward(self, x, fresh=False):
+        """x: float32 [B,3,H,W] on the engine's device -> (cls, prob, bbox_2d, bbox_3d) device tensors: views of plan-owned
+        buffers, overwritten by the next call with the same shape, or (fresh=True) newly allocated tensors."""
         if not x.is_cuda:
             raise NotImplementedError("M3DSSD HIP engine: input must be a ROCm device tensor")
         if x.device != self.device:
@@ -885,11 +905,9 @@ class Engine:
         x = x.contiguous()
         plan.named["input_ptr"][0] = x.data_ptr()
         plan.named["input_u8"][0] = 0
-        self.run_plan(plan)
-        n = plan.named
-        return n["cls"], n["prob"], n["bbox_2d"], n["bbox_3d"]
+        return self._run_to(plan, fresh)
 
-    def forward_u8(self, frames, size=None):
+    def forward_u8(self, frames, size=None, fresh=False):
         """frames: uint8 [B, h, w, 3] BGR device tensor (what cv2.imread returns, batched) -> the same outputs as
         forward(Preprocess(frames)): padding to `size` (default conf.crop_size), /255, -mean, /stds, BGR->RGB
         (lib/augmentations.py:472-501, lib/dataloader.py:943-950) happen inside the stem kernel's loads."""
@@ -905,11 +923,9 @@ class Engine:
         frames = frames.contiguous()
         plan.named["input_u8"][:] = [frames.data_ptr(), h, w]
         try:
-            self.run_plan(plan)
+            return self._run_to(plan, fresh)
         finally:
             plan.named["input_u8"][0] = 0
-        n = plan.named
-        return n["cls"], n["prob"], n["bbox_2d"], n["bbox_3d"]
 
     def forward_backbone(self, x):
         """Backbone + DCN up-sampling only (DLASeg.forward): returns the NHWC View of the 128-channel map."""

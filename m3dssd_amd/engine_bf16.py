@@ -719,8 +719,11 @@ class EngineBF16(Engine):
         b3 = torch.empty(B, R, 7, device=self.device, dtype=torch.float32)
         key = torch.empty(B, R, device=self.device, dtype=torch.int32)
         plan.named.update(cls=cls, prob=prob, bbox_2d=b2, bbox_3d=b3, score_bits=key)
+        # destination of the four bundled outputs: the plan's own buffers, or -- for one forward -- fresh tensors handed in by
+        # Engine.forward(fresh=True) (RPN.forward returns fresh tensors like the reference: written in place, no copies)
+        dst = plan.named["out_dst"] = [cls, prob, b2, b3]
         self._op(plan, "bundle_outputs", "bundle", lambda st: _hip.check(L.m3d_bundle_outputs(
-            cls_pl.data_ptr(), box_pl.data_ptr(), cls.data_ptr(), prob.data_ptr(), b2.data_ptr(), b3.data_ptr(),
+            cls_pl.data_ptr(), box_pl.data_ptr(), dst[0].data_ptr(), dst[1].data_ptr(), dst[2].data_ptr(), dst[3].data_ptr(),
             key.data_ptr(), B, A, HW, st)), nbytes=B * R * (NC + 11 + 2 * NC + 4 + 7 + 1) * 4)
         return plan
 

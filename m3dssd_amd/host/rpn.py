@@ -198,13 +198,11 @@ class RPN(nn.Module):
         reference's are: a caller may keep them across iterations.  ``conf.reuse_outputs = True`` (or ``net.reuse_outputs = True``)
         returns views of the engine's plan-owned buffers instead, which the next forward of the same shape overwrites -- the form
         the device detection stage (lib.rpn_util.detect_batch / im_detect_3d, PipelinedDetector) uses internally: it consumes the
-        outputs before the next forward and saves the 4 x [B, N, C] copies (0.17 GB at bs 8)."""
-        out = self._forward_views(x)
-        if self.reuse_outputs:
-            return out
-        return tuple(t.clone() for t in out[:4]) + out[4:]
+        outputs before the next forward.  Fresh outputs cost nothing but their allocation: `m3d_bundle_outputs` writes them in place
+        (round 6; no copies)."""
+        return self._forward_views(x, fresh=not self.reuse_outputs)
 
-    def _forward_views(self, x):
+    def _forward_views(self, x, fresh=False):
         if self.training:
             raise NotImplementedError("m3dssd_amd accelerates inference (eval mode); call .eval() or build(conf, 'test')")
         u8 = x.dtype == torch.uint8 and x.dim() == 4 and x.shape[3] == 3      # raw BGR frames [B, h, w, 3]: the test-time
@@ -216,9 +214,9 @@ class RPN(nn.Module):
             assert feat_h == self.feat_size[0], "x.shape is {}".format(x.shape)
         with torch.no_grad():
             if u8:
-                cls, prob, bbox_2d, bbox_3d = self.engine(x.device).forward_u8(x, size)
+                cls, prob, bbox_2d, bbox_3d = self.engine(x.device).forward_u8(x, size, fresh=fresh)
             else:
-                cls, prob, bbox_2d, bbox_3d = self.engine(x.device).forward(x.float())
+                cls, prob, bbox_2d, bbox_3d = self.engine(x.device).forward(x.float(), fresh=fresh)
         key = (feat_h, feat_w, x.device)
         if getattr(self, "_feat_size_key", None) != key:       # cached: a fresh host->device copy per call would
             self._feat_size_t = torch.tensor([feat_h, feat_w], dtype=torch.float, device=x.device)  # break graph capture
