@@ -849,8 +849,6 @@ def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=N
             if world > 1 and r is not None:
                 return mdist.gather_block(r[0])
             return r
-        timed_step()
-        flush()
     elif use_graph:
         graph = torch.cuda.CUDAGraph()
         cap_stream = torch.cuda.Stream()
@@ -867,9 +865,15 @@ def run_config(args, dtype, steps, batch, rank, world, dev, mdist, dump_layers=N
             if world > 1:
                 return mdist.gather_block(g_block)
             return g_block[:, :-1], g_counts
-        timed_step()
     else:
         timed_step = step
+    # the W untimed warm-up steps, in the launch mode that is timed (graph replays), directly in front of the timed region: the
+    # instrumented eager passes above end in host synchronisations, and a K = 20 region (the driver's command) that starts on a
+    # chip just back from idle read 4 % slower per step than K = 200 (6.10 vs 5.85 ms, round 6)
+    for _ in range(max(1, args.warmup)):
+        timed_step()
+    if flush is not None:
+        flush()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
