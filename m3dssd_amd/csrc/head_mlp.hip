@@ -17,6 +17,15 @@
 
 #include "common.h"
 
+// Phase ablations (M3D_ABLATE_MLP, tools/head_probe.py) exist in the DIAGNOSTIC library only (make trace: -DHEAD_TRACE).  As a runtime
+// flag in the product kernel they put a conditional branch behind every MFMA of the output layer and around every LDS store of the
+// hidden-layer epilogues (round 6, tools/loop_isa_mix.py: 50 single-MFMA basic blocks with 16 v_accvgpr_write each).
+#ifdef HEAD_TRACE
+#define MLP_ABL(bit) (a.ablate & (bit))
+#else
+#define MLP_ABL(bit) false
+#endif
+
 struct MlpArgs {
     const float *in;
     const float *w[3];       // fragment-packed; w[0] may be null (2-layer form: input is the first hidden)
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpBatch batch)
         const unsigned pstep = (unsigned)(RPP * a.in_cs) * 4u;
         f32x4 v[NP];
 #pragma unroll
-        for (int k = 0; k < NP; ++k) v[k] = (a.ablate & 4) ? f32x4{0.f, 0.f, 0.f, 0.f} : buf_load_f32x4(rin, voff, k * pstep);
+        for (int k = 0; k < NP; ++k) v[k] = MLP_ABL(4) ? f32x4{0.f, 0.f, 0.f, 0.f} : buf_load_f32x4(rin, voff, k * pstep);
         float *dst = act + row0 * MLP_LDA + c4 * 4;
 #pragma unroll
         for (int k = 0; k < NP; ++k) *reinterpret_cast<f32x4 *>(dst + k * RPP * MLP_LDA) = v[k];
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpBatch batch)
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const int row = i * 32 + ((r + e) & 3) + 8 * ((r + e) >> 2) + hrow;
-                        if (!(a.ablate & 8)) act[row * MLP_LDA + co] = fmaxf(v[e], lo[e]);   // == leaky(v): 0 < slope < 1
+                        if (!MLP_ABL(8)) act[row * MLP_LDA + co] = fmaxf(v[e], lo[e]);   // == leaky(v): 0 < slope < 1
                     }
                 }
         }
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(const MlpBatch batch)
                     for (int i = 0; i < TMo; ++i)
 #pragma unroll
                         for (int j = 0; j < TNo; ++j)
-                            if (!(a.ablate & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][g][s], fa[i][s], acc[i][j], 0, 0, 0);
+                            if (!MLP_ABL(2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][g][s], fa[i][s], acc[i][j], 0, 0, 0);
             }
         };
         for (int kt = 0; kt < kt3; kt += 2) {

@@ -23,6 +23,14 @@
 
 #include "common.h"
 
+// Phase ablations (M3D_ABLATE, the probe tools) exist in the DIAGNOSTIC library only (make trace): as runtime flags they put uniform
+// branches into the K loops of the product kernels.
+#ifdef IGEMM_TRACE
+#define IG_ABL(bit) (a.ablate & (bit))
+#else
+#define IG_ABL(bit) false
+#endif
+
 struct IgemmArgs {
     const float *in;
     const float *wgt;
@@ -251,11 +259,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
     const int l31 = lane & 31, lh4 = (lane >> 5) * 4;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int buf = (kt - kt_begin) & 1;
-        if (kt + 1 < kt_end && !(a.ablate & 1)) load_tile(kt + 1);
+        if (kt + 1 < kt_end && !IG_ABL(1)) load_tile(kt + 1);
         TRACE();
         const float *Ab = As + buf * BM * LDK + (wm + l31) * LDK + lh4;
         const float *Bb = Bs + buf * BN * LDK + (wn + l31) * LDK + lh4;
-        if (!(a.ablate & 2)) {
+        if (!IG_ABL(2)) {
             // fragment reads are software-pipelined one k-group ahead of the MFMAs that consume them, so the LDS
             // latency hides behind 16*TM*TN/4 MFMAs instead of stalling the (in-order) wave twice per k-tile
             f32x4 fa[2][TM], fb[2][TN];
@@ -291,9 +299,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a)
             }
         }
         TRACE();
-        if (kt + 1 < kt_end && !(a.ablate & 4)) store_tile(buf ^ 1);
+        if (kt + 1 < kt_end && !IG_ABL(4)) store_tile(buf ^ 1);
         TRACE();
-        if (!(a.ablate & 4)) __syncthreads();
+        if (!IG_ABL(4)) __syncthreads();
         TRACE();
     }
 

@@ -21,6 +21,14 @@
 
 #include "common.h"
 
+// Phase ablations (M3D_ABLATE, the probe tools) exist in the DIAGNOSTIC library only (make trace): as runtime flags they put uniform
+// branches into the K loops of the product kernels.
+#ifdef WINO_TRACE
+#define WN_ABL(bit) (a.ablate & (bit))
+#else
+#define WN_ABL(bit) false
+#endif
+
 struct WinoArgs {
     const float *in;
     const float *U;          // [16][Cout_pad/32][Cin/8][64 lanes][4]
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
     // padding; the XOR spreads the 16 tiles of a ds_read_b128 lane group over all 64 banks (conflict-free)
     if (is_loader) {
         // ================================ loader / input-transform waves ======================================
-        if (a.ablate & 16) __builtin_amdgcn_s_setprio(3);
+        if (WN_ABL(16)) __builtin_amdgcn_s_setprio(3);
         const int lt = tid - lt0;
         const int ltile = lt >> 2, lq = lt & 3;
         const int wq = (lq ^ ((ltile >> 2) & 3)) * 4;
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
         };
         auto transform_store = [&](int buf, f32x4 (&d)[16]) {
 #ifdef WINO_TRACE
-            if (a.ablate & 64) {               // diagnostics: LDS writes only (no transform VALU)
+            if (WN_ABL(64)) {               // diagnostics: LDS writes only (no transform VALU)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float *vb = smem + buf * WINO_VBUF + ((r * 4) * WINO_T + ltile) * WINO_BK + wq;
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
                 }
                 float *vb = smem + buf * WINO_VBUF + ((r * 4) * WINO_T + ltile) * WINO_BK + wq;
 #ifdef WINO_TRACE
-                if (a.ablate & 128) {          // diagnostics: transform VALU only (results kept alive, no LDS writes)
+                if (WN_ABL(128)) {          // diagnostics: transform VALU only (results kept alive, no LDS writes)
                     asm volatile("" :: "v"(pk_sub(t[0], t[2])), "v"(pk_add(t[1], t[2])), "v"(pk_sub(t[2], t[1])), "v"(pk_sub(t[1], t[3])));
                     continue;
                 }
@@ -197,9 +205,9 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
         for (int ks = 0; ks < KS; ks += 2) {
             // step ks: produce V(ks+1) from dB, refill dB with patch ks+3
             if (ks + 1 < KS) {
-                if (!(a.ablate & 4)) transform_store((ks + 1) & 1, dB);   // buffer last read in step ks-1 (barrier passed)
+                if (!WN_ABL(4)) transform_store((ks + 1) & 1, dB);   // buffer last read in step ks-1 (barrier passed)
                 TRACE();
-                if (ks + 3 < KS && !(a.ablate & 1)) load_patch(ks + 3, dB);
+                if (ks + 3 < KS && !WN_ABL(1)) load_patch(ks + 3, dB);
             }
             TRACE();
             lds_barrier();
@@ -207,9 +215,9 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
             // step ks+1: produce V(ks+2) from dA, refill dA with patch ks+4
             if (ks + 1 < KS) {
                 if (ks + 2 < KS) {
-                    if (!(a.ablate & 4)) transform_store((ks + 2) & 1, dA);
+                    if (!WN_ABL(4)) transform_store((ks + 2) & 1, dA);
                     TRACE();
-                    if (ks + 4 < KS && !(a.ablate & 1)) load_patch(ks + 4, dA);
+                    if (ks + 4 < KS && !WN_ABL(1)) load_patch(ks + 4, dA);
                 }
                 TRACE();
                 lds_barrier();
@@ -218,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
         }
     } else {
         // ======================================= compute waves ================================================
-        if (a.ablate & 32) __builtin_amdgcn_s_setprio(3);
+        if (WN_ABL(32)) __builtin_amdgcn_s_setprio(3);
         const int kgroups = a.Cin / 8;
         // two U-fragment register sets used alternately (loop unrolled by two, no copies): the loads of step ks+1 are
         // issued before the MFMAs of step ks and only waited for one full step later
@@ -283,16 +291,16 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WinoArgs a)
         lds_barrier();                                     // V(0) visible
         TRACE();
         for (int ks = 0; ks < KS; ks += 2) {
-            if (!(a.ablate & 8)) load_u(min(ks + 1, KS - 1), fbB);
+            if (!WN_ABL(8)) load_u(min(ks + 1, KS - 1), fbB);
             __builtin_amdgcn_sched_barrier(0);             // keep the loads ahead of the MFMAs (the scheduler sinks them)
-            if (!(a.ablate & 2)) compute(0, fbA);
+            if (!WN_ABL(2)) compute(0, fbA);
             TRACE();
             lds_barrier();
             TRACE();
             if (ks + 1 < KS) {
-                if (!(a.ablate & 8)) load_u(min(ks + 2, KS - 1), fbA);
+                if (!WN_ABL(8)) load_u(min(ks + 2, KS - 1), fbA);
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(a.ablate & 2)) compute(1, fbB);
+                if (!WN_ABL(2)) compute(1, fbB);
                 TRACE();
                 lds_barrier();
                 TRACE();
